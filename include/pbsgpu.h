@@ -1,0 +1,235 @@
+/*
+ * include/pbsgpu.h — C ABI of libpbsgpu: the MI355X (gfx950) content-defined
+ * chunker + per-chunk SHA-256 engine.
+ *
+ * This is the drop-in boundary for the reference's pxar stream path. The
+ * reference (pure Go, CGO disabled) reaches the chunker only through the Go
+ * package API of github.com/pbs-plus/pxar v0.34.0 (go.mod:30); the entry
+ * points below are what a cgo binding inside that module's `buzhash` /
+ * `backupproxy` packages would bind (INTEGRATION.md shows the stub). Every
+ * declaration cites the reference interface it stands behind.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int
+ * status (PBSGPU_OK == 0, negative = error, text via pbsgpu_strerror); opaque
+ * handles; no thread-local state — a handle may be used from any OS thread
+ * (cgo calls arrive on arbitrary threads) but calls on ONE handle must be
+ * serialised by the caller, like a Go writer owned by one goroutine
+ * (internal/tapeio/converter.go:672-680). Host memory passed in is never
+ * retained after the call returns (cgo pointer rule): it is copied into
+ * library-owned pinned staging first. Device pointers are borrowed until the
+ * ticket they were submitted under has been collected.
+ *
+ * There is NO CPU fallback: without a usable HIP device every engine call
+ * fails with PBSGPU_E_NO_DEVICE.
+ */
+#ifndef PBSGPU_H
+#define PBSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBSGPU_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------- */
+#define PBSGPU_OK 0
+#define PBSGPU_E_INVALID (-1)      /* bad argument (NULL, not a power of two, ...) */
+#define PBSGPU_E_NO_DEVICE (-2)    /* no HIP device / HIP runtime error at init */
+#define PBSGPU_E_HIP (-3)          /* a HIP call failed (see pbsgpu_last_hip_error) */
+#define PBSGPU_E_NOMEM (-4)        /* host or device allocation failed */
+#define PBSGPU_E_CAPACITY (-5)     /* caller's output buffer too small (needed size reported) */
+#define PBSGPU_E_BUSY (-6)         /* all in-flight slots used: collect a ticket first */
+#define PBSGPU_E_TICKET (-7)       /* unknown / already collected ticket */
+#define PBSGPU_E_DENSITY (-8)      /* candidate density exceeded every retry capacity */
+#define PBSGPU_E_STATE (-9)        /* call not valid in the handle's current state */
+
+const char *pbsgpu_strerror(int status);
+int pbsgpu_abi_version(void);
+/* hipError_t of the most recent failing HIP call on this process (diagnostic). */
+int pbsgpu_last_hip_error(void);
+/* Number of visible HIP devices (0 when there is no GPU / no driver). */
+int pbsgpu_device_count(void);
+
+/* ---- chunker configuration ---------------------------------------------
+ * Mirrors buzhash.NewConfig(avgSize int) (buzhash.Config, error) — reference
+ * call sites internal/pxarmount/commit_orchestrate.go:143-149 and
+ * internal/tapeio/converter.go:248 (both avg = 4 << 20), tests
+ * internal/pxarmount/commit_walk_test.go:25,380 (avg = 4096).
+ * Derived values follow the published Proxmox/casync chunker: window 64,
+ * min = avg/4, max = avg*4, mask = 2*avg-1, break when (h & mask) >= mask-2.
+ * The 256-word table is an INPUT (NULL selects the built-in casync table). */
+typedef struct pbsgpu_config {
+    uint32_t avg;
+    uint32_t min;
+    uint32_t max;
+    uint32_t window;    /* 64 */
+    uint32_t mask;      /* break_test_mask; must be 2^k - 1 */
+    uint32_t break_min; /* break_test_minimum */
+    uint32_t table[256];
+} pbsgpu_config;
+
+/* PBSGPU_E_INVALID unless avg is a power of two in [256, 2^28]
+ * (the error return of buzhash.NewConfig). */
+int pbsgpu_config_init(uint64_t avg, const uint32_t *table, pbsgpu_config *out);
+const uint32_t *pbsgpu_default_table(void);
+
+/* ---- records -------------------------------------------------------------
+ * One record per chunk = one dynamic-index entry: datastore.ChunkInfo{End,
+ * Digest} (internal/pxarmount/commit_reuse.go:105-115) plus the segment it
+ * belongs to and its size (backupproxy.KnownChunkRef{Digest, Size},
+ * commit_reuse.go:316-332). `end` is exclusive and relative to the start of
+ * the record's segment. Records come out ordered by (segment, end). */
+typedef struct pbsgpu_record {
+    uint64_t end;
+    uint8_t digest[32]; /* SHA-256 of the raw chunk bytes (CryptModeNone, commit_orchestrate.go:157) */
+    uint32_t segment;
+    uint32_t size;
+} pbsgpu_record;
+
+/* A segment is one independent stream inside the submitted byte range: fresh
+ * chunker state at `offset`, forced cut at `offset + length`. One segment =
+ * one archive payload stream, or the bytes between two InjectChunks calls
+ * (commit_reuse.go:315-341), or one file of a many-file batch. Segments must
+ * be sorted by offset and must not overlap. */
+typedef struct pbsgpu_segment {
+    uint64_t offset;
+    uint64_t length;
+} pbsgpu_segment;
+
+/* ---- engine ---------------------------------------------------------------
+ * One engine per (process, device): owns HIP streams, device work buffers and
+ * pinned staging. Stands where backupproxy's session holds its chunker +
+ * hasher (constructed from the Config at commit_orchestrate.go:137-149). */
+typedef struct pbsgpu_engine pbsgpu_engine;
+
+/* `device` = HIP ordinal; `inflight` = number of batches that may be in
+ * flight at once (1..8; 0 -> default 2). */
+int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight, pbsgpu_engine **out);
+void pbsgpu_engine_destroy(pbsgpu_engine *eng);
+int pbsgpu_engine_config(const pbsgpu_engine *eng, pbsgpu_config *out);
+
+/* Batch path (the data-parallel form of WriteEntryReader's chunk loop —
+ * internal/pxarmount/commit_reuse.go:457, commit_walk.go:475,
+ * internal/tapeio/converter.go:836): cut every segment, hash every chunk.
+ * `*_device`: bytes already resident in HBM at `dptr` (borrowed until collect).
+ * `*_host`: bytes in host memory, copied H2D through pinned staging.
+ * Asynchronous: returns a ticket as soon as the work is enqueued. */
+int pbsgpu_submit_device(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes,
+                         const pbsgpu_segment *segs, uint32_t nseg, uint64_t *ticket);
+int pbsgpu_submit_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
+                       const pbsgpu_segment *segs, uint32_t nseg, uint64_t *ticket);
+/* Block until the ticket's work is done; report its record count. */
+int pbsgpu_wait(pbsgpu_engine *eng, uint64_t ticket, uint64_t *nrecords);
+/* Wait, copy the records out (PBSGPU_E_CAPACITY + *nrecords if cap is too
+ * small; the ticket stays valid), release the ticket. */
+int pbsgpu_collect(pbsgpu_engine *eng, uint64_t ticket, pbsgpu_record *out, uint64_t cap,
+                   uint64_t *nrecords);
+
+/* Per-stage device time of a finished ticket, from HIP events recorded on the
+ * stream the kernels ran on (milliseconds). */
+typedef struct pbsgpu_timing {
+    float h2d_ms;     /* host->device staging (0 for *_device submits) */
+    float scan_ms;    /* Buzhash candidate kernel */
+    float resolve_ms; /* candidate compaction + min/max resolution */
+    float sha_ms;     /* SHA-256 kernel */
+    float total_ms;   /* first kernel start -> records ready */
+    uint64_t ncandidates;
+    uint64_t nrecords;
+    uint32_t retries; /* density retries taken */
+    uint32_t reserved;
+} pbsgpu_timing;
+int pbsgpu_ticket_timing(pbsgpu_engine *eng, uint64_t ticket, pbsgpu_timing *out);
+
+/* Kernel-level entry used by the parity tests: raw Buzhash candidates of a
+ * flat device byte range, i.e. every END offset e (64 <= e <= nbytes) whose
+ * 64-byte window [e-64, e) satisfies the break test, ascending. Synchronous. */
+int pbsgpu_candidates_device(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes,
+                             uint64_t *out, uint64_t cap, uint64_t *n);
+
+/* ---- upstream-style streaming chunker --------------------------------------
+ * `scan` semantics of the chunker behind buzhash.Config (Proxmox
+ * ChunkerImpl::scan): consume `len` bytes; *pos = 0 when no boundary was
+ * found (everything consumed), else the boundary is after data[*pos - 1] and
+ * only *pos bytes were consumed (state reset). Compatibility path: the scan
+ * itself runs on the GPU but is only efficient for large buffers. */
+typedef struct pbsgpu_chunker pbsgpu_chunker;
+int pbsgpu_chunker_create(pbsgpu_engine *eng, pbsgpu_chunker **out);
+void pbsgpu_chunker_destroy(pbsgpu_chunker *c);
+int pbsgpu_chunker_scan(pbsgpu_chunker *c, const void *data, size_t len, size_t *pos);
+int pbsgpu_chunker_reset(pbsgpu_chunker *c);
+
+/* ---- payload-stream writer ---------------------------------------------------
+ * The seam WriteEntryReader feeds (transfer.ArchiveWriter, mocked at
+ * internal/pxarmount/commit_test.go:33-67): bytes are appended to ONE
+ * continuous stream; finished (end, digest) records become available as the
+ * stream advances. `end` in the records is the absolute stream offset.
+ * `window_bytes` = device batch size (0 -> 256 MiB). */
+typedef struct pbsgpu_stream pbsgpu_stream;
+int pbsgpu_stream_create(pbsgpu_engine *eng, uint64_t window_bytes, pbsgpu_stream **out);
+void pbsgpu_stream_destroy(pbsgpu_stream *s);
+int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len);
+/* Force a cut at the current position (InjectChunks flushes the open chunk:
+ * commit_reuse.go:315-341) and skip `inject_bytes` of injected, already
+ * known chunk payload in the stream offsets. */
+int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes);
+/* End of stream: the tail becomes the final chunk. */
+int pbsgpu_stream_finish(pbsgpu_stream *s);
+/* Pop up to `cap` finished records (in stream order). */
+int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint64_t *n);
+int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *bytes_written);
+
+/* ---- whole-stream SHA-256 batch ---------------------------------------------
+ * verification.HashFile (internal/agent/verification/handler.go:36-68) and
+ * extractFileHash (internal/server/verification/job.go:1273-1303) for many
+ * files at once: digest[i] = SHA-256(base[segs[i].offset .. +length)). */
+int pbsgpu_sha256_many_device(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes,
+                              const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests /* 32*nseg */);
+int pbsgpu_sha256_many_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
+                            const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests);
+
+/* ---- digest-set operations (cross-file duplicate detection) -----------------
+ * Sort records by digest on the device and flag duplicates: dup[i] = 1 when
+ * an earlier record (lower index) carries the same digest. Used on the
+ * all-gathered (digest, size) set of all ranks. */
+typedef struct pbsgpu_dedup_stats {
+    uint64_t nrecords;
+    uint64_t nunique;
+    uint64_t total_bytes;
+    uint64_t unique_bytes;
+} pbsgpu_dedup_stats;
+int pbsgpu_dedup_host(pbsgpu_engine *eng, const pbsgpu_record *recs, uint64_t n, uint8_t *dup /* n, may be NULL */,
+                      pbsgpu_dedup_stats *stats);
+
+/* ---- dynamic index (.didx) encoding ------------------------------------------
+ * On-disk form of the record list: datastore.NewDynamicIndexWriter(ctime)
+ * .Add(end, digest).Finish() / datastore.ParseDynamicIndex
+ * (internal/pxarmount/commit_bottleneck_test.go:773-793,
+ * commit_orchestrate.go:219). 4096-byte header + 40-byte entries. */
+#define PBSGPU_DIDX_HEADER_SIZE 4096u
+int pbsgpu_didx_size(uint64_t nrecords, uint64_t *nbytes);
+int pbsgpu_didx_encode(pbsgpu_engine *eng, const pbsgpu_record *recs, uint64_t n, const uint8_t uuid[16],
+                       int64_t ctime, uint8_t *out, uint64_t cap);
+int pbsgpu_didx_decode(const uint8_t *in, uint64_t nbytes, pbsgpu_record *out, uint64_t cap, uint64_t *n,
+                       int64_t *ctime, uint8_t index_csum[32]);
+
+/* ---- synthetic corpus generator ----------------------------------------------
+ * Fills device memory with the deterministic byte stream the benchmarks and
+ * parity tests use (the oracle has the CPU twin). kind: 0 random, 1 zeros,
+ * 2 repeating 4 KiB block, 3 random with ~30 % zero extents. `stream_off`
+ * and `dptr` must be 8-byte aligned. */
+int pbsgpu_fill_device(pbsgpu_engine *eng, void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed,
+                       uint32_t kind);
+
+/* Library-owned device buffers for callers without their own allocator. */
+int pbsgpu_device_alloc(pbsgpu_engine *eng, uint64_t nbytes, void **dptr);
+int pbsgpu_device_free(pbsgpu_engine *eng, void *dptr);
+int pbsgpu_memcpy_h2d(pbsgpu_engine *eng, void *dptr, const void *hptr, uint64_t nbytes);
+int pbsgpu_memcpy_d2h(pbsgpu_engine *eng, void *hptr, const void *dptr, uint64_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBSGPU_H */

@@ -1,0 +1,19 @@
+"""pbs_plus_amd — MI355X-native content-defined chunker + SHA-256 dedup-hash engine.
+
+Host-side mirror (Python over the C ABI in include/pbsgpu.h) of the interface the
+pbs-plus reference uses for its pxar stream path:
+
+* ``buzhash.NewConfig`` / ``buzhash.Config`` — github.com/pbs-plus/pxar ``buzhash``
+  (reference internal/pxarmount/commit_orchestrate.go:143-149, internal/tapeio/converter.go:248)
+* ``Engine`` — batch cut + digest (the chunk loop behind ``WriteEntryReader``)
+* ``PayloadStream`` — the payload-stream writer seam (``transfer.ArchiveWriter``)
+* ``Chunker`` — upstream-style ``scan`` compatibility
+* ``didx`` / ``dedup`` — dynamic index records and the cross-GPU digest-set reduce
+
+Everything executes in the gfx950 kernels of ``lib/libpbsgpu.so``; there is no CPU path.
+"""
+from . import buzhash  # noqa: F401
+from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401
+from .engine import Chunker, Engine, PayloadStream  # noqa: F401
+
+__all__ = ["buzhash", "Engine", "PayloadStream", "Chunker", "RECORD_DTYPE", "PbsGpuError"]

@@ -1,0 +1,149 @@
+"""ctypes binding of libpbsgpu (the C ABI in include/pbsgpu.h).
+
+Loads the in-tree shared library ``pbs_plus_amd/lib/libpbsgpu.so`` (built by
+``__graft_entry__.build()`` / ``make -C pbs_plus_amd/csrc``). There is no
+fallback of any kind: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpbsgpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK = 0
+E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_CAPACITY, E_BUSY, E_TICKET, E_DENSITY, E_STATE = range(-1, -10, -1)
+
+
+class PbsGpuError(RuntimeError):
+    def __init__(self, status: int, what: str = ""):
+        self.status = status
+        msg = lib().pbsgpu_strerror(status).decode() if _lib is not None else str(status)
+        hip = lib().pbsgpu_last_hip_error() if _lib is not None else 0
+        super().__init__(f"{what}: {msg} (status {status}, hipError {hip})")
+
+
+class Config(C.Structure):
+    """pbsgpu_config — mirrors buzhash.Config (reference commit_orchestrate.go:143-149)."""
+
+    _fields_ = [
+        ("avg", C.c_uint32),
+        ("min", C.c_uint32),
+        ("max", C.c_uint32),
+        ("window", C.c_uint32),
+        ("mask", C.c_uint32),
+        ("break_min", C.c_uint32),
+        ("table", C.c_uint32 * 256),
+    ]
+
+
+class Segment(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("length", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("h2d_ms", C.c_float),
+        ("scan_ms", C.c_float),
+        ("resolve_ms", C.c_float),
+        ("sha_ms", C.c_float),
+        ("total_ms", C.c_float),
+        ("ncandidates", C.c_uint64),
+        ("nrecords", C.c_uint64),
+        ("retries", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class DedupStats(C.Structure):
+    _fields_ = [
+        ("nrecords", C.c_uint64),
+        ("nunique", C.c_uint64),
+        ("total_bytes", C.c_uint64),
+        ("unique_bytes", C.c_uint64),
+    ]
+
+
+# pbsgpu_record: 48 bytes, same layout as a DIDX entry + (segment, size)
+RECORD_DTYPE = np.dtype([("end", "<u8"), ("digest", "u1", (32,)), ("segment", "<u4"), ("size", "<u4")])
+assert RECORD_DTYPE.itemsize == 48
+
+# every symbol include/pbsgpu.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_U64P = C.POINTER(C.c_uint64)
+SYMBOLS = {
+    "pbsgpu_strerror": (C.c_char_p, [C.c_int]),
+    "pbsgpu_abi_version": (C.c_int, []),
+    "pbsgpu_last_hip_error": (C.c_int, []),
+    "pbsgpu_device_count": (C.c_int, []),
+    "pbsgpu_config_init": (C.c_int, [C.c_uint64, _P, C.POINTER(Config)]),
+    "pbsgpu_default_table": (C.POINTER(C.c_uint32), []),
+    "pbsgpu_engine_create": (C.c_int, [C.c_int, C.POINTER(Config), C.c_uint32, C.POINTER(_P)]),
+    "pbsgpu_engine_destroy": (None, [_P]),
+    "pbsgpu_engine_config": (C.c_int, [_P, C.POINTER(Config)]),
+    "pbsgpu_submit_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
+    "pbsgpu_submit_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
+    "pbsgpu_wait": (C.c_int, [_P, C.c_uint64, _U64P]),
+    "pbsgpu_collect": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P]),
+    "pbsgpu_ticket_timing": (C.c_int, [_P, C.c_uint64, C.POINTER(Timing)]),
+    "pbsgpu_candidates_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _U64P]),
+    "pbsgpu_chunker_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "pbsgpu_chunker_destroy": (None, [_P]),
+    "pbsgpu_chunker_scan": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pbsgpu_chunker_reset": (C.c_int, [_P]),
+    "pbsgpu_stream_create": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "pbsgpu_stream_destroy": (None, [_P]),
+    "pbsgpu_stream_write": (C.c_int, [_P, _P, C.c_size_t]),
+    "pbsgpu_stream_cut": (C.c_int, [_P, C.c_uint64]),
+    "pbsgpu_stream_finish": (C.c_int, [_P]),
+    "pbsgpu_stream_poll": (C.c_int, [_P, _P, C.c_uint64, _U64P]),
+    "pbsgpu_stream_position": (C.c_int, [_P, _U64P]),
+    "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
+    "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
+    "pbsgpu_dedup_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(DedupStats)]),
+    "pbsgpu_didx_size": (C.c_int, [C.c_uint64, _U64P]),
+    "pbsgpu_didx_encode": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int64, _P, C.c_uint64]),
+    "pbsgpu_didx_decode": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P, C.POINTER(C.c_int64), _P]),
+    "pbsgpu_fill_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "pbsgpu_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "pbsgpu_device_free": (C.c_int, [_P, _P]),
+    "pbsgpu_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "pbsgpu_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_uint64]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile libpbsgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "-s", "clean"], check=True)
+    subprocess.run(["make", "-C", CSRC, "-s", "-j4", "all"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError = the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != OK:
+        raise PbsGpuError(status, what)

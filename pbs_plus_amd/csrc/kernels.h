@@ -1,0 +1,70 @@
+// Internal launch interface between the engine (host logic) and the gfx950 kernels.
+// Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pbsgpu.h"
+
+namespace pbsk {
+
+// ---- Buzhash candidate scan geometry -------------------------------------------------
+// One wave owns one "wave tile" of 64 lanes x STRIP bytes; STRIP/16 is odd so the
+// per-lane ds_read_b128 of the LDS-staged tile is bank-conflict free.
+constexpr int kScanStrip = 240;                   // bytes per lane
+constexpr int kScanWaves = 8;                     // waves per workgroup (2 per SIMD)
+constexpr int kScanTile = 64 * kScanStrip;        // 15360 bytes per wave tile
+constexpr int kWindow = 64;
+
+struct ScanParams {
+    const uint8_t *data_al;   // 16-byte aligned base (<= caller's pointer)
+    uint32_t lead;            // caller's pointer - data_al (0..15)
+    uint64_t nbytes;          // caller's byte count
+    uint64_t ntiles;          // wave tiles covering [0, nbytes + lead)
+    const uint32_t *table_rot;// device: table pre-rotated left by (32 - bits)
+    uint32_t thr;             // break_min << (32 - bits)
+    uint32_t cap;             // slots per tile
+    uint32_t *tile_cnt;       // [ntiles] true count (may exceed cap)
+    uint32_t *tile_slots;     // [ntiles * cap] end offset within tile (1..kScanTile), a-coords
+};
+
+hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st);
+
+// exclusive scan of min(in[i], clamp) -> out[i]; *total = sum; *maxval = max(in[i]) (atomicMax'd)
+// tmp must hold at least scan_tmp_words(n) uint32.
+size_t scan_tmp_words(uint64_t n);
+hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp, uint32_t *out,
+                                 uint32_t *total, uint32_t *maxval, uint32_t *tmp, hipStream_t st);
+
+// dense, ascending candidate END offsets (caller coordinates) from the per-tile slots
+hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
+                          uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
+                          uint64_t dense_cap, hipStream_t st);
+
+// min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
+hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt,
+                                hipStream_t st);
+hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
+                                pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st);
+
+// SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
+// `queue` is a device uint32 that must be zero at launch.
+hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
+                                 const uint32_t *nrec, uint32_t *queue, int num_cus, hipStream_t st);
+// SHA-256 of whole segments (verification path): digests[32*i] for segs[i]
+hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
+                                  uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);
+
+hipError_t launch_fill(void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed, uint32_t kind,
+                       hipStream_t st);
+
+// digest-set: sort keys/index pairs by the first 8 digest bytes (big-endian) and flag duplicates
+hipError_t launch_dedup(const pbsgpu_record *recs, uint64_t n, uint64_t *keys, uint32_t *idx,
+                        uint64_t *keys_alt, uint32_t *idx_alt, uint8_t *dup, uint64_t *stats4,
+                        void *tmp, size_t tmp_bytes, hipStream_t st);
+size_t dedup_tmp_bytes(uint64_t n);
+
+}  // namespace pbsk

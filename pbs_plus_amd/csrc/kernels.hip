@@ -1,0 +1,700 @@
+// gfx950 (MI355X / CDNA4) kernels of the content-defined chunker + SHA-256 engine.
+//
+// Hot path = the chunk loop behind transfer.ArchiveWriter.WriteEntryReader
+// (reference internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836),
+// i.e. the Buzhash scan + per-chunk SHA-256 of github.com/pbs-plus/pxar v0.34.0
+// parameterised by buzhash.NewConfig (commit_orchestrate.go:143-149). Decomposition
+// (DESIGN.md): (1) candidate scan — every stream position's 64-byte window hash is a
+// pure function of those 64 bytes once chunk_size >= 64, so all positions are tested in
+// parallel, HBM-bound; (2) compaction + min/max resolution over the sparse candidate
+// list; (3) one SHA-256 lane per chunk, lanes pulling chunks from a queue, VALU-bound.
+// Integer/byte work only: no MFMA anywhere.
+#include "kernels.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace pbsk {
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// =====================================================================================
+// (1) Buzhash candidate scan
+// =====================================================================================
+// h(i) = XOR_{k=0..63} rotl(T[b[i-k]], k mod 32). With the running prefix
+// P(i) = rotl(P(i-1),1) ^ T[b[i]] this is h(i) = P(i) ^ P(i-64) (64 = 0 mod 32), so a
+// lane that keeps the last 64 prefixes in registers needs ONE table lookup per byte.
+// The table is pre-rotated by r = 32-bits on the host: rotation commutes with the
+// recurrence, and (h & mask) >= break_min becomes the single unsigned compare
+// rotl(h,r) >= break_min << r, so no AND is needed per byte.
+// LDS: the 256-entry table replicated 32x ([entry][lane&31]) so every lane of a
+// ds_read_b32 group hits its own bank regardless of the data byte.
+template <int S, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int REGION = kWindow + 64 * S;  // bytes staged per wave (halo + tile), multiple of 16
+    static_assert(S % 16 == 0 && ((S / 16) & 1) == 1, "strip must be an odd number of 16-byte slots");
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);  // [256][32]
+    uint8_t *regions = smem + 256 * 32 * 4;
+    uint32_t *counters = reinterpret_cast<uint32_t *>(regions + WAVES * REGION);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 256 * 32; i += WAVES * 64) tab[i] = p.table_rot[i >> 5];
+    __syncthreads();
+
+    uint8_t *reg = regions + wave * REGION;
+    uint32_t *wcnt = counters + wave;
+    const uint32_t *tl = tab + (lane & 31);
+    const uint64_t A = p.nbytes + p.lead;  // extent in aligned ("a") coordinates
+    const uint32_t thr = p.thr;
+
+    for (uint64_t t = (uint64_t)blockIdx.x * WAVES + wave; t < p.ntiles; t += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t wbase = t * (uint64_t)(64 * S);
+        if (lane == 0) *wcnt = 0;
+        // stage [wbase-64, wbase+64*S): coalesced 16-byte pieces, zero outside the buffer
+        constexpr int PIECES = REGION / 16;
+#pragma unroll 4
+        for (int j0 = 0; j0 < PIECES; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < PIECES) {
+                const int64_t a = (int64_t)wbase - kWindow + (int64_t)j * 16;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (a >= 0 && (uint64_t)a < A) v = *reinterpret_cast<const uint4 *>(p.data_al + a);
+                *reinterpret_cast<uint4 *>(reg + j * 16) = v;
+            }
+        }
+        wave_sync();
+
+        const uint8_t *sp = reg + lane * S;
+        uint32_t ring[64];
+        uint32_t P = 0;
+        // warm-up: the 64 bytes before the strip (previous lane's tail / halo)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sp + 16 * g);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                P = __builtin_rotateleft32(P, 1) ^ tl[b * 32];
+                ring[g * 16 + k] = P;
+            }
+        }
+        // one 16-byte group: 16 lookups, 16 window hashes, one rare-path test
+        auto group16 = [&](const int gq /*group index within a 64-byte round: static*/, const uint32_t goff) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(sp + kWindow + goff);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t h[16];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                P = __builtin_rotateleft32(P, 1) ^ tl[b * 32];
+                const int ri = gq * 16 + k;
+                h[k] = P ^ ring[ri];
+                ring[ri] = P;
+                acc = max(acc, h[k]);
+            }
+            if (acc >= thr) {  // rare: at least one of these 16 positions is a candidate
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (h[k] >= thr) {
+                        const uint32_t off = (uint32_t)(lane * S) + goff + (uint32_t)k + 1u;  // exclusive end in tile
+                        const uint64_t ea = wbase + off;
+                        if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
+                            const uint32_t slot = atomicAdd(wcnt, 1u);
+                            if (slot < p.cap) p.tile_slots[t * p.cap + slot] = off;
+                        }
+                    }
+                }
+            }
+        };
+        constexpr int ROUNDS = S / 64, REM = (S % 64) / 16;
+#pragma unroll 1
+        for (int r = 0; r < ROUNDS; ++r) {  // runtime loop keeps the ring indices static and the live set small
+            const uint32_t roff = (uint32_t)r * 64u;
+            group16(0, roff);
+            group16(1, roff + 16u);
+            group16(2, roff + 32u);
+            group16(3, roff + 48u);
+        }
+#pragma unroll
+        for (int g = 0; g < REM; ++g) group16(g, (uint32_t)(ROUNDS * 64 + g * 16));
+        wave_sync();
+        if (lane == 0) p.tile_cnt[t] = *wcnt;
+        wave_sync();
+    }
+}
+
+hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
+    if (p.ntiles == 0) return hipSuccess;
+    constexpr int S = kScanStrip, W = kScanWaves;
+    constexpr size_t lds = 256 * 32 * 4 + (size_t)W * (kWindow + 64 * S) + W * 4 + 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<S, W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    uint64_t blocks = (p.ntiles + W - 1) / W;
+    if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;  // persistent: one workgroup per CU
+    hipLaunchKernelGGL((k_scan<S, W>), dim3((unsigned)blocks), dim3(W * 64), lds, st, p);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// exclusive scan of uint32 counts (three small kernels; inputs are <= a few M entries)
+// =====================================================================================
+constexpr int kScanBlockElems = 1024;  // 256 threads x 4
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix,
+// *block_total gets the sum
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *block_total) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    *block_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t *in, uint64_t n, uint32_t clamp, uint32_t *bsum,
+                                                   uint32_t *maxval) {
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlockElems + (uint64_t)threadIdx.x * 4;
+    uint32_t s = 0, m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) {
+            const uint32_t v = in[base + k];
+            m = max(m, v);
+            s += min(v, clamp);
+        }
+    }
+    uint32_t total;
+    (void)block_excl_scan_256(s, &total);
+    // block max via wave reduce + atomic (rarely contended: one atomic per wave, only if it raises the max)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && maxval && m > 0) atomicMax(maxval, m);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// single block: in-place exclusive scan of bsum[0..nb), total -> *total
+__global__ __launch_bounds__(256) void k_scan_bsums(uint32_t *bsum, uint64_t nb, uint32_t *total) {
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t c = 0; c < nb; c += 256) {
+        const uint64_t i = c + threadIdx.x;
+        const uint32_t v = (i < nb) ? bsum[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_256(v, &tot);
+        const uint32_t carry = carry_s;
+        if (i < nb) bsum[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *in, uint64_t n, uint32_t clamp,
+                                                    const uint32_t *bsum, uint32_t *out) {
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlockElems + (uint64_t)threadIdx.x * 4;
+    uint32_t v[4];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = (base + k < n) ? min(in[base + k], clamp) : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan_256(s, &total) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+}
+
+size_t scan_tmp_words(uint64_t n) { return (size_t)((n + kScanBlockElems - 1) / kScanBlockElems) + 8; }
+
+hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp, uint32_t *out, uint32_t *total,
+                                 uint32_t *maxval, uint32_t *tmp, hipStream_t st) {
+    if (n == 0) return hipMemsetAsync(total, 0, sizeof(uint32_t), st);
+    const uint64_t nb = (n + kScanBlockElems - 1) / kScanBlockElems;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(256), 0, st, in, n, clamp, tmp, maxval);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(256), 0, st, tmp, nb, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, st, in, n, clamp, tmp, out);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// (2a) compaction: per-tile unordered slots -> dense ascending END offsets (caller coords)
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const uint32_t *tile_off,
+                                                 const uint32_t *tile_slots, uint32_t cap, uint64_t ntiles,
+                                                 uint32_t lead, uint64_t *dense, uint64_t dense_cap) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t c = min(tile_cnt[t], cap);
+    if (c == 0) return;
+    const uint32_t *sl = tile_slots + t * cap;
+    const uint64_t base = tile_off[t];
+    const uint64_t tbase = t * (uint64_t)kScanTile;
+    for (uint32_t j = 0; j < c; ++j) {
+        const uint32_t vj = sl[j];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < c; ++i) rank += (sl[i] < vj) ? 1u : 0u;  // offsets within a tile are distinct
+        if (base + rank < dense_cap) dense[base + rank] = tbase + vj - lead;
+    }
+}
+
+hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
+                          uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
+                          uint64_t dense_cap, hipStream_t st) {
+    (void)nbytes;
+    if (ntiles == 0) return hipSuccess;
+    const uint64_t nb = (ntiles + 255) / 256;
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
+                       lead, dense, dense_cap);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// (2b) min/max resolution — one wave per segment walks the sorted candidate list
+// =====================================================================================
+// Serial rule being reproduced (oracle/buzhash_oracle.c shall_break): after a cut at s the
+// next cut is the first end e with (e - s >= max) or (e - s >= max(min, 65) and e is a
+// candidate); the stream end closes the last chunk. The break test only runs in the
+// rolling loop, i.e. from chunk_size 65 on, hence the 65.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const uint32_t *ncand_p,
+                                                 const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
+                                                 uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
+                                                 pbsgpu_record *recs, uint64_t rec_cap) {
+    const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (seg >= nseg) return;
+    const uint64_t n = *ncand_p;
+    const uint64_t A = segs[seg].offset, B = A + segs[seg].length;
+    uint64_t s = A;
+    uint32_t k = 0;
+    const uint64_t rbase = WRITE ? (uint64_t)seg_off[seg] : 0;
+
+    // first candidate index with value >= A + effmin (uniform binary search)
+    uint64_t lo = 0, hi = n;
+    const uint64_t first = A + effmin;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (cands[mid] < first) lo = mid + 1; else hi = mid;
+    }
+    uint64_t wb = lo;  // window base: lane holds cands[wb + lane]
+    uint64_t cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
+
+    while (s < B) {
+        const uint64_t tlo = s + effmin, thi = s + maxsz;
+        uint64_t c;
+        for (;;) {
+            const unsigned long long m = __ballot(cv >= tlo);
+            if (m) {
+                const int j = __ffsll((long long)m) - 1;
+                c = __shfl(cv, j, 64);
+                break;
+            }
+            wb += 64;
+            cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
+        }
+        uint64_t e = (c < thi) ? c : thi;
+        if (e > B) e = B;
+        if (WRITE) {
+            if (lane == 0 && rbase + k < rec_cap) {
+                pbsgpu_record *r = recs + rbase + k;
+                r->end = e - A;
+                r->segment = seg;
+                r->size = (uint32_t)(e - s);
+            }
+        }
+        ++k;
+        s = e;
+    }
+    if (!WRITE && lane == 0) seg_cnt[seg] = k;
+}
+
+hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt, hipStream_t st) {
+    if (nseg == 0) return hipSuccess;
+    const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
+    hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
+                       maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
+                                pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st) {
+    if (nseg == 0) return hipSuccess;
+    const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
+    hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
+                       maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// (3) SHA-256 — one lane per byte range, lanes pull ranges from a queue
+// =====================================================================================
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+__device__ __forceinline__ void sha256_compress(uint32_t (&H)[8], uint32_t (&W)[16]) {
+    constexpr uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        uint32_t w;
+        if (i < 16) {
+            w = W[i];
+        } else {
+            const uint32_t w15 = W[(i + 1) & 15], w2 = W[(i + 14) & 15];
+            const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+            const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            w = W[i & 15] + s0 + W[(i + 9) & 15] + s1;
+            W[i & 15] = w;
+        }
+        const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        const uint32_t ch = g ^ (e & (f ^ g));
+        const uint32_t t1 = h + S1 + ch + K[i] + w;
+        const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        const uint32_t mj = (a & b) | (c & (a | b));
+        const uint32_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    H[0] += a; H[1] += b; H[2] += c; H[3] += d; H[4] += e; H[5] += f; H[6] += g; H[7] += h;
+}
+
+__device__ __forceinline__ void sha256_iv(uint32_t (&H)[8]) {
+    H[0] = 0x6a09e667; H[1] = 0xbb67ae85; H[2] = 0x3c6ef372; H[3] = 0xa54ff53a;
+    H[4] = 0x510e527f; H[5] = 0x9b05688c; H[6] = 0x1f83d9ab; H[7] = 0x5be0cd19;
+}
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// Work source for the SHA kernel: item i -> (byte pointer, length, digest destination)
+struct RecordSource {
+    const uint8_t *data;
+    const pbsgpu_segment *segs;
+    pbsgpu_record *recs;
+    __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
+        const pbsgpu_record *r = recs + i;
+        const uint64_t end = r->end;
+        const uint32_t size = r->size;
+        ptr = data + segs[r->segment].offset + end - size;
+        len = size;
+        dst = recs[i].digest;
+    }
+};
+struct SegmentSource {
+    const uint8_t *data;
+    const pbsgpu_segment *segs;
+    uint8_t *digests;
+    __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
+        ptr = data + segs[i].offset;
+        len = segs[i].length;
+        dst = digests + (uint64_t)i * 32;
+    }
+};
+
+// Each lane streams one byte range through SHA-256. Per loop trip every busy lane consumes
+// one 64-byte block: the raw dwords of the NEXT block are requested before the current
+// block is compressed, so the HBM/L2 latency of a lane's private stream hides behind the
+// ~1700 VALU ops of the compression even with a single wave on the SIMD.
+template <typename Source>
+__global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
+                                               uint32_t *queue) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
+
+    // "next" block descriptor (what R holds / will hold)
+    const uint8_t *base = nullptr;  // start of the lane's byte range
+    uint64_t len = 0;               // its length
+    uint64_t blk = 0, nblk = 0;     // index of the block in R, total blocks incl. padding
+    uint8_t *dst = nullptr;
+    bool have = false;              // R holds a valid block
+    bool exhausted = false;         // queue is empty for this lane
+
+    uint32_t R[17];                 // raw little-endian dwords of the next block (+1 for misalignment)
+    uint32_t sel = 0x00010203u;     // v_perm selector: byte swap + misalignment shift
+#pragma unroll
+    for (int j = 0; j < 17; ++j) R[j] = 0;
+
+    uint32_t H[8];
+    sha256_iv(H);
+
+    // loads block `blk` of (base,len) into R (raw) and sets sel
+    auto load_block = [&]() {
+        const uint64_t off = blk * 64;
+        if (off + 64 <= len) {  // pure data block: aligned dword loads + per-lane funnel selector
+            const uint8_t *p = base + off;
+            const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
+            const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
+            const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+            R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w;
+            R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w;
+            R[8] = v2.x; R[9] = v2.y; R[10] = v2.z; R[11] = v2.w;
+            R[12] = v3.x; R[13] = v3.y; R[14] = v3.z; R[15] = v3.w;
+            R[16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
+            sel = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
+        } else {  // tail / padding block (at most two per range): assemble bytes
+            const uint64_t bits = len * 8;
+            const bool last = (blk + 1 == nblk);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint64_t q = off + (uint64_t)(4 * j + t);
+                    uint32_t byte = 0;
+                    if (q < len) byte = base[q];
+                    else if (q == len) byte = 0x80u;
+                    w |= byte << (8 * t);
+                }
+                R[j] = w;
+            }
+            if (last) {  // big-endian bit length in bytes 56..63 (R is little-endian raw)
+                R[14] = __builtin_bswap32((uint32_t)(bits >> 32));
+                R[15] = __builtin_bswap32((uint32_t)bits);
+            }
+            R[16] = 0;
+            sel = 0x00010203u;
+        }
+    };
+
+    // acquire a new range for lanes that need one
+    auto acquire = [&](bool need) {
+        const unsigned long long m = __ballot(need);
+        if (m == 0) return;
+        uint32_t first = 0;
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(m));
+        first = __shfl(first, leader, 64);
+        if (need) {
+            const uint32_t i = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (i < nitems) {
+                src.get(i, base, len, dst);
+                blk = 0;
+                nblk = (len + 8) / 64 + 1;
+                have = true;
+            } else {
+                exhausted = true;
+                have = false;
+            }
+        }
+    };
+
+    acquire(true);
+    if (have) load_block();
+
+    while (__any(have)) {
+        // current block = R; convert to big-endian message words
+        uint32_t W[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[j + 1], R[j], sel);
+        const bool cur = have;
+        const bool cur_last = have && (blk + 1 == nblk);
+        uint8_t *cur_dst = dst;
+
+        // advance to the next block / next range and request its bytes
+        if (have) {
+            if (!cur_last) ++blk; else have = false;
+        }
+        acquire(!have && !exhausted);
+        if (have) load_block();
+
+        if (cur) sha256_compress(H, W);
+
+        if (cur_last) {
+            uint32_t *o = reinterpret_cast<uint32_t *>(cur_dst);  // digest is 4-byte aligned in both sources
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(H[j]);
+            sha256_iv(H);
+        }
+    }
+}
+
+static inline unsigned sha_grid(int num_cus) { return (unsigned)num_cus * 8u; }  // 2 waves per SIMD
+
+hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
+                                 const uint32_t *nrec, uint32_t *queue, int num_cus, hipStream_t st) {
+    RecordSource src{data, segs, recs};
+    hipLaunchKernelGGL((k_sha256<RecordSource>), dim3(sha_grid(num_cus)), dim3(64), 0, st, src, nrec, 0u, queue);
+    return hipGetLastError();
+}
+
+hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests,
+                                  uint32_t *queue, int num_cus, hipStream_t st) {
+    if (nseg == 0) return hipSuccess;
+    SegmentSource src{data, segs, digests};
+    unsigned grid = sha_grid(num_cus);
+    const unsigned need = (nseg + 63) / 64;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), 0, st, src, (const uint32_t *)nullptr, nseg,
+                       queue);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// synthetic corpus generator (twin of oracle_fill)
+// =====================================================================================
+__device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t fill_word(uint64_t widx, uint64_t seed, uint32_t kind) {
+    switch (kind) {
+    case 0: return splitmix64(seed, widx);
+    case 1: return 0;
+    case 2: return splitmix64(seed, widx & 511u);
+    default: {
+        const uint64_t g = widx >> 13;
+        const uint64_t r = splitmix64(seed ^ 0xA5A5A5A55A5A5A5Aull, g);
+        if ((((r >> 32) * 10u) >> 32) < 3u) return 0;
+        return splitmix64(seed, widx);
+    }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill(uint64_t *dst, uint64_t w0, uint64_t nwords, uint64_t seed,
+                                              uint32_t kind, uint8_t *tail_dst, uint32_t tail_bytes) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride)
+        dst[i] = fill_word(w0 + i, seed, kind);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tail_bytes) {
+        const uint64_t w = fill_word(w0 + nwords, seed, kind);
+        for (uint32_t b = 0; b < tail_bytes; ++b) tail_dst[b] = (uint8_t)(w >> (8 * b));
+    }
+}
+
+hipError_t launch_fill(void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed, uint32_t kind,
+                       hipStream_t st) {
+    if (nbytes == 0) return hipSuccess;
+    const uint64_t nwords = nbytes / 8;
+    const uint32_t tail = (uint32_t)(nbytes & 7u);
+    uint64_t blocks = (nwords + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, st, (uint64_t *)dptr, stream_off >> 3, nwords,
+                       seed, kind, (uint8_t *)dptr + nwords * 8, tail);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// digest-set duplicate detection (cross-file dedup over the all-gathered record set)
+// =====================================================================================
+// Sort (first 8 digest bytes, index) pairs with a stable radix sort, then a record is a
+// duplicate iff an earlier entry of its equal-prefix run carries the same 32-byte digest.
+__global__ __launch_bounds__(256) void k_dedup_keys(const pbsgpu_record *recs, uint64_t n, uint64_t *keys,
+                                                    uint32_t *idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *d = recs[i].digest;
+    uint64_t k = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) k = (k << 8) | d[b];
+    keys[i] = k;
+    idx[i] = (uint32_t)i;
+}
+
+__device__ __forceinline__ bool digest_eq(const pbsgpu_record *a, const pbsgpu_record *b) {
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(a->digest);
+    const uint32_t *y = reinterpret_cast<const uint32_t *>(b->digest);
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) eq &= (x[i] == y[i]);
+    return eq;
+}
+
+__global__ __launch_bounds__(256) void k_dedup_mark(const pbsgpu_record *recs, uint64_t n, const uint64_t *keys,
+                                                    const uint32_t *idx, uint8_t *dup, uint64_t *stats4) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_dup = false;
+    uint64_t size = 0;
+    if (j < n) {
+        const pbsgpu_record *me = recs + idx[j];
+        size = me->size;
+        const uint64_t key = keys[j];
+        for (uint64_t q = j; q > 0 && keys[q - 1] == key; --q) {
+            if (digest_eq(me, recs + idx[q - 1])) {  // stable sort: idx[q-1] < idx[j]
+                is_dup = true;
+                break;
+            }
+        }
+        if (dup) dup[idx[j]] = is_dup ? 1 : 0;
+    }
+    // stats: [0] records, [1] unique, [2] total bytes, [3] unique bytes (wave-reduced atomics)
+    uint64_t c_all = (j < n) ? 1 : 0, c_uni = (j < n && !is_dup) ? 1 : 0;
+    uint64_t b_all = size, b_uni = is_dup ? 0 : size;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        c_all += __shfl_xor(c_all, d, 64);
+        c_uni += __shfl_xor(c_uni, d, 64);
+        b_all += __shfl_xor(b_all, d, 64);
+        b_uni += __shfl_xor(b_uni, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && c_all) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats4 + 0), (unsigned long long)c_all);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats4 + 1), (unsigned long long)c_uni);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats4 + 2), (unsigned long long)b_all);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stats4 + 3), (unsigned long long)b_uni);
+    }
+}
+
+size_t dedup_tmp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                    (uint32_t *)nullptr, (size_t)n, 0, 64, (hipStream_t)0);
+    return bytes + 256;
+}
+
+hipError_t launch_dedup(const pbsgpu_record *recs, uint64_t n, uint64_t *keys, uint32_t *idx, uint64_t *keys_alt,
+                        uint32_t *idx_alt, uint8_t *dup, uint64_t *stats4, void *tmp, size_t tmp_bytes,
+                        hipStream_t st) {
+    hipError_t e = hipMemsetAsync(stats4, 0, 4 * sizeof(uint64_t), st);
+    if (e != hipSuccess || n == 0) return e;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_dedup_keys, dim3(nb), dim3(256), 0, st, recs, n, keys, idx);
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_alt, idx, idx_alt, (size_t)n, 0, 64, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dedup_mark, dim3(nb), dim3(256), 0, st, recs, n, keys_alt, idx_alt, dup, stats4);
+    return hipGetLastError();
+}
+
+}  // namespace pbsk

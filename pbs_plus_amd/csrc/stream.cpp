@@ -1,0 +1,417 @@
+// libpbsgpu host side, part 2: the streaming front ends and the record-set utilities.
+//
+//  * pbsgpu_stream_*  — the payload-stream seam transfer.ArchiveWriter.WriteEntryReader
+//    feeds (reference internal/pxarmount/commit_reuse.go:427-468, commit_walk.go:465-479,
+//    internal/tapeio/converter.go:827-842): bytes are appended to one continuous stream and
+//    (end, digest) records fall out in order, exactly what the module appends to the .didx.
+//  * pbsgpu_chunker_* — upstream `scan(data) -> pos` compatibility (buzhash.Config's chunker).
+//  * pbsgpu_dedup_host — digest-set duplicate detection on the device.
+//  * pbsgpu_didx_*    — dynamic index encode/decode (commit_bottleneck_test.go:773-793).
+// All byte-stream work runs through the same HIP kernels as the batch path.
+#include <deque>
+
+#include "engine_internal.h"
+
+using namespace pbse;
+
+// -------------------------------------------------------------------------------------
+// streaming writer
+// -------------------------------------------------------------------------------------
+struct pbsgpu_stream {
+    pbsgpu_engine *eng = nullptr;
+    uint64_t window = 0;       // new bytes per device batch
+    DevBuf dev[2];             // [carry | new bytes], ping-pong so the carry copy never overlaps
+    int cur = 0;
+    uint64_t carry = 0;        // bytes of the still-open chunk at the front of dev[cur]
+    PinnedBuf pend;            // host bytes not yet shipped
+    uint64_t pend_len = 0;
+    uint64_t base = 0;         // absolute stream offset of dev[cur][0]
+    uint64_t written = 0;      // bytes accepted so far (excludes injected bytes)
+    uint64_t inject_total = 0; // injected bytes skipped in the offsets
+    uint32_t section = 0;      // increments at every forced cut
+    bool finished = false;
+    std::deque<pbsgpu_record> out;
+    std::vector<pbsgpu_record> tmp;
+};
+
+namespace {
+
+// ship pend to the device behind the carry and cut [carry+pend]; when `final` the tail chunk is
+// emitted, otherwise it is carried over (its bytes are re-examined with the next window, which
+// reproduces the serial chunker exactly because a cut only depends on bytes before it)
+int stream_flush(pbsgpu_stream *s, bool final) {
+    pbsgpu_engine *e = s->eng;
+    const uint64_t total = s->carry + s->pend_len;
+    if (total == 0) return PBSGPU_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CHK(set_device(e));
+    Slot *slot = find_free_slot(e);
+    if (!slot) return PBSGPU_E_BUSY;
+    DevBuf &buf = s->dev[s->cur];
+    // capacity was reserved at create time: carry <= max, pend <= window
+    if (s->pend_len) {
+        // pend is pinned and library-owned: copy straight from it (batch_sync below drains the stream)
+        HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + s->carry, s->pend.p, s->pend_len, hipMemcpyHostToDevice,
+                              slot->stream));
+    }
+    uint64_t nrec = 0;
+    pbsgpu_segment seg{0, total};
+    CHK(batch_sync(e, *slot, buf.as<uint8_t>(), total, &seg, 1, &nrec));
+    s->tmp.resize((size_t)nrec);
+    if (nrec) {
+        HIPCHK(hipMemcpyAsync(s->tmp.data(), slot->recs.p, (size_t)nrec * sizeof(pbsgpu_record), hipMemcpyDeviceToHost,
+                              slot->stream));
+        HIPCHK(hipStreamSynchronize(slot->stream));
+    }
+    const uint64_t keep = final ? nrec : (nrec ? nrec - 1 : 0);
+    for (uint64_t i = 0; i < keep; ++i) {
+        pbsgpu_record r = s->tmp[(size_t)i];
+        r.end += s->base;
+        r.segment = s->section;
+        s->out.push_back(r);
+    }
+    if (final || nrec == 0) {
+        s->base += total;
+        s->carry = 0;
+    } else {
+        const pbsgpu_record &open = s->tmp[(size_t)nrec - 1];
+        const uint64_t open_start = open.end - open.size;
+        DevBuf &next = s->dev[s->cur ^ 1];
+        HIPCHK(hipMemcpyAsync(next.p, buf.as<uint8_t>() + open_start, open.size, hipMemcpyDeviceToDevice, slot->stream));
+        HIPCHK(hipStreamSynchronize(slot->stream));
+        s->base += open_start;
+        s->carry = open.size;
+        s->cur ^= 1;
+    }
+    s->pend_len = 0;
+    return PBSGPU_OK;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------
+// upstream-style chunker
+// -------------------------------------------------------------------------------------
+struct pbsgpu_chunker {
+    pbsgpu_engine *eng = nullptr;
+    uint64_t chunk_size = 0;  // bytes consumed since the last cut
+    uint8_t tail[63];         // last bytes consumed (window continuity across calls)
+    uint32_t tail_len = 0;
+    DevBuf dev;
+    PinnedBuf host;
+    std::vector<uint64_t> cands;
+};
+
+namespace {
+
+constexpr size_t kChunkerSlice = 8u << 20;
+
+void chunker_push_tail(pbsgpu_chunker *c, const uint8_t *p, size_t n) {
+    if (n >= 63) {
+        std::memcpy(c->tail, p + n - 63, 63);
+        c->tail_len = 63;
+        return;
+    }
+    const uint32_t keep = std::min<uint32_t>(c->tail_len, (uint32_t)(63 - n));
+    std::memmove(c->tail, c->tail + (c->tail_len - keep), keep);
+    std::memcpy(c->tail + keep, p, n);
+    c->tail_len = keep + (uint32_t)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream **out) {
+    if (!e || !out) return PBSGPU_E_INVALID;
+    *out = nullptr;
+    if (window_bytes == 0) window_bytes = 256ull << 20;
+    if (window_bytes < e->cfg.max) window_bytes = e->cfg.max;
+    pbsgpu_stream *s = new (std::nothrow) pbsgpu_stream();
+    if (!s) return PBSGPU_E_NOMEM;
+    s->eng = e;
+    s->window = window_bytes;
+    int st;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        st = set_device(e);
+        const size_t devcap = (size_t)window_bytes + (size_t)e->cfg.max + 256;
+        if (st == PBSGPU_OK) st = s->dev[0].ensure(devcap);
+        if (st == PBSGPU_OK) st = s->dev[1].ensure(devcap);
+        if (st == PBSGPU_OK) st = s->pend.ensure((size_t)window_bytes);
+    }
+    if (st != PBSGPU_OK) {
+        pbsgpu_stream_destroy(s);
+        return st;
+    }
+    *out = s;
+    return PBSGPU_OK;
+}
+
+void pbsgpu_stream_destroy(pbsgpu_stream *s) {
+    if (!s) return;
+    if (s->eng) {
+        std::lock_guard<std::mutex> lk(s->eng->mu);
+        (void)hipSetDevice(s->eng->device);
+        s->dev[0].release();
+        s->dev[1].release();
+        s->pend.release();
+    }
+    delete s;
+}
+
+int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
+    if (!s || (!data && len)) return PBSGPU_E_INVALID;
+    if (s->finished) return PBSGPU_E_STATE;
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    while (len) {
+        const size_t n = (size_t)std::min<uint64_t>(len, s->window - s->pend_len);
+        std::memcpy(s->pend.as<uint8_t>() + s->pend_len, p, n);
+        s->pend_len += n;
+        s->written += n;
+        p += n;
+        len -= n;
+        if (s->pend_len == s->window) CHK(stream_flush(s, false));
+    }
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->finished) return PBSGPU_E_STATE;
+    CHK(stream_flush(s, true));
+    s->base += inject_bytes;
+    s->inject_total += inject_bytes;
+    s->section++;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_finish(pbsgpu_stream *s) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->finished) return PBSGPU_OK;
+    CHK(stream_flush(s, true));
+    s->finished = true;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint64_t *n) {
+    if (!s || !n || (!out && cap)) return PBSGPU_E_INVALID;
+    uint64_t k = 0;
+    while (k < cap && !s->out.empty()) {
+        out[k++] = s->out.front();
+        s->out.pop_front();
+    }
+    *n = k;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *bytes_written) {
+    if (!s || !bytes_written) return PBSGPU_E_INVALID;
+    *bytes_written = s->written;
+    return PBSGPU_OK;
+}
+
+// ---- chunker ----------------------------------------------------------------------------
+int pbsgpu_chunker_create(pbsgpu_engine *e, pbsgpu_chunker **out) {
+    if (!e || !out) return PBSGPU_E_INVALID;
+    *out = nullptr;
+    pbsgpu_chunker *c = new (std::nothrow) pbsgpu_chunker();
+    if (!c) return PBSGPU_E_NOMEM;
+    c->eng = e;
+    int st;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        st = set_device(e);
+        if (st == PBSGPU_OK) st = c->dev.ensure(kChunkerSlice + 256);
+        if (st == PBSGPU_OK) st = c->host.ensure(kChunkerSlice + 256);
+    }
+    if (st != PBSGPU_OK) {
+        pbsgpu_chunker_destroy(c);
+        return st;
+    }
+    *out = c;
+    return PBSGPU_OK;
+}
+
+void pbsgpu_chunker_destroy(pbsgpu_chunker *c) {
+    if (!c) return;
+    if (c->eng) {
+        std::lock_guard<std::mutex> lk(c->eng->mu);
+        (void)hipSetDevice(c->eng->device);
+        c->dev.release();
+        c->host.release();
+    }
+    delete c;
+}
+
+int pbsgpu_chunker_reset(pbsgpu_chunker *c) {
+    if (!c) return PBSGPU_E_INVALID;
+    c->chunk_size = 0;
+    c->tail_len = 0;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_chunker_scan(pbsgpu_chunker *c, const void *data, size_t len, size_t *pos) {
+    if (!c || !pos || (!data && len)) return PBSGPU_E_INVALID;
+    pbsgpu_engine *e = c->eng;
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    *pos = 0;
+    size_t off = 0;
+    while (off < len) {
+        // no boundary is possible before chunk_size reaches effmin: consume without scanning
+        if (c->chunk_size + 1 < e->effmin) {
+            const size_t skip = (size_t)std::min<uint64_t>(len - off, e->effmin - 1 - c->chunk_size);
+            chunker_push_tail(c, p + off, skip);
+            c->chunk_size += skip;
+            off += skip;
+            continue;
+        }
+        // slice never extends past the forced cut at max
+        const uint64_t to_max = (uint64_t)e->cfg.max - c->chunk_size;  // >= 1
+        const size_t n = (size_t)std::min<uint64_t>(std::min<uint64_t>(len - off, kChunkerSlice - 64), to_max);
+        uint64_t ncand = 0;
+        const uint32_t tl = c->tail_len;
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            CHK(set_device(e));
+            Slot *slot = find_free_slot(e);
+            if (!slot) return PBSGPU_E_BUSY;
+            uint8_t *h = c->host.as<uint8_t>();
+            std::memcpy(h, c->tail, tl);
+            std::memcpy(h + tl, p + off, n);
+            HIPCHK(hipMemcpyAsync(c->dev.p, h, tl + n, hipMemcpyHostToDevice, slot->stream));
+            CHK(candidates_sync(e, *slot, c->dev.as<uint8_t>(), tl + n, &ncand));
+            c->cands.resize((size_t)ncand);
+            if (ncand) HIPCHK(hipMemcpy(c->cands.data(), slot->dense.p, (size_t)ncand * 8, hipMemcpyDeviceToHost));
+        }
+        // first candidate end (in slice coordinates) that satisfies the min rule
+        uint64_t cut = 0;
+        for (uint64_t i = 0; i < ncand; ++i) {
+            const uint64_t endc = c->cands[(size_t)i];  // exclusive end in [tail|slice] coordinates
+            if (endc <= tl) continue;
+            const uint64_t eslice = endc - tl;  // bytes of this slice consumed at the cut
+            if (c->chunk_size + eslice >= e->effmin) {
+                cut = eslice;
+                break;
+            }
+        }
+        if (cut == 0 && n == to_max) cut = n;  // chunk_size reaches max inside this slice
+        if (cut) {
+            c->chunk_size = 0;
+            c->tail_len = 0;
+            *pos = off + (size_t)cut;
+            return PBSGPU_OK;
+        }
+        chunker_push_tail(c, p + off, n);
+        c->chunk_size += n;
+        off += n;
+    }
+    return PBSGPU_OK;
+}
+
+// ---- digest-set duplicate detection ---------------------------------------------------------
+int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, uint8_t *dup,
+                      pbsgpu_dedup_stats *stats) {
+    if (!e || (!recs && n) || !stats) return PBSGPU_E_INVALID;
+    if (n >= (1ull << 32)) return PBSGPU_E_INVALID;
+    std::memset(stats, 0, sizeof(*stats));
+    if (n == 0) return PBSGPU_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CHK(set_device(e));
+    Slot *s = find_free_slot(e);
+    if (!s) return PBSGPU_E_BUSY;
+    const size_t tmp_bytes = pbsk::dedup_tmp_bytes(n);
+    // layout inside slot buffers: recs | keys | keys_alt | idx | idx_alt | dup | stats | tmp
+    CHK(s->recs.ensure((size_t)n * sizeof(pbsgpu_record)));
+    CHK(s->dense.ensure((size_t)n * 16 + 64));
+    CHK(s->tile_slots.ensure((size_t)n * 8 + 64));
+    CHK(s->tile_cnt.ensure((size_t)n + 64));
+    CHK(s->scalars.ensure(SC_COUNT * 4 + 64));
+    CHK(s->scan_tmp.ensure(tmp_bytes));
+    CHK(s->h_scalars.ensure(64));
+    CHK(staged_h2d(e, s->recs.p, recs, n * sizeof(pbsgpu_record), s->stream));
+    uint64_t *keys = s->dense.as<uint64_t>();
+    uint64_t *keys_alt = keys + n;
+    uint32_t *idx = s->tile_slots.as<uint32_t>();
+    uint32_t *idx_alt = idx + n;
+    uint8_t *d_dup = s->tile_cnt.as<uint8_t>();
+    uint64_t *d_stats = reinterpret_cast<uint64_t *>(s->scalars.as<uint8_t>() + 32);
+    HIPCHK(pbsk::launch_dedup(s->recs.as<pbsgpu_record>(), n, keys, idx, keys_alt, idx_alt, d_dup, d_stats,
+                              s->scan_tmp.p, tmp_bytes, s->stream));
+    HIPCHK(hipMemcpyAsync(s->h_scalars.p, d_stats, 32, hipMemcpyDeviceToHost, s->stream));
+    if (dup) HIPCHK(hipMemcpyAsync(dup, d_dup, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const uint64_t *hs = s->h_scalars.as<uint64_t>();
+    stats->nrecords = hs[0];
+    stats->nunique = hs[1];
+    stats->total_bytes = hs[2];
+    stats->unique_bytes = hs[3];
+    return PBSGPU_OK;
+}
+
+// ---- dynamic index (.didx) -----------------------------------------------------------------
+// Proxmox Backup dynamic index layout (the format datastore.ParseDynamicIndex reads):
+//   header, 4096 bytes: magic[8] | uuid[16] | ctime i64 LE | index_csum[32] | reserved
+//   entries, 40 bytes each: end u64 LE | digest[32]
+//   index_csum = SHA-256 over the concatenated entries.
+static const uint8_t kDidxMagic[8] = {28, 145, 78, 165, 25, 186, 179, 205};
+
+int pbsgpu_didx_size(uint64_t nrecords, uint64_t *nbytes) {
+    if (!nbytes) return PBSGPU_E_INVALID;
+    *nbytes = PBSGPU_DIDX_HEADER_SIZE + nrecords * 40;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_didx_encode(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, const uint8_t uuid[16],
+                       int64_t ctime, uint8_t *out, uint64_t cap) {
+    if (!e || (!recs && n) || !out) return PBSGPU_E_INVALID;
+    const uint64_t need = PBSGPU_DIDX_HEADER_SIZE + n * 40;
+    if (cap < need) return PBSGPU_E_CAPACITY;
+    std::memset(out, 0, PBSGPU_DIDX_HEADER_SIZE);
+    std::memcpy(out, kDidxMagic, 8);
+    if (uuid) std::memcpy(out + 8, uuid, 16);
+    for (int i = 0; i < 8; ++i) out[24 + i] = (uint8_t)((uint64_t)ctime >> (8 * i));
+    uint8_t *ent = out + PBSGPU_DIDX_HEADER_SIZE;
+    uint64_t prev = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (recs[i].end < prev) return PBSGPU_E_INVALID;  // one stream, ascending ends
+        prev = recs[i].end;
+        for (int b = 0; b < 8; ++b) ent[i * 40 + b] = (uint8_t)(recs[i].end >> (8 * b));
+        std::memcpy(ent + i * 40 + 8, recs[i].digest, 32);
+    }
+    // index checksum on the device (same SHA-256 kernel as the chunk digests)
+    pbsgpu_segment seg{0, n * 40};
+    return pbsgpu_sha256_many_host(e, ent, n * 40, &seg, 1, out + 32);
+}
+
+int pbsgpu_didx_decode(const uint8_t *in, uint64_t nbytes, pbsgpu_record *out, uint64_t cap, uint64_t *n,
+                       int64_t *ctime, uint8_t index_csum[32]) {
+    if (!in || !n) return PBSGPU_E_INVALID;
+    if (nbytes < PBSGPU_DIDX_HEADER_SIZE || std::memcmp(in, kDidxMagic, 8) != 0) return PBSGPU_E_INVALID;
+    const uint64_t body = nbytes - PBSGPU_DIDX_HEADER_SIZE;
+    if (body % 40) return PBSGPU_E_INVALID;
+    const uint64_t cnt = body / 40;
+    *n = cnt;
+    if (ctime) {
+        uint64_t v = 0;
+        for (int i = 0; i < 8; ++i) v |= (uint64_t)in[24 + i] << (8 * i);
+        *ctime = (int64_t)v;
+    }
+    if (index_csum) std::memcpy(index_csum, in + 32, 32);
+    if (cnt > cap || (!out && cnt)) return PBSGPU_E_CAPACITY;
+    const uint8_t *ent = in + PBSGPU_DIDX_HEADER_SIZE;
+    uint64_t prev = 0;
+    for (uint64_t i = 0; i < cnt; ++i) {
+        uint64_t end = 0;
+        for (int b = 0; b < 8; ++b) end |= (uint64_t)ent[i * 40 + b] << (8 * b);
+        if (end < prev || end - prev > 0xffffffffull) return PBSGPU_E_INVALID;
+        out[i].end = end;
+        std::memcpy(out[i].digest, ent + i * 40 + 8, 32);
+        out[i].segment = 0;
+        out[i].size = (uint32_t)(end - prev);
+        prev = end;
+    }
+    return PBSGPU_OK;
+}
+
+}  // extern "C"

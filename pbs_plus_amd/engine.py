@@ -1,0 +1,288 @@
+"""Engine / PayloadStream / Chunker — thin object wrappers over the C ABI.
+
+Device memory: ``Engine`` accepts raw device pointers (ints), anything exposing
+``data_ptr()``/``numel()``/``element_size()`` (a CUDA/HIP torch tensor) or host
+buffers (bytes / numpy); torch is plumbing only and is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RECORD_DTYPE, Segment, check
+from .buzhash import Config
+
+
+def _segs(segments):
+    if segments is None:
+        return None, 0
+    n = len(segments)
+    arr = (Segment * max(n, 1))(*[Segment(int(o), int(l)) for o, l in segments])
+    return arr, n
+
+
+def _host_view(data) -> np.ndarray:
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+    return np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+class DeviceBuffer:
+    """Library-owned device allocation (for callers without torch)."""
+
+    def __init__(self, eng: "Engine", nbytes: int):
+        self._eng = eng
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(eng._L.pbsgpu_device_alloc(eng._h, self.nbytes, C.byref(p)), "device_alloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            check(self._eng._L.pbsgpu_device_free(self._eng._h, self.ptr), "device_free")
+            self.ptr = None
+
+    def upload(self, data, offset: int = 0):
+        a = _host_view(data)
+        assert offset + a.size <= self.nbytes
+        check(self._eng._L.pbsgpu_memcpy_h2d(self._eng._h, self.ptr + offset, a.ctypes.data, a.size), "memcpy_h2d")
+
+    def download(self, offset: int = 0, nbytes: int | None = None) -> np.ndarray:
+        n = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(n, dtype=np.uint8)
+        check(self._eng._L.pbsgpu_memcpy_d2h(self._eng._h, out.ctypes.data, self.ptr + offset, n), "memcpy_d2h")
+        return out
+
+
+class Engine:
+    """One engine per (process, GPU). Stands where backupproxy's session owns the
+    chunker + hasher built from the buzhash.Config (commit_orchestrate.go:137-149)."""
+
+    def __init__(self, config: Config, device: int = 0, inflight: int = 2):
+        self._L = _lib.lib()
+        self.config = config
+        h = C.c_void_p()
+        check(self._L.pbsgpu_engine_create(int(device), C.byref(config._c), int(inflight), C.byref(h)),
+              "engine_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pbsgpu_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- device memory helpers -------------------------------------------------------------
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def fill(self, dptr: int, nbytes: int, seed: int, kind: int = 0, stream_off: int = 0) -> None:
+        check(self._L.pbsgpu_fill_device(self._h, dptr, stream_off, nbytes, seed, kind), "fill_device")
+
+    @staticmethod
+    def _dev(data, nbytes=None):
+        if isinstance(data, DeviceBuffer):
+            return data.ptr, data.nbytes if nbytes is None else nbytes
+        if _is_device_tensor(data):
+            return data.data_ptr(), data.numel() * data.element_size() if nbytes is None else nbytes
+        if isinstance(data, int):
+            assert nbytes is not None
+            return data, nbytes
+        return None, None
+
+    # ---- batch path ------------------------------------------------------------------------------
+    def submit(self, data, segments=None, nbytes: int | None = None) -> int:
+        """Enqueue cut + digest of every segment; returns a ticket."""
+        segs, nseg = _segs(segments)
+        t = C.c_uint64()
+        ptr, n = self._dev(data, nbytes)
+        if ptr is not None:
+            check(self._L.pbsgpu_submit_device(self._h, ptr, n, segs, nseg, C.byref(t)), "submit_device")
+        else:
+            a = _host_view(data)
+            check(self._L.pbsgpu_submit_host(self._h, a.ctypes.data, a.size, segs, nseg, C.byref(t)), "submit_host")
+        return t.value
+
+    def wait(self, ticket: int) -> int:
+        n = C.c_uint64()
+        check(self._L.pbsgpu_wait(self._h, ticket, C.byref(n)), "wait")
+        return n.value
+
+    def timing(self, ticket: int) -> dict:
+        t = _lib.Timing()
+        check(self._L.pbsgpu_ticket_timing(self._h, ticket, C.byref(t)), "ticket_timing")
+        return {k: getattr(t, k) for k, _ in _lib.Timing._fields_ if k != "reserved"}
+
+    def collect(self, ticket: int) -> np.ndarray:
+        n = self.wait(ticket)
+        out = np.zeros(max(n, 1), dtype=RECORD_DTYPE)
+        got = C.c_uint64()
+        check(self._L.pbsgpu_collect(self._h, ticket, out.ctypes.data, n, C.byref(got)), "collect")
+        return out[: got.value]
+
+    def chunk_and_digest(self, data, segments=None, nbytes: int | None = None) -> np.ndarray:
+        return self.collect(self.submit(data, segments, nbytes))
+
+    def candidates(self, data, nbytes: int | None = None) -> np.ndarray:
+        """Raw Buzhash candidates (ascending END offsets) of a device byte range."""
+        ptr, n = self._dev(data, nbytes)
+        assert ptr is not None, "candidates() wants device memory"
+        cnt = C.c_uint64()
+        st = self._L.pbsgpu_candidates_device(self._h, ptr, n, None, 0, C.byref(cnt))
+        if st == _lib.OK and cnt.value == 0:
+            return np.zeros(0, dtype=np.uint64)
+        if st != _lib.E_CAPACITY:
+            check(st, "candidates_device")
+        out = np.empty(cnt.value, dtype=np.uint64)
+        check(self._L.pbsgpu_candidates_device(self._h, ptr, n, out.ctypes.data, out.size, C.byref(cnt)),
+              "candidates_device")
+        return out[: cnt.value]
+
+    # ---- whole-stream SHA-256 (verification.HashFile for many files) --------------------------------
+    def sha256_many(self, data, segments, nbytes: int | None = None) -> np.ndarray:
+        segs, nseg = _segs(segments)
+        out = np.zeros((max(nseg, 1), 32), dtype=np.uint8)
+        ptr, n = self._dev(data, nbytes)
+        if ptr is not None:
+            check(self._L.pbsgpu_sha256_many_device(self._h, ptr, n, segs, nseg, out.ctypes.data), "sha256_many_device")
+        else:
+            a = _host_view(data)
+            check(self._L.pbsgpu_sha256_many_host(self._h, a.ctypes.data if a.size else None, a.size, segs, nseg,
+                                                  out.ctypes.data), "sha256_many_host")
+        return out[:nseg]
+
+    # ---- digest set ------------------------------------------------------------------------------------
+    def dedup(self, records: np.ndarray):
+        """(dup flags, stats) — dup[i] = 1 when an earlier record has the same digest."""
+        recs = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        dup = np.zeros(max(recs.size, 1), dtype=np.uint8)
+        st = _lib.DedupStats()
+        check(self._L.pbsgpu_dedup_host(self._h, recs.ctypes.data if recs.size else None, recs.size, dup.ctypes.data,
+                                        C.byref(st)), "dedup_host")
+        return dup[: recs.size], {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
+
+    # ---- dynamic index ------------------------------------------------------------------------------
+    def didx_encode(self, records: np.ndarray, uuid: bytes = b"\0" * 16, ctime: int = 0) -> bytes:
+        recs = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        nb = C.c_uint64()
+        check(self._L.pbsgpu_didx_size(recs.size, C.byref(nb)), "didx_size")
+        out = np.zeros(nb.value, dtype=np.uint8)
+        u = (C.c_uint8 * 16).from_buffer_copy(uuid)
+        check(self._L.pbsgpu_didx_encode(self._h, recs.ctypes.data if recs.size else None, recs.size, u, ctime,
+                                         out.ctypes.data, out.size), "didx_encode")
+        return out.tobytes()
+
+
+def didx_decode(blob: bytes):
+    """(records, ctime, index_csum) from a .didx image."""
+    L = _lib.lib()
+    a = np.frombuffer(blob, dtype=np.uint8)
+    n = C.c_uint64()
+    ct = C.c_int64()
+    cs = (C.c_uint8 * 32)()
+    st = L.pbsgpu_didx_decode(a.ctypes.data, a.size, None, 0, C.byref(n), C.byref(ct), cs)
+    if st not in (_lib.OK, _lib.E_CAPACITY):
+        check(st, "didx_decode")
+    out = np.zeros(max(n.value, 1), dtype=RECORD_DTYPE)
+    check(L.pbsgpu_didx_decode(a.ctypes.data, a.size, out.ctypes.data, n.value, C.byref(n), C.byref(ct), cs),
+          "didx_decode")
+    return out[: n.value], ct.value, bytes(cs)
+
+
+class PayloadStream:
+    """The payload-stream seam ``WriteEntryReader`` feeds (transfer.ArchiveWriter,
+    internal/pxarmount/commit_test.go:33-67): append bytes, get (end, digest) records."""
+
+    def __init__(self, eng: Engine, window_bytes: int = 0):
+        self._eng = eng
+        self._L = eng._L
+        h = C.c_void_p()
+        check(self._L.pbsgpu_stream_create(eng._h, window_bytes, C.byref(h)), "stream_create")
+        self._h = h
+
+    def write(self, data) -> None:
+        a = _host_view(data)
+        check(self._L.pbsgpu_stream_write(self._h, a.ctypes.data if a.size else None, a.size), "stream_write")
+
+    def inject(self, nbytes: int = 0) -> None:
+        """Forced cut (InjectChunks flushes the open chunk, commit_reuse.go:315-341)."""
+        check(self._L.pbsgpu_stream_cut(self._h, nbytes), "stream_cut")
+
+    def finish(self) -> None:
+        check(self._L.pbsgpu_stream_finish(self._h), "stream_finish")
+
+    def poll(self, cap: int = 1 << 16) -> np.ndarray:
+        outs = []
+        while True:
+            out = np.zeros(cap, dtype=RECORD_DTYPE)
+            n = C.c_uint64()
+            check(self._L.pbsgpu_stream_poll(self._h, out.ctypes.data, cap, C.byref(n)), "stream_poll")
+            outs.append(out[: n.value])
+            if n.value < cap:
+                break
+        return np.concatenate(outs) if outs else np.zeros(0, dtype=RECORD_DTYPE)
+
+    def position(self) -> int:
+        n = C.c_uint64()
+        check(self._L.pbsgpu_stream_position(self._h, C.byref(n)), "stream_position")
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pbsgpu_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Chunker:
+    """Upstream-style streaming chunker: ``scan(data) -> pos`` (0 = no boundary yet)."""
+
+    def __init__(self, eng: Engine):
+        self._eng = eng
+        self._L = eng._L
+        h = C.c_void_p()
+        check(self._L.pbsgpu_chunker_create(eng._h, C.byref(h)), "chunker_create")
+        self._h = h
+
+    def scan(self, data) -> int:
+        a = _host_view(data)
+        pos = C.c_size_t()
+        check(self._L.pbsgpu_chunker_scan(self._h, a.ctypes.data if a.size else None, a.size, C.byref(pos)),
+              "chunker_scan")
+        return pos.value
+
+    def reset(self) -> None:
+        check(self._L.pbsgpu_chunker_reset(self._h), "chunker_reset")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pbsgpu_chunker_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

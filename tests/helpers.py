@@ -1,0 +1,57 @@
+"""Test helpers: a numpy model of the engine's resolve rule and golden-fixture I/O."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def resolve_model(cands, seg_len, cmin, cmax):
+    """Python statement of kernels.hip k_resolve: given ascending candidate END offsets of one
+    stream, apply the min/max rules. Must equal the serial chunker on every input."""
+    effmin = max(cmin, 65)
+    cands = np.asarray(cands, dtype=np.uint64)
+    ends = []
+    s = 0
+    while s < seg_len:
+        tlo, thi = s + effmin, s + cmax
+        j = int(np.searchsorted(cands, tlo, side="left"))
+        c = int(cands[j]) if j < cands.size else None
+        e = c if (c is not None and c < thi) else thi
+        e = min(e, seg_len)
+        ends.append(e)
+        s = e
+    return np.asarray(ends, dtype=np.uint64)
+
+
+def records_equal(a, b):
+    if a.shape != b.shape:
+        return False
+    return (np.array_equal(a["end"], b["end"]) and np.array_equal(a["segment"], b["segment"])
+            and np.array_equal(a["size"], b["size"]) and np.array_equal(a["digest"], b["digest"]))
+
+
+def describe_mismatch(got, want, limit=5):
+    lines = [f"got {got.size} records, want {want.size}"]
+    n = min(got.size, want.size)
+    bad = [i for i in range(n) if got["end"][i] != want["end"][i] or got["segment"][i] != want["segment"][i]
+           or not np.array_equal(got["digest"][i], want["digest"][i])][:limit]
+    for i in bad:
+        lines.append(f"  [{i}] got seg={got['segment'][i]} end={got['end'][i]} size={got['size'][i]} "
+                     f"dig={bytes(got['digest'][i]).hex()[:16]} | want seg={want['segment'][i]} end={want['end'][i]} "
+                     f"size={want['size'][i]} dig={bytes(want['digest'][i]).hex()[:16]}")
+    return "\n".join(lines)
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN_DIR, name)) as f:
+        return json.load(f)
+
+
+def golden_records(case, dtype):
+    out = np.zeros(len(case["records"]), dtype=dtype)
+    for i, (seg, end, size, dig) in enumerate(case["records"]):
+        out[i]["segment"], out[i]["end"], out[i]["size"] = seg, end, size
+        out[i]["digest"] = np.frombuffer(bytes.fromhex(dig), dtype=np.uint8)
+    return out

@@ -1,0 +1,308 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle — bit-exact, integer
+work. Mirrors how the reference's tests drive the module: buzhash.NewConfig(4096) stores
+(internal/pxarmount/commit_walk_test.go:25) and the production avg 4 << 20
+(commit_orchestrate.go:144). Edge cases: empty / tiny / ragged segments, min == window,
+zero runs (max-size cuts), misaligned buffers, dense candidates."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import describe_mismatch, golden_records, load_golden, records_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines(gpu_lib):
+    from pbs_plus_amd import Engine, buzhash
+
+    cache = {}
+
+    def get(avg):
+        if avg not in cache:
+            cache[avg] = Engine(buzhash.NewConfig(avg), device=0, inflight=2)
+        return cache[avg]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def dev_fill(eng, segs):
+    """device buffer holding the concatenated synthetic segments [(seed, kind, n)], 8-byte aligned starts"""
+    table, off = [], 0
+    for _, _, n in segs:
+        table.append((off, n))
+        off += (n + 7) & ~7
+    buf = eng.alloc(max(off, 8))
+    for (seed, kind, n), (o, _) in zip(segs, table):
+        if n:
+            eng.fill(buf.ptr + o, n, seed, kind)
+    return buf, table, off
+
+
+def host_twin(O, segs, table, total):
+    out = np.zeros(max(total, 8), dtype=np.uint8)
+    for (seed, kind, n), (o, _) in zip(segs, table):
+        if n:
+            out[o:o + n] = O.fill(n, seed, kind)
+    return out
+
+
+def test_device_fill_matches_oracle_fill(engines, O):
+    eng = engines(4096)
+    for kind in range(4):
+        n = (1 << 20) + 13
+        buf = eng.alloc(n + 8)
+        eng.fill(buf.ptr, n, 42 + kind, kind, stream_off=4096)
+        got = buf.download(0, n)
+        assert np.array_equal(got, O.fill(n, 42 + kind, kind, stream_off=4096)), kind
+        buf.free()
+
+
+@pytest.mark.parametrize("avg,n,kind", [(4096, 1 << 20, 0), (4096, (3 << 20) + 17, 3), (256, 300_000, 0),
+                                        (65536, 16 << 20, 0), (4 << 20, 64 << 20, 0), (4096, 700_001, 2)])
+def test_candidates_match_oracle(engines, O, avg, n, kind):
+    """Kernel K1 alone: every window-hash candidate, ascending."""
+    eng = engines(avg)
+    buf, table, total = dev_fill(eng, [(7 + avg % 97, kind, n)])
+    got = eng.candidates(buf, n)
+    want = O.candidates(O.new_config(avg), O.fill(n, 7 + avg % 97, kind))
+    buf.free()
+    assert got.size == want.size, (got.size, want.size, got[:5], want[:5])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("lead", [1, 3, 8, 15])
+def test_candidates_misaligned_base(engines, O, lead):
+    eng = engines(4096)
+    n = 500_000
+    host = O.fill(n, 5)
+    buf = eng.alloc(n + 64)
+    buf.upload(host, offset=lead)
+    got = eng.candidates(buf.ptr + lead, n)
+    buf.free()
+    assert np.array_equal(got, O.candidates(O.new_config(4096), host))
+
+
+CASES = [
+    ("single_4k", 4096, [(1, 0, 1 << 20)]),
+    ("ragged_4k", 4096, [(2, 0, 300_000), (3, 1, 70_000), (4, 2, 200_001), (5, 3, 400_003), (6, 0, 17), (7, 0, 0),
+                         (8, 0, 1024), (9, 0, 1089), (10, 0, 63), (11, 0, 64), (12, 0, 65), (13, 0, 1)]),
+    ("min_eq_window", 256, [(14, 0, 200_000), (15, 1, 5000)]),
+    ("avg64k", 65536, [(16, 0, 12 << 20), (17, 3, 5 << 20)]),
+    ("avg4m_prod", 4 << 20, [(18, 0, 96 << 20)]),
+    ("avg4m_zero_max_cuts", 4 << 20, [(19, 1, (40 << 20) + 5), (20, 3, 40 << 20)]),
+    ("many_small", 4096, [(100 + i, i % 4, 1000 + 997 * i) for i in range(150)]),
+]
+
+
+@pytest.mark.parametrize("name,avg,segs", CASES, ids=[c[0] for c in CASES])
+def test_chunk_and_digest_matches_oracle(engines, O, name, avg, segs):
+    eng = engines(avg)
+    buf, table, total = dev_fill(eng, segs)
+    got = eng.chunk_and_digest(buf, table, nbytes=max(total, 8))
+    want = O.chunk_and_digest(O.new_config(avg), host_twin(O, segs, table, total), table)
+    buf.free()
+    assert records_equal(got, want), describe_mismatch(got, want)
+
+
+def test_host_submit_equals_device_submit(engines, O):
+    eng = engines(4096)
+    data = O.fill(2_000_003, 31)
+    got = eng.chunk_and_digest(data, [(0, 1_000_000), (1_000_001, 1_000_002)])
+    want = O.chunk_and_digest(O.new_config(4096), data, [(0, 1_000_000), (1_000_001, 1_000_002)])
+    assert records_equal(got, want), describe_mismatch(got, want)
+    # default: the whole buffer is one stream
+    got = eng.chunk_and_digest(data)
+    want = O.chunk_and_digest(O.new_config(4096), data)
+    assert records_equal(got, want), describe_mismatch(got, want)
+
+
+def test_misaligned_chunk_starts_hash_correctly(engines):
+    """Chunk starts land on arbitrary byte offsets: the per-lane funnel loads must handle all
+    four alignments; digests checked against hashlib independently of the oracle."""
+    eng = engines(4096)
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 256, 400_000, dtype=np.uint8)
+    for lead in (0, 1, 2, 3, 5):
+        buf = eng.alloc(data.size + 64)
+        buf.upload(data, offset=lead)
+        recs = eng.chunk_and_digest(buf.ptr + lead, [(0, data.size)], nbytes=data.size)
+        buf.free()
+        start = 0
+        for r in recs:
+            assert bytes(r["digest"]) == hashlib.sha256(data[start:int(r["end"])].tobytes()).digest(), (lead, start)
+            start = int(r["end"])
+        assert start == data.size
+
+
+def test_golden_fixture_on_gpu(engines, O):
+    g = load_golden("chunks_v1.json")
+    from pbs_plus_amd import RECORD_DTYPE
+
+    for case in g["cases"]:
+        eng = engines(case["avg"])
+        if case["segments"] == "le_u32_counter_262144":
+            data = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
+            got = eng.chunk_and_digest(data)
+        else:
+            segs = [(s["seed"], s["kind"], s["length"]) for s in case["segments"]]
+            # golden segments are packed back to back (no alignment padding): build on the host
+            parts, table, off = [], [], 0
+            for seed, kind, n in segs:
+                parts.append(O.fill(n, seed, kind))
+                table.append((off, n))
+                off += n
+            got = eng.chunk_and_digest(np.concatenate(parts), table)
+        want = golden_records(case, RECORD_DTYPE)
+        assert records_equal(got, want), case["name"] + "\n" + describe_mismatch(got, want)
+
+
+def test_sha256_many_all_padding_lengths(engines):
+    """verification.HashFile for many files at once (handler.go:36-68): every padding case."""
+    eng = engines(4096)
+    rng = np.random.default_rng(4)
+    lens = list(range(0, 200)) + [255, 256, 257, 4095, 4096, 65537, 1_000_003]
+    blob = rng.integers(0, 256, sum(lens) + 16, dtype=np.uint8)
+    segs, off = [], 0
+    for n in lens:
+        segs.append((off, n))
+        off += n
+    got = eng.sha256_many(blob, segs)
+    for (o, n), d in zip(segs, got):
+        assert bytes(d) == hashlib.sha256(blob[o:o + n].tobytes()).digest(), n
+
+
+def test_pipelined_tickets(engines, O):
+    """Two batches in flight on separate slots/streams give the same answers as one at a time."""
+    eng = engines(65536)
+    a, b = O.fill(9 << 20, 61), O.fill(7 << 20, 62, 3)
+    ta, tb = eng.submit(a), eng.submit(b)
+    from pbs_plus_amd import PbsGpuError
+
+    with pytest.raises(PbsGpuError):
+        eng.submit(a)  # both slots busy
+    rb, ra = eng.collect(tb), eng.collect(ta)
+    cfg = O.new_config(65536)
+    assert records_equal(ra, O.chunk_and_digest(cfg, a)) and records_equal(rb, O.chunk_and_digest(cfg, b))
+    with pytest.raises(PbsGpuError):
+        eng.collect(ta)
+
+
+def test_dense_candidates_force_capacity_retry(engines, O):
+    """A 64-byte-periodic input makes the window hash periodic: either no candidates or a hit
+    every period. Search a period that hits, then check the density-retry path."""
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(123)
+    for _ in range(4000):
+        block = rng.integers(0, 256, 64, dtype=np.uint8)
+        if O.candidates(cfg, np.tile(block, 4)).size:
+            break
+    else:
+        pytest.skip("no dense pattern found")
+    data = np.tile(block, 20_000)  # 1.28 MB, a candidate at least every 64 bytes
+    assert O.candidates(cfg, data).size >= 19_000
+    t = eng.submit(data)
+    got = eng.collect(t)
+    want = O.chunk_and_digest(cfg, data)
+    assert records_equal(got, want), describe_mismatch(got, want)
+
+
+def test_payload_stream_equals_batch(engines, O):
+    """PayloadStream (WriteEntryReader seam): windows + carry-over reproduce one-shot cutting."""
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    data = O.fill(1_300_007, 71, 3)
+    ps = PayloadStream(eng, window_bytes=1 << 16)  # small windows: many flushes with carry
+    rng = np.random.default_rng(2)
+    pos = 0
+    while pos < data.size:
+        n = int(rng.integers(1, 90_000))
+        ps.write(data[pos:pos + n])
+        pos += n
+    ps.finish()
+    got = ps.poll()
+    want = O.chunk_and_digest(cfg, data)
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    assert ps.position() == data.size
+    ps.close()
+
+
+def test_payload_stream_inject_forces_cut(engines, O):
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    a, b = O.fill(250_000, 81), O.fill(99_999, 82)
+    ps = PayloadStream(eng, window_bytes=1 << 17)
+    ps.write(a)
+    ps.inject(5_000_000)  # known chunks spliced in: open chunk is flushed, offsets skip ahead
+    ps.write(b)
+    ps.finish()
+    got = ps.poll()
+    ra, rb = O.chunk_and_digest(cfg, a), O.chunk_and_digest(cfg, b)
+    assert np.array_equal(got["end"], np.concatenate([ra["end"], rb["end"] + np.uint64(a.size + 5_000_000)]))
+    assert np.array_equal(got["digest"], np.concatenate([ra["digest"], rb["digest"]]))
+    assert got["segment"].tolist() == [0] * ra.size + [1] * rb.size
+    ps.close()
+
+
+def test_chunker_scan_semantics(engines, O):
+    """Upstream `scan`: whole-buffer feeds and small feeds give the oracle's boundaries."""
+    from pbs_plus_amd import Chunker
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    data = O.fill(600_000, 91)
+    want = O.chunk_stream(cfg, data)
+    for step in (data.size, 50_000, 4097):
+        ch = Chunker(eng)
+        ends, pos = [], 0
+        while pos < data.size:
+            n = min(step, data.size - pos)
+            off = 0
+            while off < n:
+                k = ch.scan(data[pos + off:pos + n])
+                if k == 0:
+                    break
+                off += k
+                ends.append(pos + off)
+            pos += n
+        if not ends or ends[-1] != data.size:
+            ends.append(data.size)
+        assert np.array_equal(np.asarray(ends, dtype=np.uint64), want), step
+        ch.close()
+
+
+def test_dedup_and_didx(engines, O):
+    from pbs_plus_amd.engine import didx_decode
+
+    eng = engines(4096)
+    base = O.fill(400_000, 95)
+    data = np.concatenate([base, O.fill(100_000, 96), base])  # third segment duplicates the first
+    segs = [(0, 400_000), (400_000, 100_000), (500_000, 400_000)]
+    recs = eng.chunk_and_digest(data, segs)
+    dup, stats = eng.dedup(recs)
+    n0 = int((recs["segment"] == 0).sum())
+    seen, want_dup = set(), []
+    for r in recs:
+        d = bytes(r["digest"])
+        want_dup.append(1 if d in seen else 0)
+        seen.add(d)
+    assert dup.tolist() == want_dup
+    assert sum(want_dup) >= n0 - 1
+    assert stats["nrecords"] == recs.size and stats["nunique"] == len(seen)
+    assert stats["total_bytes"] == data.size
+    assert stats["unique_bytes"] == int(recs["size"][dup == 0].sum())
+    # dynamic index of the first segment
+    r0 = recs[recs["segment"] == 0]
+    blob = eng.didx_encode(r0, uuid=bytes(range(16)), ctime=1_700_000_123)
+    back, ctime, csum = didx_decode(blob)
+    assert ctime == 1_700_000_123 and np.array_equal(back["end"], r0["end"]) and np.array_equal(back["digest"], r0["digest"])
+    assert csum == hashlib.sha256(blob[4096:]).digest()
+    assert blob[8:24] == bytes(range(16))

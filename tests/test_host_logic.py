@@ -1,0 +1,86 @@
+"""Host-side logic that runs without a GPU: segment sharding for the multi-GPU path and the
+world_size-2 digest-set exchange over gloo (the RCCL path on the GPU box uses the same code
+with backend nccl)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_segments_balanced_and_complete():
+    from pbs_plus_amd.dist import shard_segments
+
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1, 1 << 26, 1000)
+    for ws in (1, 2, 4, 8):
+        shards = shard_segments(lens, ws)
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(1000))
+        loads = [int(lens[s].sum()) for s in shards]
+        assert max(loads) - min(loads) <= int(lens.max())
+        assert all(s == sorted(s) for s in shards)
+    assert shard_segments([5, 5], 4) == [[0], [1], [], []]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from pbs_plus_amd import RECORD_DTYPE
+    from pbs_plus_amd.dist import allgather_records, shard_segments
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        lens = [1000 + 37 * i for i in range(11)]
+        mine = shard_segments(lens, ws)[rank]
+        recs = np.zeros(len(mine) + rank, dtype=RECORD_DTYPE)  # ragged on purpose (rank 0 may differ)
+        for j, seg in enumerate(mine):
+            recs[j]["segment"], recs[j]["end"], recs[j]["size"] = seg, lens[seg], lens[seg]
+            recs[j]["digest"][:] = seg % 5  # duplicates across ranks
+        for j in range(len(mine), recs.size):
+            recs[j]["segment"], recs[j]["size"] = 1000 + rank, 1
+            recs[j]["digest"][:] = 200 + rank
+        allr = allgather_records(recs)
+        q.put((rank, allr.tobytes(), recs.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_records_world_size_2_gloo():
+    import torch.multiprocessing as mp
+
+    from pbs_plus_amd import RECORD_DTYPE
+
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    all0 = np.frombuffer(got[0][1], dtype=RECORD_DTYPE)
+    all1 = np.frombuffer(got[1][1], dtype=RECORD_DTYPE)
+    assert all0.tobytes() == all1.tobytes()  # every rank sees the same global set
+    local = [np.frombuffer(g[2], dtype=RECORD_DTYPE) for g in got]
+    assert all0.tobytes() == np.concatenate(local).tobytes()  # rank order, nothing lost or padded in
+    segs = sorted(int(s) for s in all0["segment"] if s < 1000)
+    assert segs == list(range(11))
+    # duplicate structure the device dedup must find: digests seg%5 -> 5 unique among the 11
+    uniq = {bytes(d) for d in all0["digest"]}
+    assert len(uniq) == 5 + 1  # + rank 1's filler record

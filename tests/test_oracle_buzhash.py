@@ -1,0 +1,167 @@
+"""Pins the oracle's Buzhash chunker (oracle/buzhash_oracle.c).
+
+PARITY UNPINNED vs github.com/pbs-plus/pxar v0.34.0 (absent from /root/reference; the
+reference's own tests pin no boundary — SURVEY.md §8c). What is checked here:
+ * parameter derivation of buzhash.NewConfig (reference commit_orchestrate.go:143-149 fixes
+   only avg = 4 << 20; commit_walk_test.go:25 uses 4096),
+ * the invariant upstream's own chunker test checks: 1-byte feeds == whole-buffer feeds,
+ * chunk sizes recalled from upstream Proxmox's chunker test on its LE-u32-counter buffer
+   (hash-determined, so they corroborate table + scan semantics),
+ * structural properties (min/max, zero runs) and the candidate/resolve decomposition the
+   GPU engine relies on,
+ * the committed golden fixture tests/golden/chunks_v1.json.
+"""
+import numpy as np
+import pytest
+
+from helpers import golden_records, load_golden, records_equal, resolve_model
+
+
+def test_config_derivation(O):
+    c = O.new_config(4 << 20)
+    assert (c.avg, c.min, c.max, c.window) == (4 << 20, 1 << 20, 16 << 20, 64)
+    assert (c.mask, c.break_min) == (0x7FFFFF, 0x7FFFFD)
+    c = O.new_config(4096)
+    assert (c.min, c.max, c.mask, c.break_min) == (1024, 16384, 0x1FFF, 0x1FFD)
+
+
+@pytest.mark.parametrize("bad", [0, 1, 255, 3000, 4097, (1 << 28) + 1, 1 << 29])
+def test_config_rejects_non_power_of_two_or_out_of_range(O, bad):
+    with pytest.raises(ValueError):
+        O.new_config(bad)
+
+
+def test_default_table_is_balanced(O):
+    """casync's table has a balanced bit distribution per bit position (128 ones each);
+    a single mistyped word would almost surely break this."""
+    t = O.default_table()
+    assert len(set(t.tolist())) == 256
+    for bit in range(32):
+        assert int(((t >> np.uint32(bit)) & np.uint32(1)).sum()) == 128, bit
+
+
+def test_streaming_equals_whole_buffer(O):
+    """Upstream test_chunker1's invariant: feeding single bytes == feeding the whole buffer."""
+    cfg = O.new_config(4096)
+    data = O.fill(300_000, 3)
+    whole = O.chunk_stream(cfg, data)
+    for step in (1, 7, 64, 1000):
+        ch = O.StreamingChunker(cfg)
+        ends, pos, base = [], 0, 0
+        while pos < data.size:
+            n = min(step, data.size - pos)
+            off = 0
+            while off < n:
+                k = ch.scan(data[pos + off: pos + n])
+                if k == 0:
+                    break
+                off += k
+                ends.append(pos + off)
+            pos += n
+        if not ends or ends[-1] != data.size:
+            ends.append(data.size)
+        assert np.array_equal(np.asarray(ends, dtype=np.uint64), whole), step
+
+
+def test_upstream_counter_buffer_chunk_sizes(O):
+    """Buffer = LE u32 counters 0..262143 (upstream Proxmox chunker tests), avg 64 KiB.
+    Recalled upstream expectation with suggested boundaries: sizes
+    [32768, 110609, 229376, 32768, 262144, 262144, 118767]; the hash-determined numbers are
+    the cut 110609 bytes after a boundary at 32768 and the 118767 tail."""
+    buf = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
+    cfg = O.new_config(64 * 1024)
+    sizes = np.diff(np.concatenate([[0], O.chunk_stream(cfg, buf)])).astype(int).tolist()
+    assert sizes == [143377, 262144, 262144, 262144, 118767]
+    assert 143377 == 32768 + 110609
+    after = np.diff(np.concatenate([[0], O.chunk_stream(cfg, buf[32768:])])).astype(int).tolist()
+    assert after[0] == 110609
+
+
+def test_chunk_size_bounds_and_zero_runs(O):
+    cfg = O.new_config(4096)
+    data = O.fill(2_000_000, 8)
+    sizes = np.diff(np.concatenate([[0], O.chunk_stream(cfg, data)]))
+    assert sizes[:-1].min() >= cfg.min and sizes.max() <= cfg.max
+    # constant bytes hash to 0 in every window: only max-size cuts
+    for byte in (0, 0x5A):
+        z = np.full(5 * cfg.max + 123, byte, dtype=np.uint8)
+        zs = np.diff(np.concatenate([[0], O.chunk_stream(cfg, z)])).astype(int).tolist()
+        assert zs == [cfg.max] * 5 + [123]
+    assert O.candidates(cfg, np.zeros(100_000, np.uint8)).size == 0
+
+
+def test_min_equals_window_edge(O):
+    """avg 256 -> min 64 == window: the break test first runs at chunk_size 65."""
+    cfg = O.new_config(256)
+    data = O.fill(200_000, 12)
+    ends = O.chunk_stream(cfg, data)
+    sizes = np.diff(np.concatenate([[0], ends]))
+    assert sizes[:-1].min() >= 65
+    assert np.array_equal(resolve_model(O.candidates(cfg, data), data.size, cfg.min, cfg.max), ends)
+
+
+@pytest.mark.parametrize("avg,n,kind", [(256, 100_000, 0), (4096, 1_500_000, 0), (4096, 900_000, 3),
+                                        (4096, 700_000, 2), (65536, 6_000_000, 0), (4096, 64, 0),
+                                        (4096, 65, 0), (4096, 1, 0), (4096, 1024, 0), (4096, 1025, 0)])
+def test_candidate_resolve_decomposition_equals_serial(O, avg, n, kind):
+    """The engine's parallel formulation: (all-position window hash candidates) + (min/max
+    resolution over the sorted list) must equal the serial chunker."""
+    cfg = O.new_config(avg)
+    data = O.fill(n, 1000 + avg + n, kind)
+    cands = O.candidates(cfg, data)
+    assert np.all(np.diff(cands.astype(np.int64)) > 0)
+    assert np.array_equal(resolve_model(cands, n, cfg.min, cfg.max), O.chunk_stream(cfg, data))
+
+
+def test_candidate_density_matches_three_in_2avg(O):
+    cfg = O.new_config(4096)
+    n = 8 << 20
+    c = O.candidates(cfg, O.fill(n, 77))
+    expect = 3 * n / (2 * 4096)
+    assert abs(c.size - expect) < 6 * expect ** 0.5
+
+
+def test_segments_are_independent_streams(O):
+    cfg = O.new_config(4096)
+    a, b = O.fill(200_000, 1), O.fill(123_457, 2)
+    both = np.concatenate([a, b])
+    recs = O.chunk_and_digest(cfg, both, [(0, a.size), (a.size, b.size)])
+    ra = O.chunk_and_digest(cfg, a)
+    rb = O.chunk_and_digest(cfg, b)
+    assert np.array_equal(recs["end"], np.concatenate([ra["end"], rb["end"]]))
+    assert np.array_equal(recs["digest"], np.concatenate([ra["digest"], rb["digest"]]))
+    assert recs["segment"].tolist() == [0] * ra.size + [1] * rb.size
+    assert int(recs["size"].sum()) == both.size
+
+
+def test_golden_fixture(O):
+    """tests/golden/chunks_v1.json was produced by tests/golden/make_golden.py; the oracle
+    must keep reproducing it (and the GPU engine is compared with the same file)."""
+    g = load_golden("chunks_v1.json")
+    assert g["schema"] == "pbsgpu-golden-v1"
+    for case in g["cases"]:
+        cfg = O.new_config(case["avg"])
+        if case["segments"] == "le_u32_counter_262144":
+            data = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
+            table = [(0, data.size)]
+        else:
+            parts, table, off = [], [], 0
+            for s in case["segments"]:
+                parts.append(O.fill(s["length"], s["seed"], s["kind"]))
+                table.append((off, s["length"]))
+                off += s["length"]
+            data = np.concatenate(parts)
+        got = O.chunk_and_digest(cfg, data, table, impl=1)
+        want = golden_records(case, O.RECORD_DTYPE)
+        assert records_equal(got, want), case["name"]
+
+
+def test_fill_is_offset_consistent(O):
+    for kind in range(4):
+        whole = O.fill(300_000, 5, kind)
+        for off in (8, 4096, 65536 + 8, 131072):
+            assert np.array_equal(O.fill(1000, 5, kind, stream_off=off), whole[off:off + 1000]), (kind, off)
+    assert not O.fill(1 << 16, 5, 1).any()
+    z = O.fill(8 << 20, 5, 3)
+    frac = 1.0 - np.count_nonzero(z.reshape(-1, 65536).any(axis=1)) / (z.size / 65536)
+    assert 0.15 < frac < 0.45
