@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — GiB/s ingested through Buzhash CDC + per-chunk SHA-256 on MI355X.
+
+Workload (BASELINE.json configs[1]): one 64 GiB synthetic random stream per GPU, resident in
+HBM before the timed region, cut with buzhash.NewConfig(4 << 20) (the reference's production
+parameter: internal/pxarmount/commit_orchestrate.go:144, internal/tapeio/converter.go:248)
+and every chunk hashed with SHA-256. A "step" = one full pass of the hot path over that
+stream: candidate scan -> compaction/resolve -> SHA-256 of every chunk -> records on the host.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — every rank
+owns its own 64 GiB stream (segments are independent, so the data path has no collective);
+the only exchange is the digest-set all-gather + device dedup after each step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (SHA-256) and `cpu_baseline` (the C oracle, SHA-NI, one thread, on a bounded
+prefix of the same stream).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GiB = 1 << 30
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s
+SHA_OPS_PER_BYTE = 24.0     # VALU ops per input byte of the compiled SHA-256 loop
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gib", type=float, default=64.0, help="stream size per GPU in GiB (config 2: 64)")
+    ap.add_argument("--avg", type=int, default=4 << 20)
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight (1 = strictly serial steps)")
+    ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=2)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from pbs_plus_amd import Engine, buzhash
+    from pbs_plus_amd.dist import global_dedup
+
+    nbytes = int(a.gib * GiB) & ~7
+    cfg = buzhash.NewConfig(a.avg)
+    inflight = max(1, min(a.inflight, 8))
+    eng = Engine(cfg, device=local_rank, inflight=max(inflight, 1))
+    data = torch.empty(nbytes, dtype=torch.uint8, device=dev)   # the corpus: resident in HBM
+    eng.fill(data.data_ptr(), nbytes, seed=a.seed + rank, kind=0)
+    torch.cuda.synchronize()
+
+    def run_steps(k, timings=None):
+        """k passes; with inflight > 1 consecutive passes overlap on separate HIP streams."""
+        pending = []
+        nrec, recs = 0, None
+        for _ in range(k):
+            if len(pending) == inflight:
+                t = pending.pop(0)
+                if timings is not None:
+                    timings.append(eng.timing(t))
+                recs = eng.collect(t)
+                nrec = recs.size
+                if dist is not None:
+                    global_dedup(eng, recs, device=dev)
+            pending.append(eng.submit(data, None, nbytes))
+        for t in pending:
+            if timings is not None:
+                timings.append(eng.timing(t))
+            recs = eng.collect(t)
+            nrec = recs.size
+            if dist is not None:
+                global_dedup(eng, recs, device=dev)
+        return nrec, recs
+
+    run_steps(a.warmup)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timings = []
+    t0 = time.perf_counter()
+    nrec, recs = run_steps(a.steps, timings)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_bytes = float(nbytes) * world * a.steps
+        value = total_bytes / GiB / elapsed
+        sha_ms = float(np.mean([t["sha_ms"] for t in timings]))
+        scan_ms = float(np.mean([t["scan_ms"] for t in timings]))
+        resolve_ms = float(np.mean([t["resolve_ms"] for t in timings]))
+        sha_gbs = nbytes / (sha_ms * 1e-3) / 1e9
+        scan_gbs = nbytes / (scan_ms * 1e-3) / 1e9
+        out = {
+            "metric": "GiB/s ingested through CDC+SHA-256",
+            "value": round(value, 2),
+            "unit": "GiB/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic (splitmix64 random bytes generated on device, resident in HBM)",
+            "config": {
+                "workload": f"single {a.gib:g} GiB stream per GPU, Buzhash CDC avg 4 MiB (min 1 MiB, max 16 MiB) "
+                            f"+ SHA-256 per chunk (BASELINE.json configs[1])",
+                "bytes_per_gpu": nbytes, "avg_chunk": a.avg, "chunks_per_gpu": int(nrec),
+                "inflight_batches": inflight,
+                "parallelism": f"segments sharded, {world} rank(s), digest-set all-gather" if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "kernel": "k_sha256<RecordSource> (dominant: %.0f%% of device time)" % (
+                    100.0 * sha_ms / max(sha_ms + scan_ms + resolve_ms, 1e-9)),
+                "bound": "hbm",
+                "achieved": round(sha_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(sha_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "note": "SHA-256 is integer-VALU bound, not HBM bound: ~%.0f VALU ops/B -> chip ceiling %.0f GB/s; "
+                        "valu_frac is achieved/that" % (SHA_OPS_PER_BYTE, VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE),
+                "valu_frac": round(sha_gbs / (VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE), 4),
+                "algorithmic_bytes_per_launch": nbytes,
+                "kernel_ms": round(sha_ms, 3),
+                "scan_kernel": {"kernel": "k_scan<240,8>", "bound": "hbm", "achieved": round(scan_gbs, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
+                                "kernel_ms": round(scan_ms, 3)},
+                "resolve_ms": round(resolve_ms, 3),
+            },
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a, recs)
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, gpu_recs):
+    """The oracle (C restatement; SHA-NI like Go's crypto/sha256) on ONE host thread — the
+    reference's writer is a single goroutine (internal/tapeio/converter.go:672-680) — over a
+    bounded prefix of the same stream. Also cross-checks the GPU records on that prefix."""
+    from oracle import oracle as O
+
+    O.build()
+    n = int(min(a.cpu_sample_gib, a.gib) * GiB) & ~7
+    host = O.fill(n, a.seed, 0)
+    cfg = O.new_config(a.avg)
+    t0 = time.perf_counter()
+    recs = O.chunk_and_digest(cfg, host, [(0, n)], impl=1)
+    dt = time.perf_counter() - t0
+    # causality: cuts before the prefix end depend only on the prefix -> all but the tail must match
+    k = recs.size - 1
+    same = bool(k > 0 and gpu_recs.size >= k and np.array_equal(recs["end"][:k], gpu_recs["end"][:k])
+                and np.array_equal(recs["digest"][:k], gpu_recs["digest"][:k]))
+    return {
+        "value": round(n / GiB / dt, 4), "unit": "GiB/s", "cores": 1,
+        "kind": "port",
+        "sample": f"first {n / GiB:g} GiB of the same stream, oracle chunk_and_digest (byte-serial Buzhash + SHA-NI), "
+                  f"{os.cpu_count()} host cores present",
+        "prefix_records_match_gpu": same, "prefix_records": int(k),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@
 // Integer/byte work only: no MFMA anywhere.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -364,36 +365,59 @@ hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, co
 // =====================================================================================
 __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
 
+// gfx950 has v_bitop3_b32 (any 3-input bitwise op in one instruction): XOR3 = 0x96, MAJ = 0xE8.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+}
+__device__ __forceinline__ uint32_t ch3(uint32_t e, uint32_t f, uint32_t g) { return g ^ (e & (f ^ g)); }  // v_bfi
+
+__device__ constexpr uint32_t kSha256K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+// message schedule step: W[i & 15] <- sigma1(W[i-2]) + W[i-7] + sigma0(W[i-15]) + W[i-16]
+__device__ __forceinline__ uint32_t sha256_sched(uint32_t (&W)[16], int i) {
+    const uint32_t w15 = W[(i + 1) & 15], w2 = W[(i + 14) & 15];
+    const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+    const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+    const uint32_t w = W[i & 15] + s0 + W[(i + 9) & 15] + s1;
+    W[i & 15] = w;
+    return w;
+}
+
+// one round given wk = W[t] + K[t]; 14 VALU instructions (3+1 Sigma1, bfi, 2 adds, 3+1 Sigma0, maj, 2 adds)
+#define SHA256_ROUND(a, b, c, d, e, f, g, h, wk)                                   \
+    do {                                                                           \
+        const uint32_t t1_ = (h) + xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25)) + ch3(e, f, g) + (wk); \
+        const uint32_t t2_ = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22)) + maj3(a, b, c); \
+        (d) += t1_;                                                                \
+        (h) = t1_ + t2_;                                                           \
+    } while (0)
+
 __device__ __forceinline__ void sha256_compress(uint32_t (&H)[8], uint32_t (&W)[16]) {
-    constexpr uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
-        0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
-        0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
-        0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
-        0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-        0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
-        0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
     uint32_t a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        uint32_t w;
-        if (i < 16) {
-            w = W[i];
-        } else {
-            const uint32_t w15 = W[(i + 1) & 15], w2 = W[(i + 14) & 15];
-            const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-            const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
-            w = W[i & 15] + s0 + W[(i + 9) & 15] + s1;
-            W[i & 15] = w;
-        }
-        const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
-        const uint32_t ch = g ^ (e & (f ^ g));
-        const uint32_t t1 = h + S1 + ch + K[i] + w;
-        const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
-        const uint32_t mj = (a & b) | (c & (a | b));
-        const uint32_t t2 = S0 + mj;
-        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    for (int i = 0; i < 64; i += 8) {
+        uint32_t wk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wk[j] = ((i + j < 16) ? W[i + j] : sha256_sched(W, i + j)) + kSha256K[i + j];
+        SHA256_ROUND(a, b, c, d, e, f, g, h, wk[0]);
+        SHA256_ROUND(h, a, b, c, d, e, f, g, wk[1]);
+        SHA256_ROUND(g, h, a, b, c, d, e, f, wk[2]);
+        SHA256_ROUND(f, g, h, a, b, c, d, e, wk[3]);
+        SHA256_ROUND(e, f, g, h, a, b, c, d, wk[4]);
+        SHA256_ROUND(d, e, f, g, h, a, b, c, wk[5]);
+        SHA256_ROUND(c, d, e, f, g, h, a, b, wk[6]);
+        SHA256_ROUND(b, c, d, e, f, g, h, a, wk[7]);
     }
     H[0] += a; H[1] += b; H[2] += c; H[3] += d; H[4] += e; H[5] += f; H[6] += g; H[7] += h;
 }
@@ -547,12 +571,242 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
     }
 }
 
+// -------------------------------------------------------------------------------------
+// SHA-256, wave-pair form. The ingest workload is parallelism-starved on this chip: at a
+// 4 MiB average chunk even a full 288 GB of HBM holds ~70 k chunks, while 256 CUs x 4 SIMDs
+// x 2 waves offer 131 k lanes, and a lone wave only issues one instruction every ~4 cycles.
+// A batch therefore finishes when its LONGEST chunk does (max = 16 MiB = 262 144 dependent
+// compressions), so what matters is the number of instructions on that serial chain. A
+// workgroup is two waves on two SIMDs: the PRODUCER wave owns the byte streams (queue,
+// loads, tail/padding, byte swap, message schedule, + K) and hands W[t]+K[t] through LDS;
+// the CONSUMER wave executes nothing but the 64 rounds (14 VALU each) and the digest store.
+// One s_barrier per block; LDS double-buffered (2 x 16 KiB).
+template <typename Source>
+__global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
+                                                     uint32_t *queue) {
+    // One workgroup per CU (launch pads the LDS request): 4 waves on the CU's 4 SIMDs = 2 pairs.
+    // waves 0,1 = consumers of pair 0,1; waves 2,3 = their producers.
+    __shared__ uint4 wkbuf_[2][2][16][64];  // [pair][buffer][4 rounds][lane] -> 16 B per lane, contiguous rows
+    __shared__ uint32_t ctrl_[2][2][64];    // bit0 block valid, bit1 last block of its range
+    __shared__ uint8_t *dstp_[2][2][64];    // digest destination (valid when bit1)
+    __shared__ uint32_t alive[2][2];        // [pair][buffer]: producer still had blocks
+    __shared__ uint32_t tailbuf_[2][64][17];  // per-lane scratch for tail/padding blocks (17: bank spread)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int pr = wave & 1;
+    const bool producer = wave >= 2;
+    auto &wkbuf = wkbuf_[pr];
+    auto &ctrl = ctrl_[pr];
+    auto &dstp = dstp_[pr];
+    auto &tailbuf = tailbuf_[pr];
+
+    if (producer) {
+        const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
+        // byte-stream state of this lane
+        const uint8_t *base = nullptr;
+        uint64_t len = 0, blk = 0, nblk = 0;  // blk = next block to fetch
+        uint8_t *dst = nullptr;
+        bool have = false, exhausted = false;
+        // FIFO of raw blocks in flight: a block is requested D iterations before it is expanded, so
+        // HBM/TLB latency of the lane-private streams stays off the serial chain
+#ifndef PBS_SHA_FIFO
+#define PBS_SHA_FIFO 2
+#endif
+        constexpr int D = PBS_SHA_FIFO;  // even (buffer parity is derived from the slot index)
+        uint32_t R[D][17];
+        uint32_t selv[D], cflag[D];
+        uint8_t *dstv[D];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+#pragma unroll
+            for (int j = 0; j < 17; ++j) R[s][j] = 0;
+            selv[s] = 0x00010203u;
+            cflag[s] = 0;
+            dstv[s] = nullptr;
+        }
+        uint32_t *scratch = tailbuf[lane];
+
+        auto acquire = [&](bool need) {
+            const unsigned long long m = __ballot(need);
+            if (m == 0) return;
+            uint32_t first = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(m));
+            first = __shfl(first, leader, 64);
+            if (need) {
+                const uint32_t i = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (i < nitems) {
+                    src.get(i, base, len, dst);
+                    blk = 0;
+                    nblk = (len + 8) / 64 + 1;
+                    have = true;
+                } else {
+                    exhausted = true;
+                    have = false;
+                }
+            }
+        };
+        // request the lane's next block into FIFO slot s (compile-time s)
+        auto prep = [&](const int s) {
+            acquire(!have && !exhausted);
+            uint32_t c = 0;
+            if (have) {
+                const uint64_t off = blk * 64;
+                if (off + 64 <= len) {  // pure data block: 4-byte aligned vector loads + funnel selector
+                    const uint8_t *p = base + off;
+                    const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
+                    const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
+                    const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+                    R[s][0] = v0.x; R[s][1] = v0.y; R[s][2] = v0.z; R[s][3] = v0.w;
+                    R[s][4] = v1.x; R[s][5] = v1.y; R[s][6] = v1.z; R[s][7] = v1.w;
+                    R[s][8] = v2.x; R[s][9] = v2.y; R[s][10] = v2.z; R[s][11] = v2.w;
+                    R[s][12] = v3.x; R[s][13] = v3.y; R[s][14] = v3.z; R[s][15] = v3.w;
+                    R[s][16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
+                    selv[s] = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
+                } else {  // tail / padding block (<= 2 per range): assembled bytewise in LDS scratch
+                    uint8_t *sb = reinterpret_cast<uint8_t *>(scratch);
+                    for (uint32_t q = 0; q < 64; ++q) {
+                        const uint64_t g = off + q;
+                        uint8_t byte = 0;
+                        if (g < len) byte = base[g];
+                        else if (g == len) byte = 0x80u;
+                        sb[q] = byte;
+                    }
+                    if (blk + 1 == nblk) {  // big-endian bit length in bytes 56..63
+                        const uint64_t bits = len * 8;
+                        for (uint32_t q = 0; q < 8; ++q) sb[56 + q] = (uint8_t)(bits >> (56 - 8 * q));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) R[s][j] = scratch[j];
+                    R[s][16] = 0;
+                    selv[s] = 0x00010203u;
+                }
+                c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
+                dstv[s] = dst;
+                if (++blk == nblk) have = false;
+            }
+            cflag[s] = c;
+        };
+
+#pragma unroll
+        for (int s = 0; s < D; ++s) prep(s);
+        bool running = true;
+        while (running) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (running) {
+                    constexpr int kBufMask = 1;
+                    const int pb = s & kBufMask;  // D is even: buffer parity is static
+                    uint32_t W[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
+                    const uint32_t c = cflag[s];
+                    uint8_t *cur_dst = dstv[s];
+                    prep(s);  // refill the slot: the block D iterations ahead
+                    const bool any_cur = __any(c & 1u);
+                    if (any_cur) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            uint32_t x[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int t = 4 * q + j;
+                                x[j] = ((t < 16) ? W[t] : sha256_sched(W, t)) + kSha256K[t];
+                            }
+                            wkbuf[pb][q][lane] = make_uint4(x[0], x[1], x[2], x[3]);
+                        }
+                    }
+                    ctrl[pb][lane] = c;
+                    dstp[pb][lane] = cur_dst;
+                    if (lane == 0) alive[pr][pb] = any_cur ? 1u : 0u;
+                    __syncthreads();
+                    if (!(alive[0][pb] | alive[1][pb])) running = false;  // both pairs drained
+                }
+            }
+        }
+    } else {
+        uint32_t H[8];
+        sha256_iv(H);
+        for (uint32_t it = 0;; ++it) {
+            const int pb = it & 1;
+            __syncthreads();
+            if (!(alive[0][pb] | alive[1][pb])) break;
+            const uint32_t c = ctrl[pb][lane];
+            uint8_t *d = dstp[pb][lane];
+            uint4 wk[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) wk[q] = wkbuf[pb][q][lane];
+            if (c & 1u) {
+                uint32_t a = H[0], b = H[1], cc = H[2], dd = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    SHA256_ROUND(a, b, cc, dd, e, f, g, h, wk[q].x);
+                    SHA256_ROUND(h, a, b, cc, dd, e, f, g, wk[q].y);
+                    SHA256_ROUND(g, h, a, b, cc, dd, e, f, wk[q].z);
+                    SHA256_ROUND(f, g, h, a, b, cc, dd, e, wk[q].w);
+                    SHA256_ROUND(e, f, g, h, a, b, cc, dd, wk[q + 1].x);
+                    SHA256_ROUND(dd, e, f, g, h, a, b, cc, wk[q + 1].y);
+                    SHA256_ROUND(cc, dd, e, f, g, h, a, b, wk[q + 1].z);
+                    SHA256_ROUND(b, cc, dd, e, f, g, h, a, wk[q + 1].w);
+                }
+                H[0] += a; H[1] += b; H[2] += cc; H[3] += dd; H[4] += e; H[5] += f; H[6] += g; H[7] += h;
+                if (c & 2u) {
+                    uint32_t *o = reinterpret_cast<uint32_t *>(d);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(H[j]);
+                    sha256_iv(H);
+                }
+            }
+        }
+    }
+}
+
+// Dynamic-LDS padding: a wave already saturates its SIMD's integer issue rate (one wave64 VALU op
+// per ~4 cycles), so a co-resident wave halves the speed of the serial chain. Requesting LDS the
+// kernel never touches caps residency at one wave per SIMD (2 pairs / 4 single waves per CU).
+static size_t sha_lds_pad(size_t dflt) {
+    static long pad = -2;
+    if (pad == -2) {
+        const char *e = getenv("PBSGPU_SHA_LDS_PAD");
+        pad = e ? atol(e) : -1;
+    }
+    return pad >= 0 ? (size_t)pad : dflt;
+}
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+// PBSGPU_SHA_MODE=lane selects the single-wave kernel (A/B measurements); default = wave pairs
+static int sha_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("PBSGPU_SHA_MODE");
+        mode = (e && e[0] == 'l') ? 0 : 1;
+    }
+    return mode;
+}
+
 static inline unsigned sha_grid(int num_cus) { return (unsigned)num_cus * 8u; }  // 2 waves per SIMD
 
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
                                  const uint32_t *nrec, uint32_t *queue, int num_cus, hipStream_t st) {
     RecordSource src{data, segs, recs};
-    hipLaunchKernelGGL((k_sha256<RecordSource>), dim3(sha_grid(num_cus)), dim3(64), 0, st, src, nrec, 0u, queue);
+    if (sha_mode() == 1) {
+        const size_t pad = sha_lds_pad(8u << 10);  // ~77 KB static + 8 KB -> exactly one workgroup per CU
+        hipError_t e = allow_lds(&k_sha256_pair<RecordSource>, pad);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sha256_pair<RecordSource>), dim3((unsigned)num_cus), dim3(256), pad, st, src, nrec, 0u,
+                           queue);
+    } else {
+        const size_t pad = sha_lds_pad(36u << 10);  // four single-wave workgroups per CU
+        hipError_t e = allow_lds(&k_sha256<RecordSource>, pad);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u), dim3(64), pad, st, src, nrec, 0u,
+                           queue);
+    }
     return hipGetLastError();
 }
 
@@ -563,8 +817,24 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
     unsigned grid = sha_grid(num_cus);
     const unsigned need = (nseg + 63) / 64;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), 0, st, src, (const uint32_t *)nullptr, nseg,
-                       queue);
+    if (sha_mode() == 1) {
+        const size_t pad = sha_lds_pad(8u << 10);
+        hipError_t e = allow_lds(&k_sha256_pair<SegmentSource>, pad);
+        if (e != hipSuccess) return e;
+        unsigned g2 = (unsigned)num_cus;
+        const unsigned need2 = (nseg + 127) / 128;
+        if (g2 > need2) g2 = need2;
+        hipLaunchKernelGGL((k_sha256_pair<SegmentSource>), dim3(g2), dim3(256), pad, st, src,
+                           (const uint32_t *)nullptr, nseg, queue);
+    } else {
+        const size_t pad = sha_lds_pad(36u << 10);
+        hipError_t e = allow_lds(&k_sha256<SegmentSource>, pad);
+        if (e != hipSuccess) return e;
+        grid = (unsigned)num_cus * 4u;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), pad, st, src, (const uint32_t *)nullptr,
+                           nseg, queue);
+    }
     return hipGetLastError();
 }
 
