@@ -23,25 +23,29 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per in-flight batch: ROCm's default of 4 would make engine streams share queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GiB = 1 << 30
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_TOPS = 78.6       # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz int32 lane-ops/s
-SHA_OPS_PER_BYTE = 24.0     # VALU ops per input byte of the compiled SHA-256 loop
+VALU_PEAK_TOPS = 39.3       # measured: one wave64 integer op per ~4.2 cycles per SIMD (profiles/r01_ubench_int_valu_issue.log)
+SHA_OPS_PER_BYTE = 22.0     # ~1400 VALU instructions per 64-byte block (14 per round + ~10 per schedule word)
+CHAIN_US_PER_BLOCK = 1.6    # floor of the serial chain: 64 rounds x 14 instr x ~4.2 cycles at 2.4 GHz
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gib", type=float, default=64.0, help="stream size per GPU in GiB (config 2: 64)")
     ap.add_argument("--avg", type=int, default=4 << 20)
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight: 2 = double buffering (default), 1 = strictly serial steps")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="batches in flight on separate HIP streams (default 4: 4 x 64 GiB fits the 288 GB HBM); "
+                         "1 = strictly serial steps")
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2)
@@ -57,9 +61,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("PBS_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; gloo only for 1-GPU debugging
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
+    ngpu = torch.cuda.device_count()
+    if world > 1 and os.environ.get("PBS_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(ngpu, 1)  # debug: several ranks share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    comm_dev = dev if os.environ.get("PBS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
 
     from pbs_plus_amd import Engine, buzhash
     from pbs_plus_amd.dist import global_dedup
@@ -84,7 +96,7 @@ def main():
                 recs = eng.collect(t)
                 nrec = recs.size
                 if dist is not None:
-                    global_dedup(eng, recs, device=dev)
+                    global_dedup(eng, recs, device=comm_dev)
             pending.append(eng.submit(data, None, nbytes))
         for t in pending:
             if timings is not None:
@@ -92,7 +104,7 @@ def main():
             recs = eng.collect(t)
             nrec = recs.size
             if dist is not None:
-                global_dedup(eng, recs, device=dev)
+                global_dedup(eng, recs, device=comm_dev)
         return nrec, recs
 
     run_steps(a.warmup)
@@ -107,7 +119,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -156,8 +168,10 @@ def main():
                 "unit": "GB/s",
                 "frac": round(sha_gbs / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "note": "SHA-256 is integer-VALU bound, not HBM bound: ~%.0f VALU ops/B -> chip ceiling %.0f GB/s; "
-                        "valu_frac is achieved/that" % (SHA_OPS_PER_BYTE, VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE),
+                "note": "SHA-256 never touches the HBM roofline: ~%.0f integer VALU ops/B cap the chip at %.0f GB/s "
+                        "(valu_frac = achieved/that), and one launch cannot finish before the serial chain of its "
+                        "longest chunk (chain_frac = chain_floor_ms / kernel_ms)" % (
+                            SHA_OPS_PER_BYTE, VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE),
                 "valu_frac": round(sha_gbs / (VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE), 4),
                 "algorithmic_bytes_per_launch": nbytes,
                 "kernel_ms": round(sha_ms, 3),
@@ -165,7 +179,8 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
                                 "kernel_ms": round(scan_ms, 3)},
                 "resolve_ms": round(resolve_ms, 3),
-                "chain_floor_ms": round(int(max(recs["size"])) / 64 * 1.6e-3, 1),
+                "chain_floor_ms": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3, 1),
+                "chain_frac": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3 / sha_ms, 3),
                 "chain_note": "SHA-256 is sequential inside a chunk: the launch cannot finish before its longest chunk "
                               "(max 16 MiB = 262144 compressions x >=1.6 us at one wave64 integer op per ~4.2 cycles)",
             },

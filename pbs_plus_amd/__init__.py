@@ -12,8 +12,14 @@ pbs-plus reference uses for its pxar stream path:
 
 Everything executes in the gfx950 kernels of ``lib/libpbsgpu.so``; there is no CPU path.
 """
-from . import buzhash  # noqa: F401
-from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401
-from .engine import Chunker, Engine, PayloadStream  # noqa: F401
+import os as _os
+
+# The engine overlaps batches on separate HIP streams; ROCm's default of 4 hardware queues would make
+# them share queues. Must be set before the HIP runtime initialises (import this package first).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import buzhash  # noqa: F401,E402
+from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401,E402
+from .engine import Chunker, Engine, PayloadStream  # noqa: F401,E402
 
 __all__ = ["buzhash", "Engine", "PayloadStream", "Chunker", "RECORD_DTYPE", "PbsGpuError"]

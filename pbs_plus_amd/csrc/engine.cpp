@@ -111,6 +111,7 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
     p.cap = cap;
     p.tile_cnt = s.tile_cnt.as<uint32_t>();
     p.tile_slots = s.tile_slots.as<uint32_t>();
+    p.tile_queue = reinterpret_cast<unsigned long long *>(s.scalars.as<uint32_t>() + SC_TILEQ);
     HIPCHK(hipEventRecord(s.ev[EV_SCAN0], s.stream));
     HIPCHK(pbsk::launch_scan(p, e->num_cus, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SCAN1], s.stream));
@@ -128,6 +129,7 @@ int enqueue_pipeline(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     CHK(s.seg_cnt.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.seg_off.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.recs.ensure((size_t)s.rec_cap * sizeof(pbsgpu_record) + 64));
+    CHK(s.order.ensure((size_t)s.rec_cap * 4 + 64));
     CHK(enqueue_candidates(e, s, s.dptr, s.nbytes, cap, s.nseg));
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
@@ -138,8 +140,10 @@ int enqueue_pipeline(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     HIPCHK(pbsk::launch_resolve_write(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin, e->cfg.max,
                                       s.seg_off.as<uint32_t>(), s.recs.as<pbsgpu_record>(), s.rec_cap, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_RESOLVE1], s.stream));
+    HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
+                              sc + SC_WGLIMIT, e->num_cus, s.stream));
     HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
-                                       e->num_cus, s.stream));
+                                       s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
     HIPCHK(hipMemcpyAsync(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, hipMemcpyDeviceToHost, s.stream));
     return PBSGPU_OK;
@@ -400,7 +404,7 @@ void pbsgpu_engine_destroy(pbsgpu_engine *e) {
     for (auto &s : e->slots) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         for (DevBuf *b : {&s.data, &s.tile_cnt, &s.tile_off, &s.tile_slots, &s.dense, &s.scan_tmp, &s.scalars, &s.segs,
-                          &s.seg_cnt, &s.seg_off, &s.recs})
+                          &s.seg_cnt, &s.seg_off, &s.recs, &s.order})
             b->release();
         s.h_scalars.release();
         s.h_segs.release();

@@ -92,7 +92,7 @@ struct PinnedBuf {
 };
 
 // device scalars of one slot (uint32 each)
-enum : int { SC_NCAND = 0, SC_NREC = 1, SC_MAXCNT = 2, SC_QUEUE = 3, SC_COUNT = 8 };
+enum : int { SC_NCAND = 0, SC_NREC = 1, SC_MAXCNT = 2, SC_QUEUE = 3, SC_WGLIMIT = 4, SC_TILEQ = 6 /* u64 */, SC_COUNT = 8 };
 
 enum : int { EV_BEGIN = 0, EV_SCAN0, EV_SCAN1, EV_RESOLVE1, EV_SHA1, EV_COUNT };
 
@@ -100,7 +100,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     DevBuf data;  // staged copy of host submits
-    DevBuf tile_cnt, tile_off, tile_slots, dense, scan_tmp, scalars, segs, seg_cnt, seg_off, recs;
+    DevBuf tile_cnt, tile_off, tile_slots, dense, scan_tmp, scalars, segs, seg_cnt, seg_off, recs, order;
     PinnedBuf h_scalars;  // readback of SC_*
     PinnedBuf h_segs;     // pinned copy of the segment table
     // in-flight state

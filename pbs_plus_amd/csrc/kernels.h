@@ -27,6 +27,7 @@ struct ScanParams {
     uint32_t cap;             // slots per tile
     uint32_t *tile_cnt;       // [ntiles] true count (may exceed cap)
     uint32_t *tile_slots;     // [ntiles * cap] end offset within tile (1..kScanTile), a-coords
+    unsigned long long *tile_queue;  // device counter, zero at launch: next tile to hand out
 };
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st);
@@ -53,7 +54,11 @@ hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, co
 // SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
 // `queue` is a device uint32 that must be zero at launch.
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
-                                 const uint32_t *nrec, uint32_t *queue, int num_cus, hipStream_t st);
+                                 const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
+                                 const uint32_t *wg_limit, int num_cus, hipStream_t st);
+// longest-first queue order (counting sort by size class) + workgroup budget for the SHA kernel
+hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
+                        uint32_t *wg_limit, int num_cus, hipStream_t st);
 // SHA-256 of whole segments (verification path): digests[32*i] for segs[i]
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
                                   uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);

@@ -54,7 +54,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
     const uint64_t A = p.nbytes + p.lead;  // extent in aligned ("a") coordinates
     const uint32_t thr = p.thr;
 
-    for (uint64_t t = (uint64_t)blockIdx.x * WAVES + wave; t < p.ntiles; t += (uint64_t)gridDim.x * WAVES) {
+    // Tiles are handed out dynamically (a wave grabs kGrab consecutive tiles per atomic): when other
+    // batches' kernels occupy part of the chip, the workgroups that ARE resident drain all tiles and
+    // late workgroups find none, so the kernel's duration tracks the CUs it actually got.
+    constexpr uint32_t kGrab = 8;
+    uint64_t t = 0, t_end = 0;
+    for (;;) {
+        if (t == t_end) {
+            unsigned long long g = 0;
+            if (lane == 0) g = atomicAdd(p.tile_queue, (unsigned long long)kGrab);
+            t = __shfl(g, 0, 64);
+            if (t >= p.ntiles) break;
+            t_end = min(t + kGrab, p.ntiles);
+        }
         const uint64_t wbase = t * (uint64_t)(64 * S);
         if (lane == 0) *wcnt = 0;
         // stage [wbase-64, wbase+64*S): coalesced 16-byte pieces, zero outside the buffer
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
         wave_sync();
         if (lane == 0) p.tile_cnt[t] = *wcnt;
         wave_sync();
+        ++t;
     }
 }
 
@@ -434,7 +447,9 @@ struct RecordSource {
     const uint8_t *data;
     const pbsgpu_segment *segs;
     pbsgpu_record *recs;
+    const uint32_t *order;  // queue position -> record index (longest chunks first), may be null
     __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
+        if (order) i = order[i];
         const pbsgpu_record *r = recs + i;
         const uint64_t end = r->end;
         const uint32_t size = r->size;
@@ -583,7 +598,9 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
 // One s_barrier per block; LDS double-buffered (2 x 16 KiB).
 template <typename Source>
 __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
-                                                     uint32_t *queue) {
+                                                     uint32_t *queue, const uint32_t *wg_limit) {
+    // surplus workgroups leave at once so their CUs can host another batch's kernel
+    if (wg_limit && blockIdx.x >= *wg_limit) return;
     // One workgroup per CU (launch pads the LDS request): 4 waves on the CU's 4 SIMDs = 2 pairs.
     // waves 0,1 = consumers of pair 0,1; waves 2,3 = their producers.
     __shared__ uint4 wkbuf_[2][2][16][64];  // [pair][buffer][4 rounds][lane] -> 16 B per lane, contiguous rows
@@ -761,6 +778,67 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Longest-first queue order + workgroup budget for the SHA kernel (one small workgroup).
+// A batch's makespan is max(longest chunk, total work / lanes): starting the long chunks first
+// and letting lanes pull the short ones afterwards reaches that bound with FEWER lanes than
+// chunks, which leaves CUs free for the next batch's kernels (batches overlap on separate
+// streams). Counting sort by size class (no comparison sort needed for a scheduling order).
+__global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const uint32_t *nrec_p, uint32_t shift,
+                                                uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs) {
+    constexpr int BINS = 1024;
+    __shared__ uint32_t hist[BINS];
+    __shared__ uint32_t base[BINS];
+    __shared__ unsigned long long tot_blocks;
+    __shared__ uint32_t longest;
+    const uint32_t n = *nrec_p;
+    for (int i = threadIdx.x; i < BINS; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) { tot_blocks = 0; longest = 0; }
+    __syncthreads();
+    unsigned long long my_blocks = 0;
+    uint32_t my_long = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t sz = recs[i].size;
+        uint32_t b = sz >> shift;
+        if (b >= BINS) b = BINS - 1;
+        atomicAdd(&hist[BINS - 1 - b], 1u);  // descending size
+        const uint32_t blocks = (sz + 8) / 64 + 1;
+        my_blocks += blocks;
+        my_long = max(my_long, blocks);
+    }
+    atomicAdd(&tot_blocks, my_blocks);
+    atomicMax(&longest, my_long);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < BINS; ++i) { base[i] = run; run += hist[i]; }
+        // lanes needed so that total work / lanes stays below the longest chain (25 % slack)
+        const unsigned long long lg = longest ? longest : 1;
+        unsigned long long lanes = (tot_blocks * 5 / 4 + lg - 1) / lg;
+        uint32_t wgs = (uint32_t)((lanes + 127) / 128);
+        const uint32_t need = (n + 127) / 128;
+        if (wgs > need) wgs = need;
+        if (wgs < 1) wgs = 1;
+        if (wgs > max_wgs) wgs = max_wgs;
+        *wg_limit = wgs;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t b = recs[i].size >> shift;
+        if (b >= BINS) b = BINS - 1;
+        const uint32_t pos = atomicAdd(&base[BINS - 1 - b], 1u);
+        order[pos] = i;
+    }
+}
+
+hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
+                        uint32_t *wg_limit, int num_cus, hipStream_t st) {
+    uint32_t shift = 0;
+    while (((uint64_t)max_chunk >> shift) >= 1024) ++shift;
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus);
+    return hipGetLastError();
+}
+
 // Dynamic-LDS padding: a wave already saturates its SIMD's integer issue rate (one wave64 VALU op
 // per ~4 cycles), so a co-resident wave halves the speed of the serial chain. Requesting LDS the
 // kernel never touches caps residency at one wave per SIMD (2 pairs / 4 single waves per CU).
@@ -792,14 +870,15 @@ static int sha_mode() {
 static inline unsigned sha_grid(int num_cus) { return (unsigned)num_cus * 8u; }  // 2 waves per SIMD
 
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
-                                 const uint32_t *nrec, uint32_t *queue, int num_cus, hipStream_t st) {
-    RecordSource src{data, segs, recs};
+                                 const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
+                                 const uint32_t *wg_limit, int num_cus, hipStream_t st) {
+    RecordSource src{data, segs, recs, order};
     if (sha_mode() == 1) {
         const size_t pad = sha_lds_pad(8u << 10);  // ~77 KB static + 8 KB -> exactly one workgroup per CU
         hipError_t e = allow_lds(&k_sha256_pair<RecordSource>, pad);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sha256_pair<RecordSource>), dim3((unsigned)num_cus), dim3(256), pad, st, src, nrec, 0u,
-                           queue);
+                           queue, wg_limit);
     } else {
         const size_t pad = sha_lds_pad(36u << 10);  // four single-wave workgroups per CU
         hipError_t e = allow_lds(&k_sha256<RecordSource>, pad);
@@ -825,7 +904,7 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
         const unsigned need2 = (nseg + 127) / 128;
         if (g2 > need2) g2 = need2;
         hipLaunchKernelGGL((k_sha256_pair<SegmentSource>), dim3(g2), dim3(256), pad, st, src,
-                           (const uint32_t *)nullptr, nseg, queue);
+                           (const uint32_t *)nullptr, nseg, queue, (const uint32_t *)nullptr);
     } else {
         const size_t pad = sha_lds_pad(36u << 10);
         hipError_t e = allow_lds(&k_sha256<SegmentSource>, pad);
