@@ -54,9 +54,10 @@ namespace pbse {
 
 constexpr size_t kStageBytes = 32u << 20;
 
-uint32_t default_cap(const pbsgpu_engine *e) {
+uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes) {
+    const uint32_t tile_bytes = pbsk::scan_tile_bytes(nbytes);
     // expected candidates per wave tile = 3 * tile / (mask + 1); leave generous headroom
-    const double lambda = 3.0 * pbsk::kScanTile / ((double)e->cfg.mask + 1.0);
+    const double lambda = 3.0 * tile_bytes / ((double)e->cfg.mask + 1.0);
     double want = 4.0 * lambda + 16.0;
     uint32_t cap = 8;
     while (cap < want) cap <<= 1;
@@ -87,9 +88,10 @@ int validate_segments(const pbsgpu_segment *segs, uint32_t nseg, uint64_t nbytes
 // enqueue scan -> compaction (candidates land dense + ascending in slot.dense, count in SC_NCAND)
 int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint32_t cap,
                        uint64_t nseg_hint) {
-    const uint32_t lead = (uint32_t)((uintptr_t)dptr & 15u);
+    const uint32_t lead = (uint32_t)((uintptr_t)dptr & 127u);  // scan from the 128-byte line containing dptr[0]
     const uint64_t extent = nbytes + lead;
-    const uint64_t ntiles = (extent + pbsk::kScanTile - 1) / pbsk::kScanTile;
+    const uint32_t tile_bytes = pbsk::scan_tile_bytes(nbytes);
+    const uint64_t ntiles = (extent + tile_bytes - 1) / tile_bytes;
     if (ntiles * (uint64_t)cap >= (1ull << 32)) return PBSGPU_E_DENSITY;
     CHK(s.tile_cnt.ensure((size_t)ntiles * 4 + 16));
     CHK(s.tile_off.ensure((size_t)ntiles * 4 + 16));
@@ -106,6 +108,7 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
     p.lead = lead;
     p.nbytes = nbytes;
     p.ntiles = ntiles;
+    p.tile_bytes = tile_bytes;
     p.table_rot = e->d_table_rot;
     p.thr = e->thr;
     p.cap = cap;
@@ -119,7 +122,8 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
     HIPCHK(pbsk::launch_exclusive_scan(s.tile_cnt.as<uint32_t>(), ntiles, cap, s.tile_off.as<uint32_t>(),
                                        sc + SC_NCAND, sc + SC_MAXCNT, s.scan_tmp.as<uint32_t>(), s.stream));
     HIPCHK(pbsk::launch_compact(s.tile_cnt.as<uint32_t>(), s.tile_off.as<uint32_t>(), s.tile_slots.as<uint32_t>(),
-                                cap, ntiles, lead, nbytes, s.dense.as<uint64_t>(), ntiles * (uint64_t)cap, s.stream));
+                                cap, ntiles, lead, nbytes, s.dense.as<uint64_t>(), ntiles * (uint64_t)cap, tile_bytes,
+                                s.stream));
     return PBSGPU_OK;
 }
 
@@ -221,7 +225,7 @@ int submit_common(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nbytes,
     s->host_submit = host;
     s->retries = 0;
     s->synced = false;
-    int st = enqueue_pipeline(e, *s, default_cap(e));
+    int st = enqueue_pipeline(e, *s, default_cap(e, s->nbytes));
     if (st != PBSGPU_OK) {
         (void)hipStreamSynchronize(s->stream);
         return st;
@@ -245,7 +249,7 @@ int sync_slot(pbsgpu_engine *e, Slot &s) {
         }
         uint32_t cap = s.cap;
         while (cap < hs[SC_MAXCNT]) cap <<= 1;
-        if (cap > (uint32_t)pbsk::kScanTile) cap = pbsk::kScanTile;
+        if (cap > pbsk::scan_tile_bytes(s.nbytes)) cap = pbsk::scan_tile_bytes(s.nbytes);
         s.retries++;
         int st = enqueue_pipeline(e, s, cap);
         if (st != PBSGPU_OK) return st;
@@ -258,7 +262,7 @@ int sync_slot(pbsgpu_engine *e, Slot &s) {
 // run scan + compaction on `s` and wait; grows the per-tile capacity until nothing overflowed
 int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint64_t *count) {
     CHK(s.h_scalars.ensure(SC_COUNT * 4));
-    uint32_t tcap = default_cap(e);
+    uint32_t tcap = default_cap(e, nbytes);
     for (;;) {
         CHK(enqueue_candidates(e, s, dptr, nbytes, tcap));
         HIPCHK(hipMemcpyAsync(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, hipMemcpyDeviceToHost, s.stream));
@@ -266,7 +270,7 @@ int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nby
         const uint32_t *hs = s.h_scalars.as<uint32_t>();
         if (hs[SC_MAXCNT] <= tcap) break;
         while (tcap < hs[SC_MAXCNT]) tcap <<= 1;
-        if (tcap > (uint32_t)pbsk::kScanTile) tcap = pbsk::kScanTile;
+        if (tcap > pbsk::scan_tile_bytes(nbytes)) tcap = pbsk::scan_tile_bytes(nbytes);
     }
     *count = s.h_scalars.as<uint32_t>()[SC_NCAND];
     return PBSGPU_OK;
@@ -283,7 +287,7 @@ int batch_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, 
     s.host_submit = false;
     s.retries = 0;
     s.synced = false;
-    CHK(enqueue_pipeline(e, s, default_cap(e)));
+    CHK(enqueue_pipeline(e, s, default_cap(e, s.nbytes)));
     CHK(sync_slot(e, s));
     *nrec = s.nrec;
     return PBSGPU_OK;

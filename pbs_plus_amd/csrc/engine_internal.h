@@ -137,7 +137,7 @@ struct pbsgpu_engine {
 
 namespace pbse {
 
-uint32_t default_cap(const pbsgpu_engine *e);
+uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes);
 int set_device(const pbsgpu_engine *e);
 Slot *find_free_slot(pbsgpu_engine *e);
 int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint32_t cap,

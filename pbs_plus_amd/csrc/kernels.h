@@ -22,6 +22,7 @@ struct ScanParams {
     uint32_t lead;            // caller's pointer - data_al (0..15)
     uint64_t nbytes;          // caller's byte count
     uint64_t ntiles;          // wave tiles covering [0, nbytes + lead)
+    uint32_t tile_bytes;      // bytes per wave tile (selects the kernel variant)
     const uint32_t *table_rot;// device: table pre-rotated left by (32 - bits)
     uint32_t thr;             // break_min << (32 - bits)
     uint32_t cap;             // slots per tile
@@ -31,6 +32,8 @@ struct ScanParams {
 };
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st);
+// tile size the scan will use for a batch of nbytes (kernel variant is chosen from it)
+uint32_t scan_tile_bytes(uint64_t nbytes);
 
 // exclusive scan of min(in[i], clamp) -> out[i]; *total = sum; *maxval = max(in[i]) (atomicMax'd)
 // tmp must hold at least scan_tmp_words(n) uint32.
@@ -41,7 +44,7 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 // dense, ascending candidate END offsets (caller coordinates) from the per-tile slots
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
-                          uint64_t dense_cap, hipStream_t st);
+                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st);
 
 // min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,

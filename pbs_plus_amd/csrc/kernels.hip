@@ -24,6 +24,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// PBSGPU_SCAN_MODE=lds selects the LDS-tiled scan kernel (A/B measurements); default = register streaming
+static int scan_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("PBSGPU_SCAN_MODE");
+        mode = (e && e[0] == 'l') ? 0 : 1;
+    }
+    return mode;
+}
+
 // =====================================================================================
 // (1) Buzhash candidate scan
 // =====================================================================================
@@ -145,8 +155,153 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Candidate scan, register-streaming form (default). Measured on gfx950: a SIMD issues one
+// wave64 integer VALU op per ~4.2 cycles whatever its occupancy (39 T lane-ops/s chip-wide), so
+// the scan is HBM-bound only below ~5 VALU ops per byte. This form gets there by
+//  * no LDS tile: every lane streams its own long strip (LINES x 128 B) straight from HBM in
+//    full 128-byte lines (8 back-to-back dwordx4 loads -> the line is consumed while still in
+//    L1), next line prefetched into a second register set (ping-pong);
+//  * warm-up (64 B) amortised over LINES*128 bytes: 1.5 % at LINES = 34 (vs 27 % for 240-byte strips);
+//  * table replicated 64x ([entry][lane], 64 KiB, table at LDS offset 0): the lookup address
+//    (byte << 8) | (lane << 2) is ONE v_perm_b32, and every lane owns its bank;
+//  * per byte: v_perm, ds_read_b32, v_alignbit, v_xor (prefix), v_xor (window hash), 1/2 v_max3.
+// Lane strips are 4352 B apart (34 lines: even for the ping-pong, not a power of two).
+template <int LINES>
+__global__ __launch_bounds__(512, 2) void k_scan2(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    static_assert(LINES % 2 == 0, "ping-pong needs an even number of lines");
+    constexpr uint32_t SL = LINES * 128;          // strip bytes per lane
+    constexpr uint64_t TILE = 64ull * SL;         // bytes per wave tile
+    // static => the compiler knows the table's LDS address and folds it into the ds_read
+    __shared__ __attribute__((aligned(1024))) uint32_t tab[256 * 64];  // [entry][lane]
+    uint32_t *counters = reinterpret_cast<uint32_t *>(smem);           // dynamic part: counters (+ residency pad)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 256 * 64; i += 512) tab[i] = p.table_rot[i >> 6];
+    __syncthreads();
+
+    uint32_t *wcnt = counters + wave;
+    const uint64_t A = p.nbytes + p.lead;
+    const uint32_t thr = p.thr;
+    const uint32_t lane4 = (uint32_t)lane << 2;
+    const uint8_t *lds0 = reinterpret_cast<const uint8_t *>(tab);
+
+    // table lookup of byte k (0..3) of dword w: address = (byte << 8) | lane*4
+#define PBS_LOOKUP(w, k) \
+    (*reinterpret_cast<const uint32_t *>(lds0 + __builtin_amdgcn_perm((w), lane4, 0x0c0c0400u | ((uint32_t)(k) << 8))))
+
+    for (;;) {
+        unsigned long long g0 = 0;
+        if (lane == 0) g0 = atomicAdd(p.tile_queue, 1ull);
+        const uint64_t t = __shfl(g0, 0, 64);
+        if (t >= p.ntiles) break;
+        const uint64_t wbase = t * TILE;
+        const uint64_t sbase = wbase + (uint64_t)lane * SL;  // a-coordinate of this lane's strip
+        if (lane == 0) *wcnt = 0;
+        wave_sync();
+
+        auto load16 = [&](uint64_t a) -> uint4 {  // 16 bytes at a-coordinate a (zero outside the buffer)
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (a < A) v = *reinterpret_cast<const uint4 *>(p.data_al + a);
+            return v;
+        };
+
+        uint32_t ring[64];
+        uint32_t P = 0;
+        {   // warm-up: the 64 bytes before the strip
+            uint4 wv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wv[g] = (sbase >= 64) ? load16(sbase - 64 + 16 * g) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t w[4] = {wv[g].x, wv[g].y, wv[g].z, wv[g].w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    P = __builtin_rotateleft32(P, 1) ^ PBS_LOOKUP(w[k >> 2], k & 3);
+                    ring[g * 16 + k] = P;
+                }
+            }
+        }
+
+        auto process_line = [&](const uint4 (&X)[8], const uint32_t line) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const uint32_t w[4] = {X[g].x, X[g].y, X[g].z, X[g].w};
+                uint32_t h[16];
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t tv = PBS_LOOKUP(w[k >> 2], k & 3);
+                    const uint32_t rp = __builtin_rotateleft32(P, 1);
+                    const int ri = ((g & 3) * 16 + k);
+                    h[k] = __builtin_amdgcn_bitop3_b32(rp, tv, ring[ri], 0x96);  // P_new ^ P_old(-64)
+                    P = rp ^ tv;
+                    ring[ri] = P;
+                    acc = max(acc, h[k]);
+                }
+                if (acc >= thr) {  // rare
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        if (h[k] >= thr) {
+                            const uint64_t ea = sbase + (uint64_t)line * 128u + (uint32_t)(g * 16 + k + 1);
+                            if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
+                                const uint32_t slot = atomicAdd(wcnt, 1u);
+                                if (slot < p.cap) p.tile_slots[t * p.cap + slot] = (uint32_t)(ea - wbase);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        auto load_line = [&](uint4 (&X)[8], const uint32_t line) {
+            const uint64_t a = sbase + (uint64_t)line * 128u;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) X[g] = load16(a + 16 * g);
+        };
+
+        if (sbase < A) {
+            uint4 L0[8], L1[8];
+            load_line(L0, 0);
+#pragma unroll 1
+            for (uint32_t line = 0; line < (uint32_t)LINES; line += 2) {
+                load_line(L1, line + 1);
+                process_line(L0, line);
+                if (line + 2 < (uint32_t)LINES) load_line(L0, line + 2);
+                process_line(L1, line + 1);
+            }
+        }
+        wave_sync();
+        if (lane == 0) p.tile_cnt[t] = *wcnt;
+        wave_sync();
+    }
+#undef PBS_LOOKUP
+}
+
+template <int LINES>
+static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st) {
+    constexpr size_t lds = 64 + (16u << 10);  // counters + pad (64 KiB table is static): keeps SHA workgroups off this CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan2<LINES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    uint64_t blocks = (p.ntiles + 7) / 8;
+    if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;
+    hipLaunchKernelGGL((k_scan2<LINES>), dim3((unsigned)blocks), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+uint32_t scan_tile_bytes(uint64_t nbytes) {
+    if (scan_mode() == 0) return kScanTile;
+    return (nbytes >= (48ull << 20)) ? 64u * 34u * 128u : 64u * 4u * 128u;
+}
+
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
     if (p.ntiles == 0) return hipSuccess;
+    if (p.tile_bytes == 64u * 34u * 128u) return launch_scan2<34>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 4u * 128u) return launch_scan2<4>(p, num_cus, st);
     constexpr int S = kScanStrip, W = kScanWaves;
     constexpr size_t lds = 256 * 32 * 4 + (size_t)W * (kWindow + 64 * S) + W * 4 + 32;
     static bool attr_set = false;
@@ -267,14 +422,15 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const uint32_t *tile_off,
                                                  const uint32_t *tile_slots, uint32_t cap, uint64_t ntiles,
-                                                 uint32_t lead, uint64_t *dense, uint64_t dense_cap) {
+                                                 uint32_t lead, uint64_t *dense, uint64_t dense_cap,
+                                                 uint32_t tile_bytes) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint32_t c = min(tile_cnt[t], cap);
     if (c == 0) return;
     const uint32_t *sl = tile_slots + t * cap;
     const uint64_t base = tile_off[t];
-    const uint64_t tbase = t * (uint64_t)kScanTile;
+    const uint64_t tbase = t * (uint64_t)tile_bytes;
     for (uint32_t j = 0; j < c; ++j) {
         const uint32_t vj = sl[j];
         uint32_t rank = 0;
@@ -285,12 +441,12 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const
 
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
-                          uint64_t dense_cap, hipStream_t st) {
+                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st) {
     (void)nbytes;
     if (ntiles == 0) return hipSuccess;
     const uint64_t nb = (ntiles + 255) / 256;
     hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
-                       lead, dense, dense_cap);
+                       lead, dense, dense_cap, tile_bytes);
     return hipGetLastError();
 }
 
