@@ -175,7 +175,7 @@ def main():
                 "valu_frac": round(sha_gbs / (VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE), 4),
                 "algorithmic_bytes_per_launch": nbytes,
                 "kernel_ms": round(sha_ms, 3),
-                "scan_kernel": {"kernel": "k_scan<240,8>", "bound": "hbm", "achieved": round(scan_gbs, 1),
+                "scan_kernel": {"kernel": "k_scan2<34>", "bound": "hbm", "achieved": round(scan_gbs, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
                                 "kernel_ms": round(scan_ms, 3)},
                 "resolve_ms": round(resolve_ms, 3),
