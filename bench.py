@@ -131,6 +131,18 @@ def main():
     eng.collect(tk)
     serial_s = time.perf_counter() - ts0
 
+    # HBM traffic per launch: measured read/algorithmic ratios from the committed PMC passes
+    traffic = {"sha": None, "scan": None, "note": None}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            tj = json.load(f)
+        traffic["sha"] = int(tj["kernels"]["k_sha256_pair<RecordSource>"]["read_ratio_vs_algorithmic"] * nbytes)
+        traffic["scan"] = int(tj["kernels"]["k_scan2<34>"]["read_ratio_vs_algorithmic"] * nbytes)
+        traffic["note"] = "HBM read bytes per launch = measured FETCH_SIZE ratio (x2 gfx950 correction) x bytes; " \
+                          "PMC passes in profiles/r01_pmc_fetch_size_bench8g.csv"
+    except Exception:
+        pass
+
     if rank == 0:
         total_bytes = float(nbytes) * world * a.steps
         value = total_bytes / GiB / elapsed
@@ -167,7 +179,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(sha_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic["sha"],
+                "traffic_note": traffic["note"],
                 "note": "SHA-256 never touches the HBM roofline: ~%.0f integer VALU ops/B cap the chip at %.0f GB/s "
                         "(valu_frac = achieved/that), and one launch cannot finish before the serial chain of its "
                         "longest chunk (chain_frac = chain_floor_ms / kernel_ms)" % (
@@ -177,7 +190,7 @@ def main():
                 "kernel_ms": round(sha_ms, 3),
                 "scan_kernel": {"kernel": "k_scan2<34>", "bound": "hbm", "achieved": round(scan_gbs, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
-                                "kernel_ms": round(scan_ms, 3)},
+                                "kernel_ms": round(scan_ms, 3), "traffic": traffic["scan"]},
                 "resolve_ms": round(resolve_ms, 3),
                 "chain_floor_ms": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3, 1),
                 "chain_frac": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3 / sha_ms, 3),
