@@ -128,7 +128,8 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
 }
 
 // enqueue the whole pipeline for the slot's current (dptr, nbytes, segs) at capacity `cap`
-int enqueue_pipeline(pbsgpu_engine *e, Slot &s, uint32_t cap) {
+// phase 1 of a batch: candidates -> compaction -> min/max resolution (records without digests)
+int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     s.cap = cap;
     CHK(s.seg_cnt.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.seg_off.ensure((size_t)s.nseg * 4 + 16));
@@ -144,11 +145,25 @@ int enqueue_pipeline(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     HIPCHK(pbsk::launch_resolve_write(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin, e->cfg.max,
                                       s.seg_off.as<uint32_t>(), s.recs.as<pbsgpu_record>(), s.rec_cap, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_RESOLVE1], s.stream));
+    return PBSGPU_OK;
+}
+
+// phase 2: longest-first queue + SHA-256 of the first *SC_NREC records
+int enqueue_hash(pbsgpu_engine *e, Slot &s) {
+    uint32_t *sc = s.scalars.as<uint32_t>();
+    const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
     HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
                               sc + SC_WGLIMIT, e->num_cus, s.stream));
     HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
                                        s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
+    return PBSGPU_OK;
+}
+
+// enqueue the whole pipeline for the slot's current (dptr, nbytes, segs) at capacity `cap`
+int enqueue_pipeline(pbsgpu_engine *e, Slot &s, uint32_t cap) {
+    CHK(enqueue_cut(e, s, cap));
+    CHK(enqueue_hash(e, s));
     HIPCHK(hipMemcpyAsync(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, hipMemcpyDeviceToHost, s.stream));
     return PBSGPU_OK;
 }
@@ -291,6 +306,42 @@ int batch_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, 
     CHK(sync_slot(e, s));
     *nrec = s.nrec;
     return PBSGPU_OK;
+}
+
+// phase 1 only, synchronous (streaming writer): records WITHOUT digests stay in s.recs
+int cut_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
+             uint32_t nseg, uint64_t *nrec) {
+    CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
+    CHK(stage_segments(e, s, segs, nseg, nbytes));
+    s.dptr = dptr;
+    s.nbytes = nbytes;
+    s.host_submit = false;
+    s.retries = 0;
+    s.synced = false;
+    uint32_t cap = default_cap(e, nbytes);
+    for (;;) {
+        CHK(enqueue_cut(e, s, cap));
+        HIPCHK(hipMemcpyAsync(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(hipStreamSynchronize(s.stream));
+        const uint32_t *hs = s.h_scalars.as<uint32_t>();
+        if (hs[SC_MAXCNT] <= cap) break;
+        while (cap < hs[SC_MAXCNT]) cap <<= 1;
+        if (cap > pbsk::scan_tile_bytes(nbytes)) cap = pbsk::scan_tile_bytes(nbytes);
+        s.retries++;
+    }
+    s.nrec = s.h_scalars.as<uint32_t>()[SC_NREC];
+    s.ncand = s.h_scalars.as<uint32_t>()[SC_NCAND];
+    if (s.nrec > s.rec_cap) return PBSGPU_E_STATE;
+    *nrec = s.nrec;
+    return PBSGPU_OK;
+}
+
+// phase 2 for the first `nhash` records of a slot that went through cut_sync; asynchronous
+int hash_async(pbsgpu_engine *e, Slot &s, uint64_t nhash) {
+    uint32_t *hn = s.h_scalars.as<uint32_t>() + SC_COUNT;  // pinned scratch word behind the readback area
+    *hn = (uint32_t)nhash;
+    HIPCHK(hipMemcpyAsync(s.scalars.as<uint32_t>() + SC_NREC, hn, 4, hipMemcpyHostToDevice, s.stream));
+    return enqueue_hash(e, s);
 }
 
 }  // namespace pbse

@@ -147,5 +147,8 @@ int staged_h2d(pbsgpu_engine *e, void *dst, const void *src, uint64_t nbytes, hi
 int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint64_t *count);
 int batch_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
                uint32_t nseg, uint64_t *nrec);
+int cut_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
+             uint32_t nseg, uint64_t *nrec);
+int hash_async(pbsgpu_engine *e, Slot &s, uint64_t nhash);
 
 }  // namespace pbse

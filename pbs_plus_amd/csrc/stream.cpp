@@ -17,73 +17,165 @@ using namespace pbse;
 // -------------------------------------------------------------------------------------
 // streaming writer
 // -------------------------------------------------------------------------------------
+// Windows of the stream are CUT synchronously (scan + resolve: milliseconds) because the next
+// window needs to know where the still-open chunk starts, but HASHED asynchronously: the SHA-256
+// kernel of a window is bounded below by the serial chain of its longest chunk (up to ~0.46 s for a
+// 16 MiB chunk), so several windows hash concurrently on their own engine slots / HIP streams while
+// the writer keeps accepting bytes. Records are delivered strictly in stream order.
+namespace {
+
+struct WindowInFlight {
+    Slot *slot = nullptr;
+    int buf = -1;
+    uint64_t base = 0;     // absolute stream offset of the window buffer's byte 0
+    uint32_t section = 0;
+    uint64_t nemit = 0;    // records to deliver (the open tail chunk of a non-final window is excluded)
+};
+
+constexpr size_t kStreamStage = 32u << 20;
+
+}  // namespace
+
 struct pbsgpu_stream {
     pbsgpu_engine *eng = nullptr;
-    uint64_t window = 0;       // new bytes per device batch
-    DevBuf dev[2];             // [carry | new bytes], ping-pong so the carry copy never overlaps
+    uint64_t window = 0;           // new bytes per device window
+    std::vector<DevBuf> dev;       // window buffers: [carry | new bytes]
+    std::vector<char> dev_busy;    // held by a window that is still hashing
     int cur = 0;
-    uint64_t carry = 0;        // bytes of the still-open chunk at the front of dev[cur]
-    PinnedBuf pend;            // host bytes not yet shipped
-    uint64_t pend_len = 0;
-    uint64_t base = 0;         // absolute stream offset of dev[cur][0]
-    uint64_t written = 0;      // bytes accepted so far (excludes injected bytes)
-    uint64_t inject_total = 0; // injected bytes skipped in the offsets
-    uint32_t section = 0;      // increments at every forced cut
+    uint64_t carry = 0;            // bytes of the still-open chunk at the front of dev[cur]
+    uint64_t fill = 0;             // new bytes already copied behind the carry
+    hipStream_t copy_stream = nullptr;
+    PinnedBuf stage[2];
+    hipEvent_t stage_ev[2] = {};
+    int stage_idx = 0;
+    uint64_t base = 0;             // absolute stream offset of dev[cur][0]
+    uint64_t written = 0;
+    uint64_t inject_total = 0;
+    uint32_t section = 0;
     bool finished = false;
+    std::deque<WindowInFlight> inflight;
     std::deque<pbsgpu_record> out;
     std::vector<pbsgpu_record> tmp;
 };
 
 namespace {
 
-// ship pend to the device behind the carry and cut [carry+pend]; when `final` the tail chunk is
-// emitted, otherwise it is carried over (its bytes are re-examined with the next window, which
-// reproduces the serial chunker exactly because a cut only depends on bytes before it)
+// wait for the oldest hashing window, move its records to the output queue, release slot + buffer
+int stream_complete_oldest(pbsgpu_stream *s) {
+    WindowInFlight w = s->inflight.front();
+    HIPCHK(hipStreamSynchronize(w.slot->stream));
+    s->tmp.resize((size_t)w.nemit);
+    if (w.nemit) {
+        HIPCHK(hipMemcpy(s->tmp.data(), w.slot->recs.p, (size_t)w.nemit * sizeof(pbsgpu_record), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < w.nemit; ++i) {
+            pbsgpu_record r = s->tmp[(size_t)i];
+            r.end += w.base;
+            r.segment = w.section;
+            s->out.push_back(r);
+        }
+    }
+    w.slot->busy = false;
+    s->dev_busy[w.buf] = 0;
+    s->inflight.pop_front();
+    return PBSGPU_OK;
+}
+
+int stream_free_buffer(pbsgpu_stream *s) {
+    for (size_t i = 0; i < s->dev.size(); ++i)
+        if (!s->dev_busy[i] && (int)i != s->cur) return (int)i;
+    return -1;
+}
+
+// cut [carry | fill] of the current window; hash all complete chunks in the background; when not
+// `final` the tail chunk stays open and its bytes move to the front of the next window buffer (a cut
+// only depends on bytes before it, so re-examining them with more data reproduces the serial chunker)
 int stream_flush(pbsgpu_stream *s, bool final) {
     pbsgpu_engine *e = s->eng;
-    const uint64_t total = s->carry + s->pend_len;
+    const uint64_t total = s->carry + s->fill;
     if (total == 0) return PBSGPU_OK;
     std::lock_guard<std::mutex> lk(e->mu);
     CHK(set_device(e));
+    HIPCHK(hipStreamSynchronize(s->copy_stream));
     Slot *slot = find_free_slot(e);
-    if (!slot) return PBSGPU_E_BUSY;
-    DevBuf &buf = s->dev[s->cur];
-    // capacity was reserved at create time: carry <= max, pend <= window
-    if (s->pend_len) {
-        // pend is pinned and library-owned: copy straight from it (batch_sync below drains the stream)
-        HIPCHK(hipMemcpyAsync(buf.as<uint8_t>() + s->carry, s->pend.p, s->pend_len, hipMemcpyHostToDevice,
-                              slot->stream));
+    while (!slot) {
+        if (s->inflight.empty()) return PBSGPU_E_BUSY;  // slots held by other users of the engine
+        CHK(stream_complete_oldest(s));
+        slot = find_free_slot(e);
     }
+    DevBuf &buf = s->dev[s->cur];
     uint64_t nrec = 0;
     pbsgpu_segment seg{0, total};
-    CHK(batch_sync(e, *slot, buf.as<uint8_t>(), total, &seg, 1, &nrec));
-    s->tmp.resize((size_t)nrec);
-    if (nrec) {
-        HIPCHK(hipMemcpyAsync(s->tmp.data(), slot->recs.p, (size_t)nrec * sizeof(pbsgpu_record), hipMemcpyDeviceToHost,
-                              slot->stream));
-        HIPCHK(hipStreamSynchronize(slot->stream));
+    CHK(cut_sync(e, *slot, buf.as<uint8_t>(), total, &seg, 1, &nrec));
+    const uint64_t nemit = final ? nrec : (nrec ? nrec - 1 : 0);
+    pbsgpu_record open{};
+    if (!final && nrec) {
+        HIPCHK(hipMemcpy(&open, slot->recs.as<pbsgpu_record>() + (nrec - 1), sizeof(open), hipMemcpyDeviceToHost));
     }
-    const uint64_t keep = final ? nrec : (nrec ? nrec - 1 : 0);
-    for (uint64_t i = 0; i < keep; ++i) {
-        pbsgpu_record r = s->tmp[(size_t)i];
-        r.end += s->base;
-        r.segment = s->section;
-        s->out.push_back(r);
+    if (nemit) {
+        CHK(hash_async(e, *slot, nemit));
+        slot->busy = true;
+        slot->ticket = ~0ull;  // owned by the stream, never collectable through the batch API
+        s->dev_busy[s->cur] = 1;
+        WindowInFlight w;
+        w.slot = slot;
+        w.buf = s->cur;
+        w.base = s->base;
+        w.section = s->section;
+        w.nemit = nemit;
+        s->inflight.push_back(w);
     }
     if (final || nrec == 0) {
         s->base += total;
         s->carry = 0;
+        if (nemit) {  // the buffer is still being read by the SHA kernel: continue in another one
+            int nb = stream_free_buffer(s);
+            while (nb < 0) {
+                CHK(stream_complete_oldest(s));
+                nb = stream_free_buffer(s);
+            }
+            s->cur = nb;
+        }
     } else {
-        const pbsgpu_record &open = s->tmp[(size_t)nrec - 1];
         const uint64_t open_start = open.end - open.size;
-        DevBuf &next = s->dev[s->cur ^ 1];
-        HIPCHK(hipMemcpyAsync(next.p, buf.as<uint8_t>() + open_start, open.size, hipMemcpyDeviceToDevice, slot->stream));
-        HIPCHK(hipStreamSynchronize(slot->stream));
+        int nb = stream_free_buffer(s);
+        while (nb < 0) {
+            CHK(stream_complete_oldest(s));
+            nb = stream_free_buffer(s);
+        }
+        HIPCHK(hipMemcpyAsync(s->dev[nb].p, buf.as<uint8_t>() + open_start, open.size, hipMemcpyDeviceToDevice,
+                              s->copy_stream));
+        HIPCHK(hipStreamSynchronize(s->copy_stream));
         s->base += open_start;
         s->carry = open.size;
-        s->cur ^= 1;
+        s->cur = nb;
     }
-    s->pend_len = 0;
+    s->fill = 0;
+    return PBSGPU_OK;
+}
+
+// non-blocking: collect windows whose SHA kernel has finished
+int stream_reap(pbsgpu_stream *s) {
+    std::lock_guard<std::mutex> lk(s->eng->mu);
+    CHK(set_device(s->eng));
+    while (!s->inflight.empty()) {
+        hipError_t q = hipStreamQuery(s->inflight.front().slot->stream);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            break;
+        }
+        if (q != hipSuccess) {
+            g_last_hip_error.store((int)q);
+            return PBSGPU_E_HIP;
+        }
+        CHK(stream_complete_oldest(s));
+    }
+    return PBSGPU_OK;
+}
+
+int stream_drain(pbsgpu_stream *s) {
+    std::lock_guard<std::mutex> lk(s->eng->mu);
+    CHK(set_device(s->eng));
+    while (!s->inflight.empty()) CHK(stream_complete_oldest(s));
     return PBSGPU_OK;
 }
 
@@ -136,9 +228,14 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
         std::lock_guard<std::mutex> lk(e->mu);
         st = set_device(e);
         const size_t devcap = (size_t)window_bytes + (size_t)e->cfg.max + 256;
-        if (st == PBSGPU_OK) st = s->dev[0].ensure(devcap);
-        if (st == PBSGPU_OK) st = s->dev[1].ensure(devcap);
-        if (st == PBSGPU_OK) st = s->pend.ensure((size_t)window_bytes);
+        const size_t nbuf = e->slots.size() + 1;  // one being filled + one per hashing window
+        s->dev.resize(nbuf);
+        s->dev_busy.assign(nbuf, 0);
+        for (size_t i = 0; i < nbuf && st == PBSGPU_OK; ++i) st = s->dev[i].ensure(devcap);
+        for (int i = 0; i < 2 && st == PBSGPU_OK; ++i) st = s->stage[i].ensure(kStreamStage);
+        if (st == PBSGPU_OK && hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+        for (int i = 0; i < 2 && st == PBSGPU_OK; ++i)
+            if (hipEventCreateWithFlags(&s->stage_ev[i], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
     }
     if (st != PBSGPU_OK) {
         pbsgpu_stream_destroy(s);
@@ -151,11 +248,17 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
 void pbsgpu_stream_destroy(pbsgpu_stream *s) {
     if (!s) return;
     if (s->eng) {
+        (void)stream_drain(s);
         std::lock_guard<std::mutex> lk(s->eng->mu);
         (void)hipSetDevice(s->eng->device);
-        s->dev[0].release();
-        s->dev[1].release();
-        s->pend.release();
+        if (s->copy_stream) {
+            (void)hipStreamSynchronize(s->copy_stream);
+            (void)hipStreamDestroy(s->copy_stream);
+        }
+        for (auto &b : s->dev) b.release();
+        for (auto &b : s->stage) b.release();
+        for (auto &ev : s->stage_ev)
+            if (ev) (void)hipEventDestroy(ev);
     }
     delete s;
 }
@@ -165,13 +268,24 @@ int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
     if (s->finished) return PBSGPU_E_STATE;
     const uint8_t *p = static_cast<const uint8_t *>(data);
     while (len) {
-        const size_t n = (size_t)std::min<uint64_t>(len, s->window - s->pend_len);
-        std::memcpy(s->pend.as<uint8_t>() + s->pend_len, p, n);
-        s->pend_len += n;
+        size_t n = (size_t)std::min<uint64_t>(len, s->window - s->fill);
+        n = std::min(n, kStreamStage);
+        {   // caller bytes -> library-owned pinned staging -> device window (async on the copy stream)
+            std::lock_guard<std::mutex> lk(s->eng->mu);
+            CHK(set_device(s->eng));
+            const int k = s->stage_idx;
+            HIPCHK(hipEventSynchronize(s->stage_ev[k]));
+            std::memcpy(s->stage[k].p, p, n);
+            HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->carry + s->fill, s->stage[k].p, n,
+                                  hipMemcpyHostToDevice, s->copy_stream));
+            HIPCHK(hipEventRecord(s->stage_ev[k], s->copy_stream));
+            s->stage_idx ^= 1;
+        }
+        s->fill += n;
         s->written += n;
         p += n;
         len -= n;
-        if (s->pend_len == s->window) CHK(stream_flush(s, false));
+        if (s->fill == s->window) CHK(stream_flush(s, false));
     }
     return PBSGPU_OK;
 }
@@ -190,12 +304,14 @@ int pbsgpu_stream_finish(pbsgpu_stream *s) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished) return PBSGPU_OK;
     CHK(stream_flush(s, true));
+    CHK(stream_drain(s));
     s->finished = true;
     return PBSGPU_OK;
 }
 
 int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint64_t *n) {
     if (!s || !n || (!out && cap)) return PBSGPU_E_INVALID;
+    CHK(stream_reap(s));
     uint64_t k = 0;
     while (k < cap && !s->out.empty()) {
         out[k++] = s->out.front();
