@@ -190,6 +190,15 @@ int pbsgpu_sha256_many_device(pbsgpu_engine *eng, const void *dptr, uint64_t nby
 int pbsgpu_sha256_many_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
                             const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests);
 
+/* ---- whole-stream XXH3-64 batch ---------------------------------------------------
+ * The per-file hash the commit path tees new file bodies through and re-checks afterwards:
+ * xxh3.New() ... Sum64() (internal/pxarmount/commit_reuse.go:450-461), verifyBackedFileHashes
+ * (internal/pxarmount/commit_orchestrate.go:485-562). out[i] = XXH3-64(seed 0) of segs[i]. */
+int pbsgpu_xxh3_many_device(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes,
+                            const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out /* nseg */);
+int pbsgpu_xxh3_many_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
+                          const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out);
+
 /* ---- digest-set operations (cross-file duplicate detection) -----------------
  * Sort records by digest on the device and flag duplicates: dup[i] = 1 when
  * an earlier record (lower index) carries the same digest. Used on the
@@ -214,6 +223,29 @@ int pbsgpu_didx_encode(pbsgpu_engine *eng, const pbsgpu_record *recs, uint64_t n
                        int64_t ctime, uint8_t *out, uint64_t cap);
 int pbsgpu_didx_decode(const uint8_t *in, uint64_t nbytes, pbsgpu_record *out, uint64_t cap, uint64_t *n,
                        int64_t *ctime, uint8_t index_csum[32]);
+
+/* ---- payload-stream assembly ----------------------------------------------------
+ * The step before the chunker: the .ppxar payload stream WriteEntryReader appends to
+ * (one continuous stream per archive, files separated by format.HeaderSize = 16-byte
+ * headers: internal/pxarmount/commit_types.go:24-32 rangeEnd = offset + FileSize +
+ * format.HeaderSize; keepLast_chunk_test.go:105). Layout written to `dst`:
+ *   [start marker {start_type, 16}]  { [{payload_type, 16 + len_i}] [file i bytes] }*  [tail {tail_type, 16}]
+ * Each header is {type u64 LE, full size u64 LE}. The three type constants default to the
+ * pxar v2 values (EXTERNAL, injectable). payload_offsets[i] = stream offset of file i's
+ * header = what WriteEntryRef / PAYLOAD_REF records (commit_walk.go:455). */
+typedef struct pbsgpu_payload_format {
+    uint64_t payload_type;  /* PXAR_PAYLOAD */
+    uint64_t start_type;    /* PXAR_PAYLOAD_START_MARKER */
+    uint64_t tail_type;     /* PXAR_PAYLOAD_TAIL_MARKER */
+    uint32_t with_start;    /* emit the start marker */
+    uint32_t with_tail;     /* emit the tail marker */
+} pbsgpu_payload_format;
+int pbsgpu_payload_format_default(pbsgpu_payload_format *out);
+int pbsgpu_payload_size(const pbsgpu_segment *files, uint32_t nfiles, const pbsgpu_payload_format *fmt,
+                        uint64_t *nbytes);
+int pbsgpu_payload_pack_device(pbsgpu_engine *eng, const void *src, uint64_t src_bytes, const pbsgpu_segment *files,
+                               uint32_t nfiles, const pbsgpu_payload_format *fmt, void *dst, uint64_t dst_cap,
+                               uint64_t *out_len, uint64_t *payload_offsets /* nfiles or NULL */);
 
 /* ---- synthetic corpus generator ----------------------------------------------
  * Fills device memory with the deterministic byte stream the benchmarks and

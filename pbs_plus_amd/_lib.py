@@ -60,6 +60,16 @@ class Timing(C.Structure):
     ]
 
 
+class PayloadFormat(C.Structure):
+    _fields_ = [
+        ("payload_type", C.c_uint64),
+        ("start_type", C.c_uint64),
+        ("tail_type", C.c_uint64),
+        ("with_start", C.c_uint32),
+        ("with_tail", C.c_uint32),
+    ]
+
+
 class DedupStats(C.Structure):
     _fields_ = [
         ("nrecords", C.c_uint64),
@@ -105,10 +115,16 @@ SYMBOLS = {
     "pbsgpu_stream_position": (C.c_int, [_P, _U64P]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
+    "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
+    "pbsgpu_xxh3_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_dedup_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(DedupStats)]),
     "pbsgpu_didx_size": (C.c_int, [C.c_uint64, _U64P]),
     "pbsgpu_didx_encode": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int64, _P, C.c_uint64]),
     "pbsgpu_didx_decode": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P, C.POINTER(C.c_int64), _P]),
+    "pbsgpu_payload_format_default": (C.c_int, [C.POINTER(PayloadFormat)]),
+    "pbsgpu_payload_size": (C.c_int, [_P, C.c_uint32, C.POINTER(PayloadFormat), _U64P]),
+    "pbsgpu_payload_pack_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.POINTER(PayloadFormat), _P, C.c_uint64,
+                                             _U64P, _P]),
     "pbsgpu_fill_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "pbsgpu_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "pbsgpu_device_free": (C.c_int, [_P, _P]),

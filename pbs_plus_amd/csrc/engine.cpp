@@ -600,6 +600,47 @@ int pbsgpu_sha256_many_host(pbsgpu_engine *e, const void *hptr, uint64_t nbytes,
     return sha256_many(e, hptr, true, nbytes, segs, nseg, digests);
 }
 
+static int xxh3_many(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nbytes, const pbsgpu_segment *segs,
+                     uint32_t nseg, uint64_t *out) {
+    if (!e || (!ptr && nbytes) || (nseg && (!segs || !out))) return PBSGPU_E_INVALID;
+    if (nseg == 0) return PBSGPU_OK;
+    for (uint32_t i = 0; i < nseg; ++i)
+        if (segs[i].length > nbytes || segs[i].offset > nbytes - segs[i].length) return PBSGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CHK(set_device(e));
+    Slot *s = find_free_slot(e);
+    if (!s) return PBSGPU_E_BUSY;
+    CHK(s->h_segs.ensure((size_t)nseg * sizeof(pbsgpu_segment)));
+    std::memcpy(s->h_segs.p, segs, (size_t)nseg * sizeof(pbsgpu_segment));
+    CHK(s->segs.ensure((size_t)nseg * sizeof(pbsgpu_segment)));
+    HIPCHK(hipMemcpyAsync(s->segs.p, s->h_segs.p, (size_t)nseg * sizeof(pbsgpu_segment), hipMemcpyHostToDevice,
+                          s->stream));
+    const uint8_t *d = static_cast<const uint8_t *>(ptr);
+    if (host) {
+        CHK(s->data.ensure((size_t)nbytes + 64));
+        CHK(staged_h2d(e, s->data.p, ptr, nbytes, s->stream));
+        d = s->data.as<uint8_t>();
+    }
+    CHK(s->recs.ensure((size_t)nseg * 8 + 64));
+    CHK(s->scalars.ensure(SC_COUNT * 4));
+    HIPCHK(hipMemsetAsync(s->scalars.p, 0, SC_COUNT * 4, s->stream));
+    HIPCHK(pbsk::launch_xxh3(d, s->segs.as<pbsgpu_segment>(), nseg, s->recs.as<uint64_t>(),
+                             s->scalars.as<uint32_t>() + SC_QUEUE, e->num_cus, s->stream));
+    HIPCHK(hipMemcpyAsync(out, s->recs.p, (size_t)nseg * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PBSGPU_OK;
+}
+
+int pbsgpu_xxh3_many_device(pbsgpu_engine *e, const void *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
+                            uint32_t nseg, uint64_t *out) {
+    return xxh3_many(e, dptr, false, nbytes, segs, nseg, out);
+}
+
+int pbsgpu_xxh3_many_host(pbsgpu_engine *e, const void *hptr, uint64_t nbytes, const pbsgpu_segment *segs,
+                          uint32_t nseg, uint64_t *out) {
+    return xxh3_many(e, hptr, true, nbytes, segs, nseg, out);
+}
+
 int pbsgpu_fill_device(pbsgpu_engine *e, void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed,
                        uint32_t kind) {
     if (!e || (!dptr && nbytes) || ((uintptr_t)dptr & 7u) || (stream_off & 7u) || kind > 3) return PBSGPU_E_INVALID;

@@ -66,6 +66,10 @@ hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
                                   uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);
 
+// XXH3-64 (seed 0) of whole segments: out[i] for segs[i]; `queue` zero at launch
+hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
+                       int num_cus, hipStream_t st);
+
 hipError_t launch_fill(void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed, uint32_t kind,
                        hipStream_t st);
 
@@ -74,5 +78,16 @@ hipError_t launch_dedup(const pbsgpu_record *recs, uint64_t n, uint64_t *keys, u
                         uint64_t *keys_alt, uint32_t *idx_alt, uint8_t *dup, uint64_t *stats4,
                         void *tmp, size_t tmp_bytes, hipStream_t st);
 size_t dedup_tmp_bytes(uint64_t n);
+
+// payload-stream assembly: kind 0 = copy len bytes from src_base+src_off; kind 1 = 16-byte
+// {type = src_off, size = len} header at dst_off
+struct PackItem {
+    uint64_t src_off;
+    uint64_t dst_off;
+    uint64_t len;
+    uint32_t kind;
+    uint32_t pad;
+};
+hipError_t launch_pack(const uint8_t *src_base, uint8_t *dst, const PackItem *items, uint32_t nitems, hipStream_t st);
 
 }  // namespace pbsk

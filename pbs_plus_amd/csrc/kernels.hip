@@ -1202,4 +1202,249 @@ hipError_t launch_dedup(const pbsgpu_record *recs, uint64_t n, uint64_t *keys, u
     return hipGetLastError();
 }
 
+// =====================================================================================
+// payload-stream assembly (pxar v2 split archive, .ppxar): [start marker] { [header 16 B][content] }* [tail]
+// =====================================================================================
+// One work item = one <= 4 MiB piece of one file (table built on the host, which knows the file
+// list). A workgroup copies its piece with 16-byte stores to the (arbitrarily aligned) destination;
+// sources are read as 4-byte-aligned dwords and funnel-shifted (v_alignbyte) into place.
+__device__ __forceinline__ uint32_t load_shifted(const uint8_t *src) {  // 4 bytes at any alignment
+    const uint32_t o = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(src - o);
+    const uint32_t lo = a[0];
+    if (o == 0) return lo;
+    return __builtin_amdgcn_alignbyte(a[1], lo, o);
+}
+
+__global__ __launch_bounds__(256) void k_pack(const uint8_t *src_base, uint8_t *dst, const PackItem *items,
+                                              uint32_t nitems) {
+    const uint32_t it = blockIdx.x;
+    if (it >= nitems) return;
+    const PackItem w = items[it];
+    uint8_t *d = dst + w.dst_off;
+    if (w.kind != 0) {  // 16-byte header / marker: {type u64 LE, size u64 LE}
+        if (threadIdx.x < 16) {
+            const uint64_t v = (threadIdx.x < 8) ? w.src_off /* type */ : w.len /* size field */;
+            d[threadIdx.x] = (uint8_t)(v >> (8 * (threadIdx.x & 7)));
+        }
+        return;
+    }
+    const uint8_t *sp = src_base + w.src_off;
+    const uint64_t n = w.len;
+    // head: bytes until the destination is 16-byte aligned
+    uint64_t head = (16 - ((uintptr_t)d & 15u)) & 15u;
+    if (head > n) head = n;
+    if (threadIdx.x < head) d[threadIdx.x] = sp[threadIdx.x];
+    const uint64_t body = (n - head) / 16;
+    const uint8_t *sb = sp + head;
+    uint8_t *db = d + head;
+    for (uint64_t i = threadIdx.x; i < body; i += blockDim.x) {
+        const uint8_t *q = sb + i * 16;
+        uint4 v;
+        if ((((uintptr_t)q) & 3u) == 0) {
+            const u32x4_a4 t = *reinterpret_cast<const u32x4_a4 *>(q);
+            v = make_uint4(t.x, t.y, t.z, t.w);
+        } else {
+            v = make_uint4(load_shifted(q), load_shifted(q + 4), load_shifted(q + 8), load_shifted(q + 12));
+        }
+        *reinterpret_cast<uint4 *>(db + i * 16) = v;
+    }
+    const uint64_t done = head + body * 16;
+    const uint64_t tail = n - done;
+    if (threadIdx.x < tail) d[done + threadIdx.x] = sp[done + threadIdx.x];
+}
+
+hipError_t launch_pack(const uint8_t *src_base, uint8_t *dst, const PackItem *items, uint32_t nitems, hipStream_t st) {
+    if (nitems == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack, dim3(nitems), dim3(256), 0, st, src_base, dst, items, nitems);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// XXH3-64 (seed 0, default secret) of many byte ranges — the per-file hash the reference tees
+// new file bodies through (xxh3.New(), internal/pxarmount/commit_reuse.go:450-461) and re-checks
+// after the commit (commit_orchestrate.go:485-562).
+// =====================================================================================
+// 8 lanes per range, one per accumulator (XXH3's 512-bit state is 8 independent u64 lanes whose only
+// coupling is acc[i^1] += data[i]: a neighbour shuffle). A wave carries 8 ranges; octets pull ranges
+// from a queue. Inputs <= 240 bytes take the scalar formulas on the octet's first lane.
+__device__ constexpr uint8_t kXxhSecret[192] = {
+    0xb8, 0xfe, 0x6c, 0x39, 0x23, 0xa4, 0x4b, 0xbe, 0x7c, 0x01, 0x81, 0x2c, 0xf7, 0x21, 0xad, 0x1c, 0xde, 0xd4, 0x6d, 0xe9,
+    0x83, 0x90, 0x97, 0xdb, 0x72, 0x40, 0xa4, 0xa4, 0xb7, 0xb3, 0x67, 0x1f, 0xcb, 0x79, 0xe6, 0x4e, 0xcc, 0xc0, 0xe5, 0x78,
+    0x82, 0x5a, 0xd0, 0x7d, 0xcc, 0xff, 0x72, 0x21, 0xb8, 0x08, 0x46, 0x74, 0xf7, 0x43, 0x24, 0x8e, 0xe0, 0x35, 0x90, 0xe6,
+    0x81, 0x3a, 0x26, 0x4c, 0x3c, 0x28, 0x52, 0xbb, 0x91, 0xc3, 0x00, 0xcb, 0x88, 0xd0, 0x65, 0x8b, 0x1b, 0x53, 0x2e, 0xa3,
+    0x71, 0x64, 0x48, 0x97, 0xa2, 0x0d, 0xf9, 0x4e, 0x38, 0x19, 0xef, 0x46, 0xa9, 0xde, 0xac, 0xd8, 0xa8, 0xfa, 0x76, 0x3f,
+    0xe3, 0x9c, 0x34, 0x3f, 0xf9, 0xdc, 0xbb, 0xc7, 0xc7, 0x0b, 0x4f, 0x1d, 0x8a, 0x51, 0xe0, 0x4b, 0xcd, 0xb4, 0x59, 0x31,
+    0xc8, 0x9f, 0x7e, 0xc9, 0xd9, 0x78, 0x73, 0x64, 0xea, 0xc5, 0xac, 0x83, 0x34, 0xd3, 0xeb, 0xc3, 0xc5, 0x81, 0xa0, 0xff,
+    0xfa, 0x13, 0x63, 0xeb, 0x17, 0x0d, 0xdd, 0x51, 0xb7, 0xf0, 0xda, 0x49, 0xd3, 0x16, 0x55, 0x26, 0x29, 0xd4, 0x68, 0x9e,
+    0x2b, 0x16, 0xbe, 0x58, 0x7d, 0x47, 0xa1, 0xfc, 0x8f, 0xf8, 0xb8, 0xd1, 0x7a, 0xd0, 0x31, 0xce, 0x45, 0xcb, 0x3a, 0x8f,
+    0x95, 0x16, 0x04, 0x28, 0xaf, 0xd7, 0xfb, 0xca, 0xbb, 0x4b, 0x40, 0x7e};
+
+namespace xxh {
+constexpr uint64_t P32_1 = 0x9E3779B1ull, P32_2 = 0x85EBCA77ull, P32_3 = 0xC2B2AE3Dull;
+constexpr uint64_t P64_1 = 0x9E3779B185EBCA87ull, P64_2 = 0xC2B2AE3D27D4EB4Full, P64_3 = 0x165667B19E3779F9ull;
+constexpr uint64_t P64_4 = 0x85EBCA77C2B2AE63ull, P64_5 = 0x27D4EB2F165667C5ull;
+constexpr uint64_t PMX1 = 0x165667919E3779F9ull, PMX2 = 0x9FB21C651E98DF25ull;
+
+__device__ __forceinline__ uint64_t sec64(int off) {  // little-endian 8 bytes of the secret (any offset)
+    uint64_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) v |= (uint64_t)kXxhSecret[off + b] << (8 * b);
+    return v;
+}
+__device__ __forceinline__ uint64_t sec64_dyn(int off) {
+    uint64_t v = 0;
+    for (int b = 0; b < 8; ++b) v |= (uint64_t)kXxhSecret[off + b] << (8 * b);
+    return v;
+}
+__device__ __forceinline__ uint64_t rd64(const uint8_t *p) {  // byte-safe little-endian load
+    uint64_t v = 0;
+    for (int b = 0; b < 8; ++b) v |= (uint64_t)p[b] << (8 * b);
+    return v;
+}
+__device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+__device__ __forceinline__ uint64_t fold128(uint64_t a, uint64_t b) { return (a * b) ^ __umul64hi(a, b); }
+__device__ __forceinline__ uint64_t avalanche(uint64_t h) {
+    h ^= h >> 37;
+    h *= PMX1;
+    return h ^ (h >> 32);
+}
+__device__ __forceinline__ uint64_t avalanche64(uint64_t h) {
+    h ^= h >> 33;
+    h *= P64_2;
+    h ^= h >> 29;
+    h *= P64_3;
+    return h ^ (h >> 32);
+}
+__device__ __forceinline__ uint64_t mix16(const uint8_t *d, int so) {
+    return fold128(rd64(d) ^ sec64_dyn(so), rd64(d + 8) ^ sec64_dyn(so + 8));
+}
+// inputs of 0..240 bytes (one lane)
+__device__ uint64_t short_hash(const uint8_t *d, uint64_t n) {
+    if (n == 0) return avalanche64(sec64(56) ^ sec64(64));
+    if (n <= 3) {
+        const uint32_t comb = ((uint32_t)d[0] << 16) | ((uint32_t)d[n >> 1] << 24) | (uint32_t)d[n - 1] | ((uint32_t)n << 8);
+        const uint32_t flip = (uint32_t)sec64(0) ^ (uint32_t)(sec64(0) >> 32);
+        return avalanche64((uint64_t)(comb ^ flip));
+    }
+    if (n <= 8) {
+        const uint64_t in1 = rd32(d), in2 = rd32(d + n - 4);
+        uint64_t h = (in2 + (in1 << 32)) ^ (sec64(8) ^ sec64(16));
+        h ^= rotl64(h, 49) ^ rotl64(h, 24);
+        h *= PMX2;
+        h ^= (h >> 35) + n;
+        h *= PMX2;
+        return h ^ (h >> 28);
+    }
+    if (n <= 16) {
+        const uint64_t lo = rd64(d) ^ (sec64(24) ^ sec64(32));
+        const uint64_t hi = rd64(d + n - 8) ^ (sec64(40) ^ sec64(48));
+        return avalanche(n + __builtin_bswap64(lo) + hi + fold128(lo, hi));
+    }
+    if (n <= 128) {
+        uint64_t acc = n * P64_1;
+        if (n > 32) {
+            if (n > 64) {
+                if (n > 96) acc += mix16(d + 48, 96) + mix16(d + n - 64, 112);
+                acc += mix16(d + 32, 64) + mix16(d + n - 48, 80);
+            }
+            acc += mix16(d + 16, 32) + mix16(d + n - 32, 48);
+        }
+        acc += mix16(d, 0) + mix16(d + n - 16, 16);
+        return avalanche(acc);
+    }
+    uint64_t acc = n * P64_1;
+    for (int i = 0; i < 8; ++i) acc += mix16(d + 16 * i, 16 * i);
+    acc = avalanche(acc);
+    const int rounds = (int)(n / 16);
+    for (int i = 8; i < rounds; ++i) acc += mix16(d + 16 * i, 16 * (i - 8) + 3);
+    acc += mix16(d + n - 16, 136 - 17);
+    return avalanche(acc);
+}
+}  // namespace xxh
+
+__global__ __launch_bounds__(256) void k_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
+                                              uint64_t *out, uint32_t *queue) {
+    using namespace xxh;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 7;          // accumulator index
+    const int ol = lane & ~7;         // first lane of this octet
+    // per-lane secret words: stripe s of a block uses secret[8*(s+li) ..], scramble uses secret[128+8*li ..]
+    uint64_t sk[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sk[s] = sec64_dyn(8 * (s + li));
+    const uint64_t sk_scr = sec64_dyn(128 + 8 * li);
+    const uint64_t sk_last = sec64_dyn(121 + 8 * li);
+    const uint64_t sk_merge = sec64_dyn(11 + 8 * li);
+    const uint64_t init[8] = {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1};
+
+    // Wave-uniform outer loop: every trip each live octet takes ONE range. The queue grab is done
+    // with all 64 lanes converged (ballot + one atomic per wave); inside the body the only shuffles
+    // are intra-octet and the control flow around them is octet-uniform.
+    bool done = false;
+    while (!__all(done)) {
+        const unsigned long long need = __ballot(!done && li == 0);
+        uint32_t first = 0;
+        if (need) {
+            const int leader = __ffsll((long long)need) - 1;
+            if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(need));
+            first = __shfl(first, leader, 64);
+        }
+        uint32_t idx = first + (uint32_t)__popcll(need & ((1ull << ol) - 1ull));  // rank of this octet
+        if (!done && idx >= nseg) done = true;
+        if (!done) {
+            const uint8_t *d = data + segs[idx].offset;
+            const uint64_t n = segs[idx].length;
+            if (n <= 240) {
+                if (li == 0) out[idx] = short_hash(d, n);
+            } else {
+                uint64_t acc = init[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) acc = (li == i) ? init[i] : acc;
+                auto stripe = [&](const uint8_t *sp, uint64_t key) {
+                    uint64_t v;
+                    __builtin_memcpy(&v, sp + 8 * li, 8);
+                    const uint64_t k = v ^ key;
+                    const uint64_t nb = __shfl_xor(v, 1, 64);  // data of accumulator li^1
+                    acc += nb;
+                    acc += (uint64_t)(uint32_t)k * (uint64_t)(uint32_t)(k >> 32);
+                };
+                const uint64_t nb_blocks = (n - 1) / 1024;
+                for (uint64_t b = 0; b < nb_blocks; ++b) {
+                    const uint8_t *bp = d + b * 1024;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) stripe(bp + 64 * s, sk[s]);
+                    acc ^= acc >> 47;
+                    acc ^= sk_scr;
+                    acc *= P32_1;
+                }
+                const uint64_t nstripes = ((n - 1) - 1024 * nb_blocks) / 64;
+                const uint8_t *bp = d + nb_blocks * 1024;
+                for (uint64_t s = 0; s < nstripes; ++s) stripe(bp + 64 * s, sec64_dyn(8 * ((int)s + li)));
+                stripe(d + n - 64, sk_last);
+                // merge: pairs (acc[2k] ^ secret[11+16k], acc[2k+1] ^ secret[11+16k+8])
+                const uint64_t mine = acc ^ sk_merge;
+                const uint64_t other = __shfl_xor(mine, 1, 64);
+                uint64_t part = ((li & 1) == 0) ? fold128(mine, other) : 0;
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                if (li == 0) out[idx] = avalanche(n * P64_1 + part);
+            }
+        }
+    }
+}
+
+hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
+                       int num_cus, hipStream_t st) {
+    if (nseg == 0) return hipSuccess;
+    unsigned grid = (unsigned)num_cus * 4u;
+    const unsigned need = (nseg + 31) / 32;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, data, segs, nseg, out, queue);
+    return hipGetLastError();
+}
+
 }  // namespace pbsk

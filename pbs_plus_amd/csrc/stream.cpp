@@ -425,6 +425,69 @@ int pbsgpu_chunker_scan(pbsgpu_chunker *c, const void *data, size_t len, size_t 
     return PBSGPU_OK;
 }
 
+// ---- payload-stream assembly -----------------------------------------------------------------
+int pbsgpu_payload_format_default(pbsgpu_payload_format *out) {
+    if (!out) return PBSGPU_E_INVALID;
+    out->payload_type = 0x28147a1b0b7c1a25ull;  // PXAR_PAYLOAD            (pxar v2 constants, EXTERNAL)
+    out->start_type = 0x834c68c2194a4ed2ull;    // PXAR_PAYLOAD_START_MARKER
+    out->tail_type = 0x6c72b78b984c81b5ull;     // PXAR_PAYLOAD_TAIL_MARKER
+    out->with_start = 1;
+    out->with_tail = 1;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_payload_size(const pbsgpu_segment *files, uint32_t nfiles, const pbsgpu_payload_format *fmt,
+                        uint64_t *nbytes) {
+    if (!nbytes || !fmt || (nfiles && !files)) return PBSGPU_E_INVALID;
+    uint64_t n = (fmt->with_start ? 16 : 0) + (fmt->with_tail ? 16 : 0);
+    for (uint32_t i = 0; i < nfiles; ++i) n += 16 + files[i].length;
+    *nbytes = n;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_payload_pack_device(pbsgpu_engine *e, const void *src, uint64_t src_bytes, const pbsgpu_segment *files,
+                               uint32_t nfiles, const pbsgpu_payload_format *fmt, void *dst, uint64_t dst_cap,
+                               uint64_t *out_len, uint64_t *payload_offsets) {
+    if (!e || !fmt || !dst || !out_len || (nfiles && (!files || !src))) return PBSGPU_E_INVALID;
+    uint64_t need = 0;
+    CHK(pbsgpu_payload_size(files, nfiles, fmt, &need));
+    *out_len = need;
+    if (dst_cap < need) return PBSGPU_E_CAPACITY;
+    for (uint32_t i = 0; i < nfiles; ++i)
+        if (files[i].length > src_bytes || files[i].offset > src_bytes - files[i].length) return PBSGPU_E_INVALID;
+    constexpr uint64_t kPiece = 4ull << 20;
+    std::vector<pbsk::PackItem> items;
+    items.reserve((size_t)nfiles * 2 + (size_t)(need / kPiece) + 4);
+    uint64_t pos = 0;
+    auto header = [&](uint64_t type, uint64_t size) {
+        items.push_back(pbsk::PackItem{type, pos, size, 1u, 0u});
+        pos += 16;
+    };
+    if (fmt->with_start) header(fmt->start_type, 16);
+    for (uint32_t i = 0; i < nfiles; ++i) {
+        if (payload_offsets) payload_offsets[i] = pos;
+        header(fmt->payload_type, 16 + files[i].length);
+        for (uint64_t o = 0; o < files[i].length; o += kPiece) {
+            const uint64_t n = std::min<uint64_t>(kPiece, files[i].length - o);
+            items.push_back(pbsk::PackItem{files[i].offset + o, pos + o, n, 0u, 0u});
+        }
+        pos += files[i].length;
+    }
+    if (fmt->with_tail) header(fmt->tail_type, 16);
+    if (items.size() >= (1ull << 31)) return PBSGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CHK(set_device(e));
+    Slot *s = find_free_slot(e);
+    if (!s) return PBSGPU_E_BUSY;
+    const size_t bytes = items.size() * sizeof(pbsk::PackItem);
+    CHK(s->tile_slots.ensure(bytes + 64));
+    CHK(staged_h2d(e, s->tile_slots.p, items.data(), bytes, s->stream));
+    HIPCHK(pbsk::launch_pack(static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst),
+                             s->tile_slots.as<pbsk::PackItem>(), (uint32_t)items.size(), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PBSGPU_OK;
+}
+
 // ---- digest-set duplicate detection ---------------------------------------------------------
 int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, uint8_t *dup,
                       pbsgpu_dedup_stats *stats) {

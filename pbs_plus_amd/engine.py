@@ -168,6 +168,35 @@ class Engine:
                                                   out.ctypes.data), "sha256_many_host")
         return out[:nseg]
 
+    # ---- whole-stream XXH3-64 (the xxh3.New() tee of writeBackedFile / verifyBackedFileHashes) -------
+    def xxh3_many(self, data, segments, nbytes: int | None = None) -> np.ndarray:
+        segs, nseg = _segs(segments)
+        out = np.zeros(max(nseg, 1), dtype=np.uint64)
+        ptr, n = self._dev(data, nbytes)
+        if ptr is not None:
+            check(self._L.pbsgpu_xxh3_many_device(self._h, ptr, n, segs, nseg, out.ctypes.data), "xxh3_many_device")
+        else:
+            a = _host_view(data)
+            check(self._L.pbsgpu_xxh3_many_host(self._h, a.ctypes.data if a.size else None, a.size, segs, nseg,
+                                                out.ctypes.data), "xxh3_many_host")
+        return out[:nseg]
+
+    # ---- payload-stream assembly (.ppxar layout: markers + 16-byte headers + file bodies) ----------
+    def payload_pack(self, src, files, dst, with_start: bool = True, with_tail: bool = True):
+        """Lay the file bodies `files` = [(offset, length)] of device buffer `src` out as the pxar
+        payload stream in device buffer `dst`. Returns (stream length, payload offset of every file's header)."""
+        fmt = _lib.PayloadFormat()
+        check(self._L.pbsgpu_payload_format_default(C.byref(fmt)), "payload_format_default")
+        fmt.with_start, fmt.with_tail = int(with_start), int(with_tail)
+        segs, n = _segs(files)
+        sp, sn = self._dev(src)
+        dp, dn = self._dev(dst)
+        out_len = C.c_uint64()
+        offs = np.zeros(max(n, 1), dtype=np.uint64)
+        check(self._L.pbsgpu_payload_pack_device(self._h, sp, sn, segs, n, C.byref(fmt), dp, dn, C.byref(out_len),
+                                                 offs.ctypes.data), "payload_pack_device")
+        return out_len.value, offs[:n]
+
     # ---- digest set ------------------------------------------------------------------------------------
     def dedup(self, records: np.ndarray):
         """(dup flags, stats) — dup[i] = 1 when an earlier record has the same digest."""

@@ -355,3 +355,66 @@ def test_full_size_config2_properties(engines, O):
         data = buf.download(start, int(sizes[i]))
         assert bytes(recs["digest"][i]) == hashlib.sha256(data.tobytes()).digest(), i
     buf.free()
+
+
+def test_payload_pack_layout_and_chunking(engines, O):
+    """(f)-3 payload-stream assembly: markers + 16-byte {type, 16+len} headers + bodies, then the
+    packed stream is cut as ONE stream (chunks span files) and must equal the oracle on the same bytes.
+    Header arithmetic mirrors commit_types.go:24-32 (rangeEnd = offset + FileSize + HeaderSize)."""
+    eng = engines(4096)
+    rng = np.random.default_rng(17)
+    lens = [0, 1, 15, 16, 17, 4096, 100_003, 1 << 20, 333, 2_000_001]
+    offs, pos = [], 3  # odd source offsets: misaligned gather
+    for n in lens:
+        offs.append(pos)
+        pos += n + int(rng.integers(0, 7))
+    src_host = rng.integers(0, 256, pos + 64, dtype=np.uint8)
+    src = eng.alloc(src_host.size)
+    src.upload(src_host)
+    files = list(zip(offs, lens))
+    total = 32 + sum(16 + n for n in lens)
+    dst = eng.alloc(total + 5)
+    out_len, hdr_offs = eng.payload_pack(src, files, dst)
+    assert out_len == total
+    got = dst.download(0, total)
+    PAYLOAD, START, TAIL = 0x28147a1b0b7c1a25, 0x834c68c2194a4ed2, 0x6c72b78b984c81b5
+    want = bytearray(START.to_bytes(8, "little") + (16).to_bytes(8, "little"))
+    exp_offs = []
+    for o, n in files:
+        exp_offs.append(len(want))
+        want += PAYLOAD.to_bytes(8, "little") + (16 + n).to_bytes(8, "little") + src_host[o:o + n].tobytes()
+    want += TAIL.to_bytes(8, "little") + (16).to_bytes(8, "little")
+    assert got.tobytes() == bytes(want)
+    assert hdr_offs.tolist() == exp_offs
+    # reference arithmetic: next file's header starts at rangeEnd = offset + FileSize + HeaderSize
+    for (o, n), a, b in zip(files[:-1], exp_offs[:-1], exp_offs[1:]):
+        assert b == a + n + 16
+    recs = eng.chunk_and_digest(dst, [(0, total)], nbytes=total)
+    wrecs = O.chunk_and_digest(O.new_config(4096), np.frombuffer(bytes(want), dtype=np.uint8))
+    assert records_equal(recs, wrecs), describe_mismatch(recs, wrecs)
+    src.free()
+    dst.free()
+
+
+def test_xxh3_many_matches_xxhash_library(engines):
+    """XXH3-64 of many files at once (the hash writeBackedFile tees through, commit_reuse.go:450-461),
+    checked against the independent xxhash C library on every length class and odd alignments."""
+    import xxhash
+
+    eng = engines(4096)
+    rng = np.random.default_rng(21)
+    lens = list(range(0, 260)) + [511, 512, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 65_537, 1_000_003, 3 << 20]
+    blob = rng.integers(0, 256, sum(lens) + len(lens) * 3 + 64, dtype=np.uint8)
+    segs, off = [], 1
+    for n in lens:
+        segs.append((off, n))
+        off += n + (n % 3)  # ragged, unaligned starts
+    got = eng.xxh3_many(blob, segs)
+    for (o, n), g in zip(segs, got):
+        assert int(g) == xxhash.xxh3_64_intdigest(blob[o:o + n].tobytes()), n
+    # device-resident variant
+    buf = eng.alloc(blob.size)
+    buf.upload(blob)
+    got2 = eng.xxh3_many(buf, segs)
+    buf.free()
+    assert np.array_equal(got, got2)
