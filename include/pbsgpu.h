@@ -247,6 +247,27 @@ int pbsgpu_payload_pack_device(pbsgpu_engine *eng, const void *src, uint64_t src
                                uint32_t nfiles, const pbsgpu_payload_format *fmt, void *dst, uint64_t dst_cap,
                                uint64_t *out_len, uint64_t *payload_offsets /* nfiles or NULL */);
 
+/* ---- chunk-reuse planner (host-side index arithmetic) --------------------------------
+ * What the commit walk does with the PREVIOUS snapshot's dynamic index before it decides
+ * to splice old chunks in (InjectChunks) or to re-feed the bytes to the chunker:
+ *   lookupDynamicEntries(idx, rangeStart, rangeEnd) -> chunks, startPadding, endPadding
+ *     (internal/pxarmount/commit_reuse.go:84-135; table test commit_bottleneck_test.go:795-835)
+ *   shouldReuse: padding / (range + padding) <= chunkPaddingThreshold = 0.1
+ *     (commit_reuse.go:152-183, commit_types.go:14; test commit_bottleneck_test.go:837-895)
+ * `idx` is the record list of one stream (ascending `end`, e.g. from pbsgpu_didx_decode). */
+typedef struct pbsgpu_reuse_chunk {
+    uint64_t size;       /* chunk length */
+    uint64_t padding;    /* bytes of the chunk outside the requested range */
+    uint64_t end_offset; /* chunk end in the old payload stream */
+    uint8_t digest[32];
+} pbsgpu_reuse_chunk;
+int pbsgpu_reuse_lookup(const pbsgpu_record *idx, uint64_t n, uint64_t range_start, uint64_t range_end,
+                        pbsgpu_reuse_chunk *out, uint64_t cap, uint64_t *nchunks, uint64_t *start_padding,
+                        uint64_t *end_padding);
+/* saved = the chunk kept from the previous batch (keepLastChunk), or NULL. *reuse = 1/0. */
+int pbsgpu_reuse_should(const pbsgpu_record *idx, uint64_t n, uint64_t range_start, uint64_t range_end,
+                        const pbsgpu_reuse_chunk *saved, double threshold, int *reuse);
+
 /* ---- synthetic corpus generator ----------------------------------------------
  * Fills device memory with the deterministic byte stream the benchmarks and
  * parity tests use (the oracle has the CPU twin). kind: 0 random, 1 zeros,

@@ -70,6 +70,10 @@ class PayloadFormat(C.Structure):
     ]
 
 
+class ReuseChunk(C.Structure):
+    _fields_ = [("size", C.c_uint64), ("padding", C.c_uint64), ("end_offset", C.c_uint64), ("digest", C.c_uint8 * 32)]
+
+
 class DedupStats(C.Structure):
     _fields_ = [
         ("nrecords", C.c_uint64),
@@ -125,6 +129,8 @@ SYMBOLS = {
     "pbsgpu_payload_size": (C.c_int, [_P, C.c_uint32, C.POINTER(PayloadFormat), _U64P]),
     "pbsgpu_payload_pack_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, C.POINTER(PayloadFormat), _P, C.c_uint64,
                                              _U64P, _P]),
+    "pbsgpu_reuse_lookup": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64, _U64P, _U64P, _U64P]),
+    "pbsgpu_reuse_should": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_double, C.POINTER(C.c_int)]),
     "pbsgpu_fill_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "pbsgpu_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "pbsgpu_device_free": (C.c_int, [_P, _P]),
