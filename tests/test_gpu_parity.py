@@ -418,3 +418,62 @@ def test_xxh3_many_matches_xxhash_library(engines):
     got2 = eng.xxh3_many(buf, segs)
     buf.free()
     assert np.array_equal(got, got2)
+
+
+def test_alternate_kernels_stay_bit_exact(gpu_lib):
+    """The A/B kernels (single-wave SHA-256, LDS-tiled scan) are selected by environment variables read
+    once per process: run a small parity check in a subprocess with both switched."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "from pbs_plus_amd import Engine, buzhash\n"
+        "from tests.helpers import records_equal\n"
+        "for avg, n, kind in ((4096, 3_000_001, 3), (4 << 20, 80 << 20, 0)):\n"
+        "    eng = Engine(buzhash.NewConfig(avg))\n"
+        "    data = O.fill(n, 5, kind)\n"
+        "    assert records_equal(eng.chunk_and_digest(data), O.chunk_and_digest(O.new_config(avg), data)), avg\n"
+        "    eng.close()\n"
+        "print('alt-ok')\n" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    env = dict(__import__("os").environ, PBSGPU_SHA_MODE="lane", PBSGPU_SCAN_MODE="lds")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "alt-ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_engine_is_safe_from_many_threads(engines, O):
+    """cgo calls arrive on arbitrary OS threads: 4 threads hammer one engine (each its own data);
+    E_BUSY is a legal answer when both slots are taken, wrong results are not."""
+    import threading
+
+    from pbs_plus_amd import PbsGpuError, _lib
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    datas = [O.fill(700_000 + 1111 * i, 400 + i, i % 4) for i in range(4)]
+    wants = [O.chunk_and_digest(cfg, d) for d in datas]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(6):
+                while True:
+                    try:
+                        got = eng.chunk_and_digest(datas[i])
+                        break
+                    except PbsGpuError as exc:
+                        if exc.status != _lib.E_BUSY:
+                            raise
+                if not records_equal(got, wants[i]):
+                    errors.append((i, "mismatch"))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
