@@ -167,17 +167,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
 //    (byte << 8) | (lane << 2) is ONE v_perm_b32, and every lane owns its bank;
 //  * per byte: v_perm, ds_read_b32, v_alignbit, v_xor (prefix), v_xor (window hash), 1/2 v_max3.
 // Lane strips are 4352 B apart (34 lines: even for the ping-pong, not a power of two).
-template <int LINES>
-__global__ __launch_bounds__(512, 2) void k_scan2(ScanParams p) {
+#ifndef PBS_SCAN_THREADS
+#define PBS_SCAN_THREADS 512
+#endif
+#ifndef PBS_SCAN_WPS
+#define PBS_SCAN_WPS 2
+#endif
+template <int LINES, int NBUF>
+__global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    static_assert(LINES % 2 == 0, "ping-pong needs an even number of lines");
+    static_assert(NBUF == 2 || NBUF == 3, "2 or 3 rotating line buffers");
+    static_assert(LINES % NBUF == 0, "strip must be a whole number of buffer rotations");
     constexpr uint32_t SL = LINES * 128;          // strip bytes per lane
     constexpr uint64_t TILE = 64ull * SL;         // bytes per wave tile
     // static => the compiler knows the table's LDS address and folds it into the ds_read
     __shared__ __attribute__((aligned(1024))) uint32_t tab[256 * 64];  // [entry][lane]
     uint32_t *counters = reinterpret_cast<uint32_t *>(smem);           // dynamic part: counters (+ residency pad)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 256 * 64; i += 512) tab[i] = p.table_rot[i >> 6];
+    for (int i = tid; i < 256 * 64; i += PBS_SCAN_THREADS) tab[i] = p.table_rot[i >> 6];
     __syncthreads();
 
     uint32_t *wcnt = counters + wave;
@@ -260,14 +267,29 @@ __global__ __launch_bounds__(512, 2) void k_scan2(ScanParams p) {
         };
 
         if (sbase < A) {
-            uint4 L0[8], L1[8];
-            load_line(L0, 0);
+            if constexpr (NBUF == 2) {
+                uint4 L0[8], L1[8];
+                load_line(L0, 0);
 #pragma unroll 1
-            for (uint32_t line = 0; line < (uint32_t)LINES; line += 2) {
-                load_line(L1, line + 1);
-                process_line(L0, line);
-                if (line + 2 < (uint32_t)LINES) load_line(L0, line + 2);
-                process_line(L1, line + 1);
+                for (uint32_t line = 0; line < (uint32_t)LINES; line += 2) {
+                    load_line(L1, line + 1);
+                    process_line(L0, line);
+                    if (line + 2 < (uint32_t)LINES) load_line(L0, line + 2);
+                    process_line(L1, line + 1);
+                }
+            } else {  // two lines in flight ahead of the one being hashed
+                uint4 L0[8], L1[8], L2[8];
+                load_line(L0, 0);
+                load_line(L1, 1);
+#pragma unroll 1
+                for (uint32_t line = 0; line < (uint32_t)LINES; line += 3) {
+                    load_line(L2, line + 2);
+                    process_line(L0, line);
+                    if (line + 3 < (uint32_t)LINES) load_line(L0, line + 3);
+                    process_line(L1, line + 1);
+                    if (line + 4 < (uint32_t)LINES) load_line(L1, line + 4);
+                    process_line(L2, line + 2);
+                }
             }
         }
         wave_sync();
@@ -277,31 +299,51 @@ __global__ __launch_bounds__(512, 2) void k_scan2(ScanParams p) {
 #undef PBS_LOOKUP
 }
 
-template <int LINES>
+template <int LINES, int NBUF>
 static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st) {
-    constexpr size_t lds = 64 + (16u << 10);  // counters + pad (64 KiB table is static): keeps SHA workgroups off this CU
+    // counters + pad (64 KiB table is static): keeps SHA workgroups off this CU; 15 KiB lets two 384-thread
+    // workgroups share a CU
+    constexpr size_t lds = 64 + ((PBS_SCAN_THREADS == 512) ? (16u << 10) : (15u << 10));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan2<LINES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan2<LINES, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    uint64_t blocks = (p.ntiles + 7) / 8;
-    if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;
-    hipLaunchKernelGGL((k_scan2<LINES>), dim3((unsigned)blocks), dim3(512), lds, st, p);
+    constexpr unsigned wpb = PBS_SCAN_THREADS / 64;
+    uint64_t blocks = (p.ntiles + wpb - 1) / wpb;
+    const uint64_t maxb = (uint64_t)num_cus * ((PBS_SCAN_THREADS == 512) ? 1 : 2);
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL((k_scan2<LINES, NBUF>), dim3((unsigned)blocks), dim3(PBS_SCAN_THREADS), lds, st, p);
     return hipGetLastError();
+}
+
+// PBSGPU_SCAN_VARIANT (experiments): 0 = 34 lines/2 buffers, 1 = 36/3, 2 = 66/2, 3 = 72/3
+static int scan_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PBSGPU_SCAN_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 3) v = 0;
+    }
+    return v;
 }
 
 uint32_t scan_tile_bytes(uint64_t nbytes) {
     if (scan_mode() == 0) return kScanTile;
-    return (nbytes >= (48ull << 20)) ? 64u * 34u * 128u : 64u * 4u * 128u;
+    if (nbytes < (48ull << 20)) return 64u * 4u * 128u;
+    constexpr uint32_t lines[4] = {34, 36, 66, 72};
+    return 64u * lines[scan_variant()] * 128u;
 }
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
     if (p.ntiles == 0) return hipSuccess;
-    if (p.tile_bytes == 64u * 34u * 128u) return launch_scan2<34>(p, num_cus, st);
-    if (p.tile_bytes == 64u * 4u * 128u) return launch_scan2<4>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 34u * 128u) return launch_scan2<34, 2>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 36u * 128u) return launch_scan2<36, 3>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 66u * 128u) return launch_scan2<66, 2>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 72u * 128u) return launch_scan2<72, 3>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 4u * 128u) return launch_scan2<4, 2>(p, num_cus, st);
     constexpr int S = kScanStrip, W = kScanWaves;
     constexpr size_t lds = 256 * 32 * 4 + (size_t)W * (kWindow + 64 * S) + W * 4 + 32;
     static bool attr_set = false;
