@@ -24,6 +24,7 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"io"
 	"runtime"
 	"unsafe"
 )
@@ -117,6 +118,30 @@ func (s *Stream) Write(p []byte) (int, error) {
 		return 0, err
 	}
 	return len(p), nil
+}
+
+// ReadFrom implements io.ReaderFrom without the extra copy of Write: the reader fills the
+// library's pinned staging memory directly (zero-copy feed of WriteEntryReader's io.Reader).
+func (s *Stream) ReadFrom(r io.Reader) (int64, error) {
+	var total int64
+	for {
+		var buf unsafe.Pointer
+		var capacity C.size_t
+		if err := check(C.pbsgpu_stream_reserve(s.h, &buf, &capacity), "stream_reserve"); err != nil {
+			return total, err
+		}
+		n, rerr := io.ReadFull(r, unsafe.Slice((*byte)(buf), int(capacity)))
+		if err := check(C.pbsgpu_stream_commit(s.h, C.size_t(n)), "stream_commit"); err != nil {
+			return total, err
+		}
+		total += int64(n)
+		if rerr == io.EOF || rerr == io.ErrUnexpectedEOF {
+			return total, nil
+		}
+		if rerr != nil {
+			return total, rerr
+		}
+	}
 }
 
 func (s *Stream) Inject(injectedBytes uint64) error {

@@ -171,6 +171,11 @@ typedef struct pbsgpu_stream pbsgpu_stream;
 int pbsgpu_stream_create(pbsgpu_engine *eng, uint64_t window_bytes, pbsgpu_stream **out);
 void pbsgpu_stream_destroy(pbsgpu_stream *s);
 int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len);
+/* Zero-copy feed: borrow library-owned pinned memory, fill it (e.g. io.ReadFull straight from the
+ * source file, the reader side of WriteEntryReader), then commit the first `len` bytes. Saves the
+ * caller-buffer -> staging copy of pbsgpu_stream_write. One reservation at a time. */
+int pbsgpu_stream_reserve(pbsgpu_stream *s, void **buf, size_t *cap);
+int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len);
 /* Force a cut at the current position (InjectChunks flushes the open chunk:
  * commit_reuse.go:315-341) and skip `inject_bytes` of injected, already
  * known chunk payload in the stream offsets. */

@@ -113,6 +113,8 @@ SYMBOLS = {
     "pbsgpu_stream_create": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "pbsgpu_stream_destroy": (None, [_P]),
     "pbsgpu_stream_write": (C.c_int, [_P, _P, C.c_size_t]),
+    "pbsgpu_stream_reserve": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "pbsgpu_stream_commit": (C.c_int, [_P, C.c_size_t]),
     "pbsgpu_stream_cut": (C.c_int, [_P, C.c_uint64]),
     "pbsgpu_stream_finish": (C.c_int, [_P]),
     "pbsgpu_stream_poll": (C.c_int, [_P, _P, C.c_uint64, _U64P]),

@@ -48,6 +48,7 @@ struct pbsgpu_stream {
     PinnedBuf stage[2];
     hipEvent_t stage_ev[2] = {};
     int stage_idx = 0;
+    int reserved = -1;             // staging buffer handed out by pbsgpu_stream_reserve
     uint64_t base = 0;             // absolute stream offset of dev[cur][0]
     uint64_t written = 0;
     uint64_t inject_total = 0;
@@ -265,7 +266,7 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
 
 int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
     if (!s || (!data && len)) return PBSGPU_E_INVALID;
-    if (s->finished) return PBSGPU_E_STATE;
+    if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
     const uint8_t *p = static_cast<const uint8_t *>(data);
     while (len) {
         size_t n = (size_t)std::min<uint64_t>(len, s->window - s->fill);
@@ -287,6 +288,40 @@ int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
         len -= n;
         if (s->fill == s->window) CHK(stream_flush(s, false));
     }
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_reserve(pbsgpu_stream *s, void **buf, size_t *cap) {
+    if (!s || !buf || !cap) return PBSGPU_E_INVALID;
+    if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
+    std::lock_guard<std::mutex> lk(s->eng->mu);
+    CHK(set_device(s->eng));
+    const int k = s->stage_idx;
+    HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
+    s->reserved = k;
+    *buf = s->stage[k].p;
+    *cap = (size_t)std::min<uint64_t>(kStreamStage, s->window - s->fill);
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->reserved < 0) return PBSGPU_E_STATE;
+    const int k = s->reserved;
+    if (len > (size_t)std::min<uint64_t>(kStreamStage, s->window - s->fill)) return PBSGPU_E_INVALID;
+    s->reserved = -1;
+    if (len == 0) return PBSGPU_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->eng->mu);
+        CHK(set_device(s->eng));
+        HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->carry + s->fill, s->stage[k].p, len,
+                              hipMemcpyHostToDevice, s->copy_stream));
+        HIPCHK(hipEventRecord(s->stage_ev[k], s->copy_stream));
+        s->stage_idx ^= 1;
+    }
+    s->fill += len;
+    s->written += len;
+    if (s->fill == s->window) CHK(stream_flush(s, false));
     return PBSGPU_OK;
 }
 

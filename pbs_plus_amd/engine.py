@@ -250,6 +250,15 @@ class PayloadStream:
         a = _host_view(data)
         check(self._L.pbsgpu_stream_write(self._h, a.ctypes.data if a.size else None, a.size), "stream_write")
 
+    def reserve(self) -> np.ndarray:
+        """Borrow pinned staging memory as a writable uint8 array; fill a prefix, then commit(n)."""
+        buf, cap = C.c_void_p(), C.c_size_t()
+        check(self._L.pbsgpu_stream_reserve(self._h, C.byref(buf), C.byref(cap)), "stream_reserve")
+        return np.ctypeslib.as_array((C.c_uint8 * cap.value).from_address(buf.value))
+
+    def commit(self, n: int) -> None:
+        check(self._L.pbsgpu_stream_commit(self._h, n), "stream_commit")
+
     def inject(self, nbytes: int = 0) -> None:
         """Forced cut (InjectChunks flushes the open chunk, commit_reuse.go:315-341)."""
         check(self._L.pbsgpu_stream_cut(self._h, nbytes), "stream_cut")

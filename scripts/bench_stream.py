@@ -16,10 +16,20 @@ ps = PayloadStream(eng, window_bytes=int(window_gib * (1 << 30)))
 n = int(total_gib * 4)
 t0 = time.perf_counter()
 nrec = 0
+zero_copy = len(sys.argv) > 4 and sys.argv[4] == "zc"
 for i in range(n):
-    ps.write(piece)
+    if zero_copy:  # fill the library's pinned staging directly (what io.ReadFull would do)
+        off = 0
+        while off < piece.size:
+            buf = ps.reserve()
+            k = min(buf.size, piece.size - off)
+            buf[:k] = piece[off:off + k]
+            ps.commit(k)
+            off += k
+    else:
+        ps.write(piece)
     nrec += ps.poll().size
 ps.finish()
 nrec += ps.poll().size
 dt = time.perf_counter() - t0
-print(f"stream: {total_gib} GiB, window {window_gib} GiB, inflight {inflight}: {total_gib/dt:.2f} GiB/s, {nrec} records, {dt:.2f} s")
+print(f"stream{' zero-copy' if zero_copy else ''}: {total_gib} GiB, window {window_gib} GiB, inflight {inflight}: {total_gib/dt:.2f} GiB/s, {nrec} records, {dt:.2f} s")

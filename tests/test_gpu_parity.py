@@ -477,3 +477,25 @@ def test_engine_is_safe_from_many_threads(engines, O):
     for t in ts:
         t.join(timeout=120)
     assert not errors, errors
+
+
+def test_payload_stream_zero_copy_feed(engines, O):
+    """reserve/commit (the io.ReaderFrom form of the WriteEntryReader seam) == write()."""
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4096)
+    data = O.fill(900_001, 77, 0)
+    ps = PayloadStream(eng, window_bytes=1 << 17)
+    off = 0
+    rng = np.random.default_rng(3)
+    while off < data.size:
+        buf = ps.reserve()
+        k = int(min(buf.size, data.size - off, rng.integers(1, 70_000)))
+        buf[:k] = data[off:off + k]
+        ps.commit(k)
+        off += k
+    ps.finish()
+    got = ps.poll()
+    want = O.chunk_and_digest(O.new_config(4096), data)
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    ps.close()
