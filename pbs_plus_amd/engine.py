@@ -16,11 +16,15 @@ from .buzhash import Config
 
 
 def _segs(segments):
+    """[(offset, length)] or an (n, 2) uint64 array -> (pointer-compatible object, n).
+    pbsgpu_segment is two little-endian u64, i.e. exactly one row of such an array."""
     if segments is None:
         return None, 0
     n = len(segments)
-    arr = (Segment * max(n, 1))(*[Segment(int(o), int(l)) for o, l in segments])
-    return arr, n
+    if n == 0:
+        return None, 0
+    a = np.ascontiguousarray(segments, dtype=np.uint64).reshape(n, 2)
+    return a.ctypes.data_as(C.POINTER(Segment)), n
 
 
 def _host_view(data) -> np.ndarray:

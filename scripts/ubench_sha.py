@@ -14,7 +14,7 @@ buf = eng.alloc(total)
 eng.fill(buf.ptr, total, 1, 0)
 res = []
 for n in counts:
-    segs = [(i * seg, seg) for i in range(n)]
+    segs = np.stack([np.arange(n, dtype=np.uint64) * np.uint64(seg), np.full(n, seg, dtype=np.uint64)], axis=1)
     eng.sha256_many(buf, segs[: min(n, 64)], nbytes=total)  # warm
     t0 = time.perf_counter(); d = eng.sha256_many(buf, segs, nbytes=total); dt = time.perf_counter() - t0
     blocks = seg // 64 + 1

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One SHA-256 launch at a given lane count (for rocprofv3 counter passes)."""
 import os, sys, time
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pbs_plus_amd import Engine, buzhash
 n = int(sys.argv[1]); seg = int(sys.argv[2]) if len(sys.argv) > 2 else 131136

@@ -499,3 +499,46 @@ def test_payload_stream_zero_copy_feed(engines, O):
     want = O.chunk_and_digest(O.new_config(4096), data)
     assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
     ps.close()
+
+
+def test_incremental_rechunk_after_edits_keeps_boundaries_local(engines, O):
+    """BASELINE.json configs[4] shape (re-chunk after ~2 % random edits, boundary-shift stress), scaled:
+    64 MiB corpus, avg 64 KiB; extents of log-uniform length, 1/3 overwrite, 1/3 insert, 1/3 delete.
+    (1) the edited stream is bit-exact vs the oracle; (2) content-defined cuts resynchronise, so the
+    share of chunks whose digest already existed stays high (device digest-set dedup)."""
+    eng = engines(65536)
+    cfg = O.new_config(65536)
+    rng = np.random.default_rng(5)
+    old = O.fill(64 << 20, 500, 0)
+    pieces, pos, edited = [], 0, 0
+    target = int(0.02 * old.size)
+    cuts = np.sort(rng.choice(old.size - (1 << 20), 40, replace=False))
+    for c in cuts:
+        if c < pos:
+            continue
+        if edited >= target:
+            break
+        ln = int(np.exp(rng.uniform(np.log(4096), np.log(256 << 10))))
+        kind = int(rng.integers(0, 3))
+        pieces.append(old[pos:c])
+        if kind == 0:    # overwrite
+            pieces.append(rng.integers(0, 256, ln, dtype=np.uint8))
+            pos = c + ln
+        elif kind == 1:  # insert
+            pieces.append(rng.integers(0, 256, ln, dtype=np.uint8))
+            pos = c
+        else:            # delete
+            pos = c + ln
+        edited += ln
+    pieces.append(old[pos:])
+    new = np.concatenate(pieces)
+    assert 0.005 * old.size < edited < 0.06 * old.size
+    r_old = eng.chunk_and_digest(old)
+    r_new = eng.chunk_and_digest(new)
+    want = O.chunk_and_digest(cfg, new)
+    assert records_equal(r_new, want), describe_mismatch(r_new, want)
+    both = np.concatenate([r_old, r_new])
+    dup, stats = eng.dedup(both)
+    reused = int(dup[r_old.size:].sum())
+    assert reused / r_new.size > 0.85, (reused, r_new.size)
+    assert stats["nunique"] < r_old.size + 0.15 * r_new.size
