@@ -56,6 +56,8 @@ constexpr size_t kStageBytes = 32u << 20;
 
 uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes) {
     const uint32_t tile_bytes = pbsk::scan_tile_bytes(nbytes);
+    // a corpus that needed a larger per-tile capacity once tends to need it again: start there
+    if (e->cap_hint_tile == tile_bytes && e->cap_hint) return e->cap_hint;
     // expected candidates per wave tile = 3 * tile / (mask + 1); leave generous headroom
     const double lambda = 3.0 * tile_bytes / ((double)e->cfg.mask + 1.0);
     double want = 4.0 * lambda + 16.0;
@@ -153,7 +155,7 @@ int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
     HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
-                              sc + SC_WGLIMIT, e->num_cus, s.stream));
+                              sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, s.stream));
     HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
                                        s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
@@ -265,6 +267,8 @@ int sync_slot(pbsgpu_engine *e, Slot &s) {
         uint32_t cap = s.cap;
         while (cap < hs[SC_MAXCNT]) cap <<= 1;
         if (cap > pbsk::scan_tile_bytes(s.nbytes)) cap = pbsk::scan_tile_bytes(s.nbytes);
+        e->cap_hint = cap;
+        e->cap_hint_tile = pbsk::scan_tile_bytes(s.nbytes);
         s.retries++;
         int st = enqueue_pipeline(e, s, cap);
         if (st != PBSGPU_OK) return st;

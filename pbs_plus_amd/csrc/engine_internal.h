@@ -129,6 +129,8 @@ struct pbsgpu_engine {
     uint32_t *d_table_rot = nullptr;
     std::vector<pbse::Slot> slots;
     uint64_t next_ticket = 1;
+    uint32_t cap_hint = 0;       // per-tile slot capacity that a density retry settled on
+    uint32_t cap_hint_tile = 0;  // ... for this tile size
     pbse::PinnedBuf stage[2];
     hipEvent_t stage_ev[2] = {};
     std::mutex mu;

@@ -983,7 +983,14 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
 // chunks, which leaves CUs free for the next batch's kernels (batches overlap on separate
 // streams). Counting sort by size class (no comparison sort needed for a scheduling order).
 __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const uint32_t *nrec_p, uint32_t shift,
-                                                uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs) {
+                                                uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs,
+                                                const uint32_t *maxcnt, uint32_t cap) {
+    // a scan tile overflowed its slot list: this pass will be re-run with a larger capacity, so do not
+    // spend a SHA pass on its (incomplete) cut list
+    if (maxcnt && *maxcnt > cap) {
+        if (threadIdx.x == 0) *wg_limit = 0;
+        return;
+    }
     constexpr int BINS = 1024;
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t base[BINS];
@@ -1030,10 +1037,11 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
 }
 
 hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
-                        uint32_t *wg_limit, int num_cus, hipStream_t st) {
+                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, hipStream_t st) {
     uint32_t shift = 0;
     while (((uint64_t)max_chunk >> shift) >= 1024) ++shift;
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus,
+                       maxcnt, cap);
     return hipGetLastError();
 }
 
