@@ -461,25 +461,6 @@ int pbsgpu_chunker_scan(pbsgpu_chunker *c, const void *data, size_t len, size_t 
 }
 
 // ---- payload-stream assembly -----------------------------------------------------------------
-int pbsgpu_payload_format_default(pbsgpu_payload_format *out) {
-    if (!out) return PBSGPU_E_INVALID;
-    out->payload_type = 0x28147a1b0b7c1a25ull;  // PXAR_PAYLOAD            (pxar v2 constants, EXTERNAL)
-    out->start_type = 0x834c68c2194a4ed2ull;    // PXAR_PAYLOAD_START_MARKER
-    out->tail_type = 0x6c72b78b984c81b5ull;     // PXAR_PAYLOAD_TAIL_MARKER
-    out->with_start = 1;
-    out->with_tail = 1;
-    return PBSGPU_OK;
-}
-
-int pbsgpu_payload_size(const pbsgpu_segment *files, uint32_t nfiles, const pbsgpu_payload_format *fmt,
-                        uint64_t *nbytes) {
-    if (!nbytes || !fmt || (nfiles && !files)) return PBSGPU_E_INVALID;
-    uint64_t n = (fmt->with_start ? 16 : 0) + (fmt->with_tail ? 16 : 0);
-    for (uint32_t i = 0; i < nfiles; ++i) n += 16 + files[i].length;
-    *nbytes = n;
-    return PBSGPU_OK;
-}
-
 int pbsgpu_payload_pack_device(pbsgpu_engine *e, const void *src, uint64_t src_bytes, const pbsgpu_segment *files,
                                uint32_t nfiles, const pbsgpu_payload_format *fmt, void *dst, uint64_t dst_cap,
                                uint64_t *out_len, uint64_t *payload_offsets) {
@@ -568,13 +549,7 @@ int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, u
 //   header, 4096 bytes: magic[8] | uuid[16] | ctime i64 LE | index_csum[32] | reserved
 //   entries, 40 bytes each: end u64 LE | digest[32]
 //   index_csum = SHA-256 over the concatenated entries.
-static const uint8_t kDidxMagic[8] = {28, 145, 78, 165, 25, 186, 179, 205};
-
-int pbsgpu_didx_size(uint64_t nrecords, uint64_t *nbytes) {
-    if (!nbytes) return PBSGPU_E_INVALID;
-    *nbytes = PBSGPU_DIDX_HEADER_SIZE + nrecords * 40;
-    return PBSGPU_OK;
-}
+extern const uint8_t pbsgpu_didx_magic[8];  // hostonly.cpp
 
 int pbsgpu_didx_encode(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, const uint8_t uuid[16],
                        int64_t ctime, uint8_t *out, uint64_t cap) {
@@ -582,7 +557,7 @@ int pbsgpu_didx_encode(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, 
     const uint64_t need = PBSGPU_DIDX_HEADER_SIZE + n * 40;
     if (cap < need) return PBSGPU_E_CAPACITY;
     std::memset(out, 0, PBSGPU_DIDX_HEADER_SIZE);
-    std::memcpy(out, kDidxMagic, 8);
+    std::memcpy(out, pbsgpu_didx_magic, 8);
     if (uuid) std::memcpy(out + 8, uuid, 16);
     for (int i = 0; i < 8; ++i) out[24 + i] = (uint8_t)((uint64_t)ctime >> (8 * i));
     uint8_t *ent = out + PBSGPU_DIDX_HEADER_SIZE;
@@ -596,36 +571,6 @@ int pbsgpu_didx_encode(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, 
     // index checksum on the device (same SHA-256 kernel as the chunk digests)
     pbsgpu_segment seg{0, n * 40};
     return pbsgpu_sha256_many_host(e, ent, n * 40, &seg, 1, out + 32);
-}
-
-int pbsgpu_didx_decode(const uint8_t *in, uint64_t nbytes, pbsgpu_record *out, uint64_t cap, uint64_t *n,
-                       int64_t *ctime, uint8_t index_csum[32]) {
-    if (!in || !n) return PBSGPU_E_INVALID;
-    if (nbytes < PBSGPU_DIDX_HEADER_SIZE || std::memcmp(in, kDidxMagic, 8) != 0) return PBSGPU_E_INVALID;
-    const uint64_t body = nbytes - PBSGPU_DIDX_HEADER_SIZE;
-    if (body % 40) return PBSGPU_E_INVALID;
-    const uint64_t cnt = body / 40;
-    *n = cnt;
-    if (ctime) {
-        uint64_t v = 0;
-        for (int i = 0; i < 8; ++i) v |= (uint64_t)in[24 + i] << (8 * i);
-        *ctime = (int64_t)v;
-    }
-    if (index_csum) std::memcpy(index_csum, in + 32, 32);
-    if (cnt > cap || (!out && cnt)) return PBSGPU_E_CAPACITY;
-    const uint8_t *ent = in + PBSGPU_DIDX_HEADER_SIZE;
-    uint64_t prev = 0;
-    for (uint64_t i = 0; i < cnt; ++i) {
-        uint64_t end = 0;
-        for (int b = 0; b < 8; ++b) end |= (uint64_t)ent[i * 40 + b] << (8 * b);
-        if (end < prev || end - prev > 0xffffffffull) return PBSGPU_E_INVALID;
-        out[i].end = end;
-        std::memcpy(out[i].digest, ent + i * 40 + 8, 32);
-        out[i].segment = 0;
-        out[i].size = (uint32_t)(end - prev);
-        prev = end;
-    }
-    return PBSGPU_OK;
 }
 
 }  // extern "C"
