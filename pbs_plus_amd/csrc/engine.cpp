@@ -6,6 +6,9 @@
 // path launches the HIP kernels; without a device the engine cannot be created.
 #include "engine_internal.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace pbse {
 std::atomic<int> g_last_hip_error{0};
 }
@@ -448,6 +451,18 @@ int pbsgpu_collect(pbsgpu_engine *e, uint64_t ticket, pbsgpu_record *out, uint64
     }
     if (nrecords) *nrecords = s->nrec;
     if (s->nrec > cap || (!out && s->nrec)) return PBSGPU_E_CAPACITY;
+    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;  // ingest log line, like tapeio's MB/s progress
+    if (trace) {
+        float scan = 0, res = 0, sha = 0;
+        (void)hipEventElapsedTime(&scan, s->ev[EV_SCAN0], s->ev[EV_SCAN1]);
+        (void)hipEventElapsedTime(&res, s->ev[EV_SCAN1], s->ev[EV_RESOLVE1]);
+        (void)hipEventElapsedTime(&sha, s->ev[EV_RESOLVE1], s->ev[EV_SHA1]);
+        (void)hipGetLastError();
+        fprintf(stderr, "[pbsgpu] ticket %llu: %.2f MiB, %llu candidates, %llu chunks, scan %.3f ms, resolve %.3f ms, "
+                        "sha256 %.3f ms, retries %u\n",
+                (unsigned long long)s->ticket, s->nbytes / 1048576.0, (unsigned long long)s->ncand,
+                (unsigned long long)s->nrec, scan, res, sha, s->retries);
+    }
     if (s->nrec) {
         HIPCHK(hipMemcpyAsync(out, s->recs.p, (size_t)s->nrec * sizeof(pbsgpu_record), hipMemcpyDeviceToHost,
                               s->stream));

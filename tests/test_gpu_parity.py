@@ -542,3 +542,24 @@ def test_incremental_rechunk_after_edits_keeps_boundaries_local(engines, O):
     reused = int(dup[r_old.size:].sum())
     assert reused / r_new.size > 0.85, (reused, r_new.size)
     assert stats["nunique"] < r_old.size + 0.15 * r_new.size
+
+
+def test_dedup_digest_prefix_collisions_are_not_duplicates(engines):
+    """The device dedup sorts by the first 8 digest bytes: records that share that prefix but differ
+    later are NOT duplicates (domain 'collision' case), true duplicates inside the same run are."""
+    from pbs_plus_amd import RECORD_DTYPE
+
+    eng = engines(4096)
+    rng = np.random.default_rng(6)
+    recs = np.zeros(40, dtype=RECORD_DTYPE)
+    recs["size"] = rng.integers(1, 1 << 20, 40)
+    recs["digest"] = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    recs["digest"][:24, :8] = recs["digest"][0, :8]          # 24 records share one 8-byte prefix ...
+    recs["digest"][10] = recs["digest"][3]                    # ... of which two pairs are real duplicates
+    recs["digest"][20] = recs["digest"][7]
+    recs["digest"][35] = recs["digest"][30]                   # and one duplicate pair with a unique prefix
+    dup, stats = eng.dedup(recs)
+    want = np.zeros(40, dtype=np.uint8)
+    want[[10, 20, 35]] = 1
+    assert dup.tolist() == want.tolist()
+    assert stats["nunique"] == 37 and stats["unique_bytes"] == int(recs["size"][want == 0].sum())
