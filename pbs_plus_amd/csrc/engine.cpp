@@ -105,12 +105,19 @@ int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     CHK(enqueue_candidates(e, s, s.dptr, s.nbytes, cap, s.nseg));
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
-    HIPCHK(pbsk::launch_resolve_count(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin, e->cfg.max,
-                                      s.seg_cnt.as<uint32_t>(), s.stream));
-    HIPCHK(pbsk::launch_exclusive_scan(s.seg_cnt.as<uint32_t>(), s.nseg, 0xffffffffu, s.seg_off.as<uint32_t>(),
-                                       sc + SC_NREC, nullptr, s.scan_tmp.as<uint32_t>(), s.stream));
-    HIPCHK(pbsk::launch_resolve_write(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin, e->cfg.max,
-                                      s.seg_off.as<uint32_t>(), s.recs.as<pbsgpu_record>(), s.rec_cap, s.stream));
+    if (s.nseg == 1) {  // one stream: records start at 0, a single walk writes them and their count
+        HIPCHK(pbsk::launch_resolve_single(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, e->effmin, e->cfg.max,
+                                           sc + SC_ZERO, sc + SC_NREC, s.recs.as<pbsgpu_record>(), s.rec_cap,
+                                           s.stream));
+    } else {
+        HIPCHK(pbsk::launch_resolve_count(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin,
+                                          e->cfg.max, s.seg_cnt.as<uint32_t>(), s.stream));
+        HIPCHK(pbsk::launch_exclusive_scan(s.seg_cnt.as<uint32_t>(), s.nseg, 0xffffffffu, s.seg_off.as<uint32_t>(),
+                                           sc + SC_NREC, nullptr, s.scan_tmp.as<uint32_t>(), s.stream));
+        HIPCHK(pbsk::launch_resolve_write(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin,
+                                          e->cfg.max, s.seg_off.as<uint32_t>(), s.recs.as<pbsgpu_record>(),
+                                          s.rec_cap, s.stream));
+    }
     HIPCHK(hipEventRecord(s.ev[EV_RESOLVE1], s.stream));
     return PBSGPU_OK;
 }

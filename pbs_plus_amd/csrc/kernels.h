@@ -54,6 +54,10 @@ hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, co
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
                                 pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st);
 
+hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                 uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
+                                 pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st);
+
 // SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
 // `queue` is a device uint32 that must be zero at launch.
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
         ++k;
         s = e;
     }
-    if (!WRITE && lane == 0) seg_cnt[seg] = k;
+    if (lane == 0 && seg_cnt) seg_cnt[seg] = k;  // count pass; also the single-segment write pass (count -> *nrec)
 }
 
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
@@ -568,6 +568,15 @@ hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, co
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
                        maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap);
+    return hipGetLastError();
+}
+
+// one segment: its records start at index 0, so a single walk writes them and the count (-> *nrec)
+hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                 uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
+                                 pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st) {
+    hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec,
+                       zero_off, recs, rec_cap);
     return hipGetLastError();
 }
 
