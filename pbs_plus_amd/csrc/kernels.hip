@@ -949,38 +949,61 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
             }
         }
     } else {
+        // CONSUMER: software-pipelined over blocks. After barrier k+1 (producer has published block k+1) it
+        // first issues the LDS reads of block k+1 into the OTHER register set and only then runs the 64 rounds
+        // of block k from registers, so LDS latency and barrier skew hide behind ~3700 cycles of rounds. The
+        // early copy to registers is also what keeps two LDS buffers sufficient.
         uint32_t H[8];
         sha256_iv(H);
-        for (uint32_t it = 0;; ++it) {
-            const int pb = it & 1;
-            __syncthreads();
-            if (!(alive[0][pb] | alive[1][pb])) break;
-            const uint32_t c = ctrl[pb][lane];
-            uint8_t *d = dstp[pb][lane];
+        struct Blk {
+            uint32_t al, c;
+            uint8_t *d;
             uint4 wk[16];
+        };
+        auto fetch = [&](Blk &x, const int pb) {
+            x.al = alive[0][pb] | alive[1][pb];
+            x.c = ctrl[pb][lane];
+            x.d = dstp[pb][lane];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) wk[q] = wkbuf[pb][q][lane];
-            if (c & 1u) {
+            for (int q = 0; q < 16; ++q) x.wk[q] = wkbuf[pb][q][lane];
+        };
+        auto rounds = [&](const Blk &x) {
+            if (x.c & 1u) {
                 uint32_t a = H[0], b = H[1], cc = H[2], dd = H[3], e = H[4], f = H[5], g = H[6], h = H[7];
 #pragma unroll
                 for (int q = 0; q < 16; q += 2) {
-                    SHA256_ROUND(a, b, cc, dd, e, f, g, h, wk[q].x);
-                    SHA256_ROUND(h, a, b, cc, dd, e, f, g, wk[q].y);
-                    SHA256_ROUND(g, h, a, b, cc, dd, e, f, wk[q].z);
-                    SHA256_ROUND(f, g, h, a, b, cc, dd, e, wk[q].w);
-                    SHA256_ROUND(e, f, g, h, a, b, cc, dd, wk[q + 1].x);
-                    SHA256_ROUND(dd, e, f, g, h, a, b, cc, wk[q + 1].y);
-                    SHA256_ROUND(cc, dd, e, f, g, h, a, b, wk[q + 1].z);
-                    SHA256_ROUND(b, cc, dd, e, f, g, h, a, wk[q + 1].w);
+                    SHA256_ROUND(a, b, cc, dd, e, f, g, h, x.wk[q].x);
+                    SHA256_ROUND(h, a, b, cc, dd, e, f, g, x.wk[q].y);
+                    SHA256_ROUND(g, h, a, b, cc, dd, e, f, x.wk[q].z);
+                    SHA256_ROUND(f, g, h, a, b, cc, dd, e, x.wk[q].w);
+                    SHA256_ROUND(e, f, g, h, a, b, cc, dd, x.wk[q + 1].x);
+                    SHA256_ROUND(dd, e, f, g, h, a, b, cc, x.wk[q + 1].y);
+                    SHA256_ROUND(cc, dd, e, f, g, h, a, b, x.wk[q + 1].z);
+                    SHA256_ROUND(b, cc, dd, e, f, g, h, a, x.wk[q + 1].w);
                 }
                 H[0] += a; H[1] += b; H[2] += cc; H[3] += dd; H[4] += e; H[5] += f; H[6] += g; H[7] += h;
-                if (c & 2u) {
-                    uint32_t *o = reinterpret_cast<uint32_t *>(d);
+                if (x.c & 2u) {
+                    uint32_t *o = reinterpret_cast<uint32_t *>(x.d);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(H[j]);
                     sha256_iv(H);
                 }
             }
+        };
+        Blk A, B;
+        __syncthreads();  // barrier 0: block 0 is published
+        fetch(A, 0);
+        for (;;) {
+            if (!A.al) break;          // block k is the drained marker: the producers have left after its barrier
+            __syncthreads();           // barrier k+1
+            fetch(B, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rounds(A);
+            if (!B.al) break;
+            __syncthreads();           // barrier k+2
+            fetch(A, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rounds(B);
         }
     }
 }
