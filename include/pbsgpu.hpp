@@ -1,0 +1,289 @@
+// include/pbsgpu.hpp — header-only C++17 host mirror of the reference's Go interface for the pxar
+// stream path, over the C ABI in pbsgpu.h (the reference is compiled Go; no Go toolchain exists in
+// the build image, so the host side above the C ABI is C++ — names, argument meaning and error
+// behaviour follow the module API as pbs-plus uses it):
+//
+//   buzhash::NewConfig(avg)                      internal/pxarmount/commit_orchestrate.go:143-149,
+//                                                internal/tapeio/converter.go:248
+//   datastore::NewDynamicIndexWriter(ctime).Add(end, digest).Finish()
+//                                                internal/pxarmount/commit_bottleneck_test.go:773-793
+//   datastore::ParseDynamicIndex / DynamicIndexReader{Count, ChunkInfo, ChunkFromOffset}
+//                                                internal/pxarmount/commit_reuse.go:84-135, commit_orchestrate.go:219
+//   transfer::PayloadWriter{WriteEntryReader, InjectChunks, Finish}  (the payload half of transfer.ArchiveWriter)
+//                                                internal/pxarmount/commit_test.go:33-67, commit_reuse.go:315-341,457
+//
+// Go's (value, error) returns become a Result<T>{value, err}: err.empty() means success.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <istream>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pbsgpu.h"
+
+namespace pbsgpu {
+
+template <typename T> struct Result {
+    T value{};
+    std::string err;  // empty = nil error
+    explicit operator bool() const { return err.empty(); }
+};
+
+inline std::string errorf(const char *what, int status) {
+    return std::string("pbsgpu: ") + what + ": " + pbsgpu_strerror(status);
+}
+
+namespace buzhash {
+
+// buzhash.Config: a plain value handed to NewPBSStore / NewLocalStore / BackupConfig.ChunkConfig
+struct Config {
+    int AvgSize = 0, MinSize = 0, MaxSize = 0, WindowSize = 0;
+    uint32_t BreakTestMask = 0, BreakTestMinimum = 0;
+    pbsgpu_config c{};
+};
+
+// buzhash.NewConfig(avgSize int) (Config, error)
+inline Result<Config> NewConfig(int avgSize) {
+    Result<Config> r;
+    const int st = pbsgpu_config_init(avgSize < 0 ? 0 : (uint64_t)avgSize, nullptr, &r.value.c);
+    if (st != PBSGPU_OK) {
+        r.err = "buzhash: average chunk size must be a power of two in [256, 2^28]";
+        return r;
+    }
+    const pbsgpu_config &c = r.value.c;
+    r.value.AvgSize = (int)c.avg;
+    r.value.MinSize = (int)c.min;
+    r.value.MaxSize = (int)c.max;
+    r.value.WindowSize = (int)c.window;
+    r.value.BreakTestMask = c.mask;
+    r.value.BreakTestMinimum = c.break_min;
+    return r;
+}
+
+}  // namespace buzhash
+
+namespace datastore {
+
+using Digest = std::array<uint8_t, 32>;
+
+// datastore.ChunkInfo{End, Digest}
+struct ChunkInfo {
+    uint64_t End = 0;
+    Digest Digest_{};
+};
+
+// backupproxy.KnownChunkRef{Digest, Size}
+struct KnownChunkRef {
+    Digest Digest_{};
+    uint64_t Size = 0;
+};
+
+// datastore.DynamicIndexReader
+class DynamicIndexReader {
+  public:
+    int Count() const { return (int)recs_.size(); }
+    // (info, ok)
+    std::pair<ChunkInfo, bool> ChunkInfoAt(int i) const {
+        ChunkInfo ci;
+        if (i < 0 || i >= Count()) return {ci, false};
+        ci.End = recs_[(size_t)i].end;
+        std::memcpy(ci.Digest_.data(), recs_[(size_t)i].digest, 32);
+        return {ci, true};
+    }
+    // index of the chunk containing `offset`; ok = false past the end (commit_reuse.go:89-92)
+    std::pair<int, bool> ChunkFromOffset(uint64_t offset) const {
+        size_t lo = 0, hi = recs_.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (recs_[mid].end <= offset) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= recs_.size()) return {0, false};
+        return {(int)lo, true};
+    }
+    int64_t CTime() const { return ctime_; }
+    const Digest &IndexCsum() const { return csum_; }
+    const std::vector<pbsgpu_record> &Records() const { return recs_; }
+
+  private:
+    friend Result<std::shared_ptr<DynamicIndexReader>> ParseDynamicIndex(const std::vector<uint8_t> &data);
+    std::vector<pbsgpu_record> recs_;
+    int64_t ctime_ = 0;
+    Digest csum_{};
+};
+
+// datastore.ParseDynamicIndex(data) (*DynamicIndexReader, error)
+inline Result<std::shared_ptr<DynamicIndexReader>> ParseDynamicIndex(const std::vector<uint8_t> &data) {
+    Result<std::shared_ptr<DynamicIndexReader>> r;
+    uint64_t n = 0;
+    int st = pbsgpu_didx_decode(data.data(), data.size(), nullptr, 0, &n, nullptr, nullptr);
+    if (st != PBSGPU_OK && st != PBSGPU_E_CAPACITY) {
+        r.err = errorf("parse dynamic index", st);
+        return r;
+    }
+    auto idx = std::make_shared<DynamicIndexReader>();
+    idx->recs_.resize((size_t)n);
+    st = pbsgpu_didx_decode(data.data(), data.size(), idx->recs_.data(), n, &n, &idx->ctime_, idx->csum_.data());
+    if (st != PBSGPU_OK) {
+        r.err = errorf("parse dynamic index", st);
+        return r;
+    }
+    r.value = std::move(idx);
+    return r;
+}
+
+// datastore.NewDynamicIndexWriter(ctime).Add(end, digest).Finish() — the index checksum is computed
+// by the engine's SHA-256 kernel, so Finish needs an engine.
+class DynamicIndexWriter {
+  public:
+    explicit DynamicIndexWriter(int64_t ctime) : ctime_(ctime) {}
+    void Add(uint64_t endOffset, const Digest &digest) {
+        pbsgpu_record r{};
+        r.end = endOffset;
+        std::memcpy(r.digest, digest.data(), 32);
+        r.size = (uint32_t)(endOffset - (recs_.empty() ? 0 : recs_.back().end));
+        recs_.push_back(r);
+    }
+    Result<std::vector<uint8_t>> Finish(pbsgpu_engine *eng, const std::array<uint8_t, 16> &uuid = {}) {
+        Result<std::vector<uint8_t>> r;
+        uint64_t nb = 0;
+        pbsgpu_didx_size(recs_.size(), &nb);
+        r.value.resize((size_t)nb);
+        const int st = pbsgpu_didx_encode(eng, recs_.data(), recs_.size(), uuid.data(), ctime_, r.value.data(), nb);
+        if (st != PBSGPU_OK) {
+            r.value.clear();
+            r.err = errorf("finish dynamic index", st);
+        }
+        return r;
+    }
+
+  private:
+    int64_t ctime_;
+    std::vector<pbsgpu_record> recs_;
+};
+
+inline DynamicIndexWriter NewDynamicIndexWriter(int64_t ctime) { return DynamicIndexWriter(ctime); }
+
+}  // namespace datastore
+
+// One engine per (process, GPU): stands where backupproxy's store/session owns chunker + hasher.
+class Engine {
+  public:
+    static Result<std::shared_ptr<Engine>> New(int device, const buzhash::Config &cfg, unsigned inflight = 2) {
+        Result<std::shared_ptr<Engine>> r;
+        pbsgpu_engine *h = nullptr;
+        const int st = pbsgpu_engine_create(device, &cfg.c, inflight, &h);
+        if (st != PBSGPU_OK) {
+            r.err = errorf("engine create", st);
+            return r;
+        }
+        r.value = std::shared_ptr<Engine>(new Engine(h));
+        return r;
+    }
+    ~Engine() { pbsgpu_engine_destroy(h_); }
+    pbsgpu_engine *handle() const { return h_; }
+
+  private:
+    explicit Engine(pbsgpu_engine *h) : h_(h) {}
+    Engine(const Engine &) = delete;
+    pbsgpu_engine *h_;
+};
+
+namespace transfer {
+
+// The payload half of transfer.ArchiveWriter: WriteEntryReader pulls `size` bytes from a reader and
+// appends them to the payload stream; finished chunks arrive at the sink in stream order as
+// (ChunkInfo, size) — exactly what the session appends to the .ppxar.didx.
+class PayloadWriter {
+  public:
+    using Sink = std::function<void(const datastore::ChunkInfo &, uint32_t size)>;
+
+    static Result<std::unique_ptr<PayloadWriter>> New(std::shared_ptr<Engine> eng, Sink sink, uint64_t windowBytes = 0) {
+        Result<std::unique_ptr<PayloadWriter>> r;
+        pbsgpu_stream *s = nullptr;
+        const int st = pbsgpu_stream_create(eng->handle(), windowBytes, &s);
+        if (st != PBSGPU_OK) {
+            r.err = errorf("stream create", st);
+            return r;
+        }
+        r.value.reset(new PayloadWriter(std::move(eng), s, std::move(sink)));
+        return r;
+    }
+    ~PayloadWriter() { pbsgpu_stream_destroy(s_); }
+
+    // WriteEntryReader(entry, r, size) error — reads exactly `size` bytes from r (zero-copy into the
+    // library's pinned staging), error on a short read like the Go writer
+    std::string WriteEntryReader(std::istream &r, uint64_t size) {
+        uint64_t left = size;
+        while (left) {
+            void *buf = nullptr;
+            size_t cap = 0;
+            int st = pbsgpu_stream_reserve(s_, &buf, &cap);
+            if (st != PBSGPU_OK) return errorf("write entry", st);
+            const size_t want = (size_t)std::min<uint64_t>(cap, left);
+            r.read(static_cast<char *>(buf), (std::streamsize)want);
+            const size_t got = (size_t)r.gcount();
+            st = pbsgpu_stream_commit(s_, got);
+            if (st != PBSGPU_OK) return errorf("write entry", st);
+            left -= got;
+            if (got < want) return "write entry: unexpected EOF";
+            if (std::string e = drain(); !e.empty()) return e;
+        }
+        return {};
+    }
+    // WriteEntry(entry, content []byte)
+    std::string WriteEntry(const void *data, size_t len) {
+        const int st = pbsgpu_stream_write(s_, data, len);
+        if (st != PBSGPU_OK) return errorf("write entry", st);
+        return drain();
+    }
+    // InjectChunks(refs): the open chunk is flushed, offsets skip the injected payload (commit_reuse.go:315-341)
+    std::string InjectChunks(const std::vector<datastore::KnownChunkRef> &refs) {
+        uint64_t total = 0;
+        for (const auto &k : refs) total += k.Size;
+        const int st = pbsgpu_stream_cut(s_, total);
+        if (st != PBSGPU_OK) return errorf("inject chunks", st);
+        return drain();
+    }
+    // Encoder().PayloadPosition(): bytes of payload accepted so far (commit_reuse.go:265)
+    uint64_t PayloadPosition() const {
+        uint64_t n = 0;
+        pbsgpu_stream_position(s_, &n);
+        return n;
+    }
+    std::string Finish() {
+        const int st = pbsgpu_stream_finish(s_);
+        if (st != PBSGPU_OK) return errorf("finish", st);
+        return drain();
+    }
+
+  private:
+    PayloadWriter(std::shared_ptr<Engine> e, pbsgpu_stream *s, Sink sink) : eng_(std::move(e)), s_(s), sink_(std::move(sink)) {}
+    std::string drain() {
+        pbsgpu_record buf[256];
+        for (;;) {
+            uint64_t n = 0;
+            const int st = pbsgpu_stream_poll(s_, buf, 256, &n);
+            if (st != PBSGPU_OK) return errorf("poll", st);
+            for (uint64_t i = 0; i < n; ++i) {
+                datastore::ChunkInfo ci;
+                ci.End = buf[i].end;
+                std::memcpy(ci.Digest_.data(), buf[i].digest, 32);
+                sink_(ci, buf[i].size);
+            }
+            if (n < 256) return {};
+        }
+    }
+    std::shared_ptr<Engine> eng_;
+    pbsgpu_stream *s_;
+    Sink sink_;
+};
+
+}  // namespace transfer
+}  // namespace pbsgpu

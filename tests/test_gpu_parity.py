@@ -563,3 +563,23 @@ def test_dedup_digest_prefix_collisions_are_not_duplicates(engines):
     want[[10, 20, 35]] = 1
     assert dup.tolist() == want.tolist()
     assert stats["nunique"] == 37 and stats["unique_bytes"] == int(recs["size"][want == 0].sum())
+
+
+def test_cpp_mirror_writer_matches_oracle(gpu_lib, O, tmp_path):
+    """include/pbsgpu.hpp on the GPU: PayloadWriter.WriteEntry / WriteEntryReader / Finish and the
+    DynamicIndexWriter round trip, driven the way commit_walk_test.go drives the Go module."""
+    import subprocess
+
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    exe = str(tmp_path / "test_cpp_writer")
+    libdir = __import__("os").path.join(root, "pbs_plus_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", __import__("os").path.join(root, "tests", "native", "test_cpp_writer.cpp"),
+                    "-L" + libdir, "-lpbsgpu", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    n = 700_001
+    out = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "cpp-writer-ok" in out.stdout, out.stdout + out.stderr
+    lines = [l.split() for l in out.stdout.splitlines() if l and not l.startswith("cpp-")]
+    want = O.chunk_and_digest(O.new_config(4096), O.fill(n, 77, 0))
+    assert len(lines) == want.size
+    for (end, size, dig), w in zip(lines, want):
+        assert int(end) == int(w["end"]) and int(size) == int(w["size"]) and dig == bytes(w["digest"]).hex()

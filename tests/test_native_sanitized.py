@@ -22,3 +22,14 @@ def test_host_only_code_under_asan_ubsan(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1"))
     assert out.returncode == 0 and "native-host-ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_cpp_mirror_reader_under_asan(tmp_path):
+    """include/pbsgpu.hpp, host-only half (NewConfig error return, ParseDynamicIndex, ChunkFromOffset)."""
+    csrc = os.path.join(ROOT, "pbs_plus_amd", "csrc")
+    exe = str(tmp_path / "test_cpp_reader")
+    flags = ["-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra"]
+    subprocess.run(["g++", *flags, os.path.join(ROOT, "tests", "native", "test_cpp_reader.cpp"),
+                    os.path.join(csrc, "hostonly.cpp"), os.path.join(csrc, "reuse.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "cpp-reader-ok" in out.stdout, out.stdout + out.stderr
