@@ -260,10 +260,19 @@ __global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanPa
                 }
             }
         };
+        // interior tiles (every lane's strip fully inside the buffer) load without per-piece bounds tests:
+        // the predicate is wave-uniform, so it costs one scalar branch per line instead of 8 exec-mask dances
+        const bool interior = __all(sbase + SL <= A);
         auto load_line = [&](uint4 (&X)[8], const uint32_t line) {
             const uint64_t a = sbase + (uint64_t)line * 128u;
+            if (interior) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(p.data_al + a);
 #pragma unroll
-            for (int g = 0; g < 8; ++g) X[g] = load16(a + 16 * g);
+                for (int g = 0; g < 8; ++g) X[g] = q[g];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) X[g] = load16(a + 16 * g);
+            }
         };
 
         if (sbase < A) {
