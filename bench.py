@@ -228,7 +228,30 @@ def cpu_baseline(a, gpu_recs):
     k = recs.size - 1
     same = bool(k > 0 and gpu_recs.size >= k and np.array_equal(recs["end"][:k], gpu_recs["end"][:k])
                 and np.array_equal(recs["digest"][:k], gpu_recs["digest"][:k]))
+    # informational: the same port on many host cores at once (one independent 256 MiB stream per thread;
+    # ctypes releases the GIL). The single-thread figure above stays the baseline: the reference's writer is
+    # one goroutine.
+    many = None
+    try:
+        import threading
+        nthreads = max(1, min(64, (os.cpu_count() or 1)))
+        per = 256 << 20
+        bufs = [O.fill(per, a.seed + 100 + i, 0) for i in range(min(nthreads, 8))]  # 8 distinct buffers, reused
+        def work(i):
+            O.chunk_and_digest(cfg, bufs[i % len(bufs)], [(0, per)], impl=1)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        t1 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dtm = time.perf_counter() - t1
+        many = {"value": round(nthreads * per / GiB / dtm, 2), "unit": "GiB/s", "cores": nthreads,
+                "sample": f"{nthreads} threads x 256 MiB independent streams"}
+    except Exception as exc:  # pragma: no cover
+        many = {"error": repr(exc)}
     return {
+        "many_core": many,
         "value": round(n / GiB / dt, 4), "unit": "GiB/s", "cores": 1,
         "kind": "port",
         "sample": f"first {n / GiB:g} GiB of the same stream, oracle chunk_and_digest (byte-serial Buzhash + SHA-NI), "

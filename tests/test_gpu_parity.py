@@ -583,3 +583,27 @@ def test_cpp_mirror_writer_matches_oracle(gpu_lib, O, tmp_path):
     assert len(lines) == want.size
     for (end, size, dig), w in zip(lines, want):
         assert int(end) == int(w["end"]) and int(size) == int(w["size"]) and dig == bytes(w["digest"]).hex()
+
+
+def test_tiny_entries_never_reach_a_content_cut(engines):
+    """The reference's own store round-trips write files of <= 17 bytes (commit_walk_test.go:21-147):
+    far below min chunk, so no content-defined cut is ever taken — the archive payload is ONE chunk whose
+    digest is the SHA-256 of the concatenation. Same through PayloadStream, entry by entry."""
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4096)
+    ps = PayloadStream(eng, window_bytes=1 << 16)
+    entries = [b"hello world", b"", b"a", b"0123456789abcdef!", b"nested/file", b"\x00" * 17, b"tail"]
+    for e in entries:
+        ps.write(e)
+    ps.finish()
+    recs = ps.poll()
+    blob = b"".join(entries)
+    assert recs.size == 1 and int(recs["end"][0]) == len(blob) == ps.position()
+    assert bytes(recs["digest"][0]) == hashlib.sha256(blob).digest()
+    ps.close()
+    # and an empty archive produces no chunk at all
+    ps = PayloadStream(eng)
+    ps.finish()
+    assert ps.poll().size == 0
+    ps.close()
