@@ -193,9 +193,23 @@ int staged_h2d(pbsgpu_engine *e, void *dst, const void *src, uint64_t nbytes, hi
     return PBSGPU_OK;
 }
 
+// *_device entry points borrow a DEVICE pointer; a host slice handed in by mistake must not reach a kernel
+bool is_device_pointer(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;  // unregistered host memory
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeUnified;
+}
+
 int submit_common(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nbytes, const pbsgpu_segment *segs,
                   uint32_t nseg, uint64_t *ticket) {
     if (!e || !ticket || (!ptr && nbytes)) return PBSGPU_E_INVALID;
+    if (!host && nbytes) {
+        if (set_device(e) != PBSGPU_OK || !is_device_pointer(ptr)) return PBSGPU_E_INVALID;
+    }
     std::lock_guard<std::mutex> lk(e->mu);
     CHK(set_device(e));
     Slot *s = find_free_slot(e);
@@ -370,8 +384,14 @@ int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight
     e->thr = cfg->break_min << (32 - bits);
     e->effmin = std::max<uint32_t>(cfg->min, pbsk::kWindow + 1);
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-        e->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+        // the code objects in this library are gfx950 (MI355X / CDNA4) only: fail here, not at the first launch
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && getenv("PBSGPU_ALLOW_ANY_ARCH") == nullptr) {
+            delete e;
+            return PBSGPU_E_NO_DEVICE;
+        }
+    }
 
     uint32_t rot[256];
     const uint32_t r = (32 - bits) & 31;
@@ -505,6 +525,7 @@ int pbsgpu_candidates_device(pbsgpu_engine *e, const void *dptr, uint64_t nbytes
     if (!e || !n || (!dptr && nbytes)) return PBSGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);
     CHK(set_device(e));
+    if (nbytes && !is_device_pointer(dptr)) return PBSGPU_E_INVALID;
     Slot *s = find_free_slot(e);
     if (!s) return PBSGPU_E_BUSY;
     uint64_t cnt = 0;

@@ -143,6 +143,7 @@ namespace pbse {
 uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes);
 int set_device(const pbsgpu_engine *e);
 Slot *find_free_slot(pbsgpu_engine *e);
+bool is_device_pointer(const void *p);
 int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint32_t cap,
                        uint64_t nseg_hint = 0);
 int staged_h2d(pbsgpu_engine *e, void *dst, const void *src, uint64_t nbytes, hipStream_t st);

@@ -607,3 +607,20 @@ def test_tiny_entries_never_reach_a_content_cut(engines):
     ps.finish()
     assert ps.poll().size == 0
     ps.close()
+
+
+def test_device_entry_points_reject_host_pointers(engines):
+    """A host buffer handed to a *_device entry point (an easy cgo mistake) is refused, not dereferenced."""
+    import ctypes as C
+
+    from pbs_plus_amd import _lib
+
+    eng = engines(4096)
+    host = np.zeros(1 << 16, dtype=np.uint8)
+    t = C.c_uint64()
+    st = eng._L.pbsgpu_submit_device(eng._h, host.ctypes.data, host.size, None, 0, C.byref(t))
+    assert st == _lib.E_INVALID
+    n = C.c_uint64()
+    assert eng._L.pbsgpu_candidates_device(eng._h, host.ctypes.data, host.size, None, 0, C.byref(n)) == _lib.E_INVALID
+    # the engine is still usable afterwards
+    assert eng.chunk_and_digest(host).size == 4  # 64 KiB of zeros, avg 4 KiB -> four max-size (16 KiB) chunks
