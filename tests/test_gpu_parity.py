@@ -624,3 +624,47 @@ def test_device_entry_points_reject_host_pointers(engines):
     assert eng._L.pbsgpu_candidates_device(eng._h, host.ctypes.data, host.size, None, 0, C.byref(n)) == _lib.E_INVALID
     # the engine is still usable afterwards
     assert eng.chunk_and_digest(host).size == 4  # 64 KiB of zeros, avg 4 KiB -> four max-size (16 KiB) chunks
+
+
+def test_cross_file_duplication_fraction(engines, O):
+    """BASELINE.json configs[3] shape, scaled: a corpus of files of which 40 % are exact copies of an
+    earlier file (seeded permutation). Whole-file copies yield identical chunk sequences, so the device
+    digest-set reduce must report exactly the copied files' bytes as duplicates."""
+    eng = engines(65536)
+    rng = np.random.default_rng(4)
+    nfiles, flen = 50, 1 << 20
+    originals = {}
+    src_of = []
+    for i in range(nfiles):
+        if i >= 5 and rng.random() < 0.4:
+            src_of.append(int(rng.integers(0, i)))
+        else:
+            src_of.append(i)
+    # resolve copy-of-copy chains to the original
+    for i in range(nfiles):
+        while src_of[src_of[i]] != src_of[i]:
+            src_of[i] = src_of[src_of[i]]
+    parts = []
+    for i in range(nfiles):
+        s = src_of[i]
+        if s not in originals:
+            originals[s] = O.fill(flen + 4099 * (s % 7), 600 + s, 0)
+        parts.append(originals[s])
+    offs, pos = [], 0
+    for p in parts:
+        offs.append(pos)
+        pos += p.size
+    data = np.concatenate(parts)
+    segs = [(o, p.size) for o, p in zip(offs, parts)]
+    recs = eng.chunk_and_digest(data, segs)
+    dup, stats = eng.dedup(recs)
+    dup_bytes_expected = sum(p.size for i, p in enumerate(parts) if src_of[i] != i)
+    assert stats["total_bytes"] == data.size
+    assert stats["total_bytes"] - stats["unique_bytes"] == dup_bytes_expected
+    assert 0.2 < dup_bytes_expected / data.size < 0.6
+    # duplicates are flagged on the LATER occurrence only
+    first_seen = {}
+    for r, d in zip(recs, dup):
+        key = bytes(r["digest"])
+        assert int(d) == (1 if key in first_seen else 0)
+        first_seen.setdefault(key, int(r["segment"]))
