@@ -149,6 +149,13 @@ int pbsgpu_ticket_timing(pbsgpu_engine *eng, uint64_t ticket, pbsgpu_timing *out
 int pbsgpu_candidates_device(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes,
                              uint64_t *out, uint64_t cap, uint64_t *n);
 
+/* The resolve step alone: cut ONE stream of `stream_len` bytes from an explicit ascending list of
+ * candidate END offsets (as returned by pbsgpu_candidates_device, in stream coordinates). Used when
+ * one stream's candidates were found piecewise — e.g. a stream split over several GPUs, each scanning
+ * its byte range and all-gathering the lists. Records come back without digests. */
+int pbsgpu_resolve_candidates(pbsgpu_engine *eng, const uint64_t *cands, uint64_t ncand, uint64_t stream_len,
+                              pbsgpu_record *out, uint64_t cap, uint64_t *nrecords);
+
 /* ---- upstream-style streaming chunker --------------------------------------
  * `scan` semantics of the chunker behind buzhash.Config (Proxmox
  * ChunkerImpl::scan): consume `len` bytes; *pos = 0 when no boundary was

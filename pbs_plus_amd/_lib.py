@@ -106,6 +106,7 @@ SYMBOLS = {
     "pbsgpu_collect": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P]),
     "pbsgpu_ticket_timing": (C.c_int, [_P, C.c_uint64, C.POINTER(Timing)]),
     "pbsgpu_candidates_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _U64P]),
+    "pbsgpu_resolve_candidates": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_uint64, _U64P]),
     "pbsgpu_chunker_create": (C.c_int, [_P, C.POINTER(_P)]),
     "pbsgpu_chunker_destroy": (None, [_P]),
     "pbsgpu_chunker_scan": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

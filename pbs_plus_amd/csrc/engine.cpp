@@ -536,6 +536,42 @@ int pbsgpu_candidates_device(pbsgpu_engine *e, const void *dptr, uint64_t nbytes
     return PBSGPU_OK;
 }
 
+int pbsgpu_resolve_candidates(pbsgpu_engine *e, const uint64_t *cands, uint64_t ncand, uint64_t stream_len,
+                              pbsgpu_record *out, uint64_t cap, uint64_t *nrecords) {
+    if (!e || !nrecords || (ncand && !cands) || ncand >= (1ull << 32)) return PBSGPU_E_INVALID;
+    for (uint64_t i = 1; i < ncand; ++i)
+        if (cands[i] <= cands[i - 1]) return PBSGPU_E_INVALID;  // strictly ascending
+    std::lock_guard<std::mutex> lk(e->mu);
+    CHK(set_device(e));
+    Slot *s = find_free_slot(e);
+    if (!s) return PBSGPU_E_BUSY;
+    pbsgpu_segment whole{0, stream_len};
+    CHK(s->h_scalars.ensure(SC_COUNT * 4 + 64));
+    CHK(stage_segments(e, *s, &whole, 1, stream_len));
+    CHK(s->recs.ensure((size_t)s->rec_cap * sizeof(pbsgpu_record) + 64));
+    CHK(s->dense.ensure((size_t)ncand * 8 + 64));
+    CHK(s->scalars.ensure(SC_COUNT * 4));
+    HIPCHK(hipMemsetAsync(s->scalars.p, 0, SC_COUNT * 4, s->stream));
+    if (ncand) CHK(staged_h2d(e, s->dense.p, cands, ncand * 8, s->stream));
+    uint32_t *hn = s->h_scalars.as<uint32_t>() + SC_COUNT;
+    *hn = (uint32_t)ncand;
+    uint32_t *sc = s->scalars.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(sc + SC_NCAND, hn, 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(pbsk::launch_resolve_single(s->dense.as<uint64_t>(), sc + SC_NCAND, s->segs.as<pbsgpu_segment>(), e->effmin,
+                                       e->cfg.max, sc + SC_ZERO, sc + SC_NREC, s->recs.as<pbsgpu_record>(), s->rec_cap,
+                                       s->stream));
+    HIPCHK(hipMemcpyAsync(s->h_scalars.p, s->scalars.p, SC_COUNT * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const uint64_t n = s->h_scalars.as<uint32_t>()[SC_NREC];
+    *nrecords = n;
+    if (n > cap || (!out && n)) return PBSGPU_E_CAPACITY;
+    if (n) {
+        HIPCHK(hipMemcpy(out, s->recs.p, (size_t)n * sizeof(pbsgpu_record), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) std::memset(out[i].digest, 0, 32);  // not hashed here
+    }
+    return PBSGPU_OK;
+}
+
 static int sha256_many(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nbytes, const pbsgpu_segment *segs,
                        uint32_t nseg, uint8_t *digests) {
     if (!e || (!ptr && nbytes) || (nseg && (!segs || !digests))) return PBSGPU_E_INVALID;

@@ -65,3 +65,75 @@ def global_dedup(engine, local_records: np.ndarray, device=None, group=None):
     allrecs = allgather_records(local_records, device=device, group=group)
     dup, stats = engine.dedup(allrecs)
     return dup, stats, allrecs
+
+
+# ---- one stream split over several GPUs -----------------------------------------------------------
+def split_plan(total_len: int, world_size: int, max_chunk: int):
+    """Byte range each rank must hold for a stream split evenly over the ranks.
+
+    Rank r OWNS [r*S, min((r+1)*S, T)) and must have the bytes [lo, hi) resident, where lo reaches 63 bytes
+    to the left (window halo for the candidates it reports) and hi reaches max_chunk to the right (so that
+    every chunk STARTING in its range is fully local). Returns [(own_start, own_end, lo, hi)]."""
+    S = -(-total_len // world_size)
+    S = (S + 7) & ~7
+    plan = []
+    for r in range(world_size):
+        a, b = min(r * S, total_len), min((r + 1) * S, total_len)
+        plan.append((a, b, max(0, a - 63), min(total_len, b + max_chunk)))
+    return plan
+
+
+def _allgather_var(arr: np.ndarray, device=None, group=None) -> list:
+    """all_gather of variable-length 1-D uint8-viewable arrays -> list (per rank) of numpy arrays."""
+    import torch
+    import torch.distributed as dist
+
+    ws = dist.get_world_size(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    cnt = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    pad = np.zeros(cap, dtype=np.uint8)
+    pad[: raw.size] = raw
+    mine = torch.from_numpy(pad).to(dev)
+    bufs = [torch.empty_like(mine) for _ in range(ws)]
+    dist.all_gather(bufs, mine, group=group)
+    return [bufs[r].cpu().numpy()[: counts[r]].copy() for r in range(ws)]
+
+
+def split_stream_chunk_and_digest(engine, local, total_len: int, device=None, group=None) -> np.ndarray:
+    """Cut + hash ONE stream of `total_len` bytes that is split over the ranks (second row).
+
+    `local` = this rank's device-resident bytes [lo, hi) as given by split_plan. Data path: every rank scans
+    its own bytes; exchange steps: (1) all-gather of the candidate END offsets (a few per MiB), (2) all-gather
+    of the digests. The cut chain is resolved identically on every rank from the gathered list (the resolve
+    kernel), then each rank hashes the chunks that START in its range. Returns the full record list."""
+    import torch.distributed as dist
+
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
+    cfg = engine.config
+    own_a, own_b, lo, hi = split_plan(total_len, ws, cfg.MaxSize)[rank]
+    ptr, nbytes = engine._dev(local)
+    assert nbytes >= hi - lo, "local buffer shorter than split_plan asks for"
+    if hi > lo:
+        ends = engine.candidates(ptr, hi - lo) + np.uint64(lo)       # stream coordinates
+        ends = ends[(ends > own_a) & (ends <= own_b)]                 # report each candidate exactly once
+    else:
+        ends = np.zeros(0, dtype=np.uint64)
+    parts = _allgather_var(ends, device=device, group=group)
+    allc = np.concatenate([p.view(np.uint64) for p in parts]) if parts else ends
+    recs = engine.resolve_candidates(allc, total_len)
+    starts = recs["end"] - recs["size"].astype(np.uint64)
+    mine = np.flatnonzero((starts >= own_a) & (starts < own_b))
+    digs = np.zeros((0, 32), dtype=np.uint8)
+    if mine.size:
+        segs = np.stack([starts[mine] - np.uint64(lo), recs["size"][mine].astype(np.uint64)], axis=1)
+        digs = engine.sha256_many(ptr, segs, nbytes=hi - lo)
+    gathered = _allgather_var(digs, device=device, group=group)
+    alld = np.concatenate([g.reshape(-1, 32) for g in gathered]) if gathered else digs
+    assert alld.shape[0] == recs.size, (alld.shape, recs.size)
+    recs["digest"] = alld  # ranks own contiguous, ascending runs of chunks -> rank order == stream order
+    return recs

@@ -159,6 +159,19 @@ class Engine:
               "candidates_device")
         return out[: cnt.value]
 
+    def resolve_candidates(self, cands: np.ndarray, stream_len: int) -> np.ndarray:
+        """Cut one stream from an explicit ascending candidate list (records without digests)."""
+        c = np.ascontiguousarray(cands, dtype=np.uint64)
+        n = C.c_uint64()
+        st = self._L.pbsgpu_resolve_candidates(self._h, c.ctypes.data if c.size else None, c.size, stream_len, None, 0,
+                                               C.byref(n))
+        if st not in (_lib.OK, _lib.E_CAPACITY):
+            check(st, "resolve_candidates")
+        out = np.zeros(max(n.value, 1), dtype=RECORD_DTYPE)
+        check(self._L.pbsgpu_resolve_candidates(self._h, c.ctypes.data if c.size else None, c.size, stream_len,
+                                                out.ctypes.data, n.value, C.byref(n)), "resolve_candidates")
+        return out[: n.value]
+
     # ---- whole-stream SHA-256 (verification.HashFile for many files) --------------------------------
     def sha256_many(self, data, segments, nbytes: int | None = None) -> np.ndarray:
         segs, nseg = _segs(segments)

@@ -668,3 +668,64 @@ def test_cross_file_duplication_fraction(engines, O):
         key = bytes(r["digest"])
         assert int(d) == (1 if key in first_seen else 0)
         first_seen.setdefault(key, int(r["segment"]))
+
+
+def _split_worker(rank, ws, port, q):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from pbs_plus_amd import Engine, buzhash
+    from pbs_plus_amd.dist import split_plan, split_stream_chunk_and_digest
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        T = (40 << 20) + 12345
+        cfg = buzhash.NewConfig(65536)
+        eng = Engine(cfg, device=0)  # both ranks share the one GPU of the test box
+        a, b, lo, hi = split_plan(T, ws, cfg.MaxSize)[rank]
+        whole = O.fill(T, 4242, 3)
+        buf = eng.alloc(hi - lo + 8)
+        buf.upload(whole[lo:hi])
+        recs = split_stream_chunk_and_digest(eng, buf, T)
+        q.put((rank, recs.tobytes()))
+        buf.free()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_stream_split_over_two_ranks(gpu_lib, O):
+    """one stream split over ranks (63-byte halo, max-size right overlap, gathered candidate
+    lists, identical resolve everywhere, per-rank hashing) equals the oracle on the whole stream. Two
+    processes over gloo share the single GPU of the test box; on an 8-GPU node the same code runs over RCCL."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from pbs_plus_amd import RECORD_DTYPE
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=150) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = np.frombuffer(got[0][1], dtype=RECORD_DTYPE)
+    r1 = np.frombuffer(got[1][1], dtype=RECORD_DTYPE)
+    assert r0.tobytes() == r1.tobytes()
+    T = (40 << 20) + 12345
+    want = O.chunk_and_digest(O.new_config(65536), O.fill(T, 4242, 3))
+    assert records_equal(r0, want), describe_mismatch(r0, want)

@@ -84,3 +84,16 @@ def test_allgather_records_world_size_2_gloo():
     # duplicate structure the device dedup must find: digests seg%5 -> 5 unique among the 11
     uniq = {bytes(d) for d in all0["digest"]}
     assert len(uniq) == 5 + 1  # + rank 1's filler record
+
+
+def test_split_plan_covers_stream_with_halo_and_overlap():
+    from pbs_plus_amd.dist import split_plan
+
+    T, mx = 1_000_003, 16384
+    for ws in (1, 2, 3, 8):
+        plan = split_plan(T, ws, mx)
+        assert plan[0][0] == 0 and plan[-1][1] == T
+        for (a, b, lo, hi), nxt in zip(plan, plan[1:] + [None]):
+            assert lo == max(0, a - 63) and hi == min(T, b + mx) and a <= b
+            if nxt is not None:
+                assert nxt[0] == b
