@@ -313,12 +313,10 @@ static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st)
     // counters + pad (64 KiB table is static): keeps SHA workgroups off this CU; 15 KiB lets two 384-thread
     // workgroups share a CU
     constexpr size_t lds = 64 + ((PBS_SCAN_THREADS == 512) ? (16u << 10) : (15u << 10));
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per launch, not once per process: the attribute is per device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan2<LINES, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     constexpr unsigned wpb = PBS_SCAN_THREADS / 64;
     uint64_t blocks = (p.ntiles + wpb - 1) / wpb;
@@ -355,12 +353,10 @@ hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
     if (p.tile_bytes == 64u * 4u * 128u) return launch_scan2<4, 2>(p, num_cus, st);
     constexpr int S = kScanStrip, W = kScanWaves;
     constexpr size_t lds = 256 * 32 * 4 + (size_t)W * (kWindow + 64 * S) + W * 4 + 32;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<S, W>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     uint64_t blocks = (p.ntiles + W - 1) / W;
     if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;  // persistent: one workgroup per CU
