@@ -55,3 +55,40 @@ def golden_records(case, dtype):
         out[i]["segment"], out[i]["end"], out[i]["size"] = seg, end, size
         out[i]["digest"] = np.frombuffer(bytes.fromhex(dig), dtype=np.uint8)
     return out
+
+
+def scan_lane_model(data, table, mask, break_min, strip=4352):
+    """numpy statement of kernels.hip k_scan2's per-lane algebra, for one buffer cut into lane strips:
+      * prefix recurrence P(i) = rotl(P(i-1), 1) ^ T'[b[i]] restarted 64 bytes before every strip,
+      * window hash h'(i) = P(i) ^ P(i-64)   (64 = 0 mod 32, so the leaving byte needs no rotation),
+      * table pre-rotated by r = 32 - bits, candidate test h' >= break_min << r (one unsigned compare).
+    Returns ascending candidate END offsets; must equal oracle.candidates()."""
+    data = np.asarray(data, dtype=np.uint8)
+    bits = int(mask + 1).bit_length() - 1
+    assert (1 << bits) == mask + 1
+    r = (32 - bits) & 31
+    T = np.asarray(table, dtype=np.uint64)
+    Trot = (((T << r) | (T >> (32 - r))) & 0xFFFFFFFF) if r else T.copy()
+    thr = (int(break_min) << r) & 0xFFFFFFFF
+    n = data.size
+    out = []
+    for s0 in range(0, n, strip):
+        lo = max(0, s0 - 64)
+        P = 0
+        ring = [0] * 64
+        # warm-up over the 64 bytes before the strip (zeros before the buffer start)
+        warm = [0] * (64 - (s0 - lo)) + data[lo:s0].tolist()
+        for k, b in enumerate(warm):
+            P = (((P << 1) | (P >> 31)) & 0xFFFFFFFF) ^ int(Trot[b])
+            ring[k] = P
+        for i in range(s0, min(n, s0 + strip)):
+            rp = ((P << 1) | (P >> 31)) & 0xFFFFFFFF
+            tv = int(Trot[data[i]])
+            ri = (i - s0) & 63
+            h = rp ^ tv ^ ring[ri]
+            P = rp ^ tv
+            ring[ri] = P
+            e = i + 1
+            if h >= thr and e >= 64:
+                out.append(e)
+    return np.asarray(out, dtype=np.uint64)

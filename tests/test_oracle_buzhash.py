@@ -165,3 +165,17 @@ def test_fill_is_offset_consistent(O):
     z = O.fill(8 << 20, 5, 3)
     frac = 1.0 - np.count_nonzero(z.reshape(-1, 65536).any(axis=1)) / (z.size / 65536)
     assert 0.15 < frac < 0.45
+
+
+@pytest.mark.parametrize("avg,n,kind,strip", [(4096, 70_000, 0, 4352), (256, 9_000, 0, 512), (4096, 50_000, 3, 512),
+                                              (65536, 300_000, 0, 4352)])
+def test_scan_kernel_algebra_model_equals_rolling_hash(O, avg, n, kind, strip):
+    """The three identities the scan kernel rests on (prefix ring, unrotated leaving term, pre-rotated table
+    with one unsigned compare), stated in numpy (tests/helpers.py::scan_lane_model) and checked against the
+    oracle's rolling hash — so kernel edits can be validated against the math without a GPU."""
+    from helpers import scan_lane_model
+
+    cfg = O.new_config(avg)
+    data = O.fill(n, 31 + avg, kind)
+    got = scan_lane_model(data, O.default_table(), cfg.mask, cfg.break_min, strip=strip)
+    assert np.array_equal(got, O.candidates(cfg, data))
