@@ -202,6 +202,7 @@ __global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanPa
         if (lane == 0) g0 = atomicAdd(p.tile_queue, 1ull);
         const uint64_t t = __shfl(g0, 0, 64);
         if (t >= p.ntiles) break;
+        const uint64_t t_idx = t;
         const uint64_t wbase = t * TILE;
         const uint64_t sbase = wbase + (uint64_t)lane * SL;  // a-coordinate of this lane's strip
         if (lane == 0) *wcnt = 0;
@@ -230,33 +231,60 @@ __global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanPa
             }
         }
 
+        // 128 bytes = 16 batches of 8 table lookups, software-pipelined: the lookups of batch j+1 are issued
+        // before batch j is consumed and ONE s_waitcnt lgkmcnt(8) covers a whole batch (the compiler's default is a
+        // counted wait in front of every single use: ~1 extra issue slot per byte)
         auto process_line = [&](const uint4 (&X)[8], const uint32_t line) {
+            uint32_t tv[2][8];
+            auto issue = [&](const int batch, uint32_t (&dst)[8]) {
+                const uint4 &v = X[batch >> 1];
+                const uint32_t w0 = (batch & 1) ? v.z : v.x, w1 = (batch & 1) ? v.w : v.y;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const uint32_t w[4] = {X[g].x, X[g].y, X[g].z, X[g].w};
-                uint32_t h[16];
-                uint32_t acc = 0;
+                for (int k = 0; k < 4; ++k) dst[k] = PBS_LOOKUP(w0, k);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t tv = PBS_LOOKUP(w[k >> 2], k & 3);
-                    const uint32_t rp = __builtin_rotateleft32(P, 1);
-                    const int ri = ((g & 3) * 16 + k);
-                    h[k] = __builtin_amdgcn_bitop3_b32(rp, tv, ring[ri], 0x96);  // P_new ^ P_old(-64)
-                    P = rp ^ tv;
-                    ring[ri] = P;
-                    acc = max(acc, h[k]);
+                for (int k = 0; k < 4; ++k) dst[4 + k] = PBS_LOOKUP(w1, k);
+            };
+            issue(0, tv[0]);
+            uint32_t h[16];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int batch = 0; batch < 16; ++batch) {
+                if (batch < 15) {
+                    issue(batch + 1, tv[(batch + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // keep "issue next, wait once, consume" as written
+                    __builtin_amdgcn_s_waitcnt(0xC87F);  // lgkmcnt(8): everything but the 8 newest lookups has landed
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
                 }
-                if (acc >= thr) {  // rare
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t(&t)[8] = tv[batch & 1];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if (h[k] >= thr) {
-                            const uint64_t ea = sbase + (uint64_t)line * 128u + (uint32_t)(g * 16 + k + 1);
-                            if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
-                                const uint32_t slot = atomicAdd(wcnt, 1u);
-                                if (slot < p.cap) p.tile_slots[t * p.cap + slot] = (uint32_t)(ea - wbase);
+                for (int k = 0; k < 8; ++k) {
+                    const int pos = batch * 8 + k;       // byte within the line
+                    const int hk = pos & 15;
+                    const uint32_t rp = __builtin_rotateleft32(P, 1);
+                    const int ri = pos & 63;
+                    h[hk] = __builtin_amdgcn_bitop3_b32(rp, t[k], ring[ri], 0x96);  // P_new ^ P_old(-64)
+                    P = rp ^ t[k];
+                    ring[ri] = P;
+                    acc = max(acc, h[hk]);
+                }
+                if (batch & 1) {  // end of a 16-byte group
+                    if (acc >= thr) {  // rare
+                        const int g = batch >> 1;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            if (h[k] >= thr) {
+                                const uint64_t ea = sbase + (uint64_t)line * 128u + (uint32_t)(g * 16 + k + 1);
+                                if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
+                                    const uint32_t slot = atomicAdd(wcnt, 1u);
+                                    if (slot < p.cap) p.tile_slots[t_idx * p.cap + slot] = (uint32_t)(ea - wbase);
+                                }
                             }
                         }
                     }
+                    acc = 0;
                 }
             }
         };
