@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
     const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (seg >= nseg) return;
+    __builtin_amdgcn_s_setprio(2);  // a latency-bound serial walk: do not queue behind throughput waves on this SIMD
     const uint64_t n = *ncand_p;
     const uint64_t A = segs[seg].offset, B = A + segs[seg].length;
     uint64_t s = A;
