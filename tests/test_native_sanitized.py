@@ -33,3 +33,14 @@ def test_cpp_mirror_reader_under_asan(tmp_path):
                     os.path.join(csrc, "hostonly.cpp"), os.path.join(csrc, "reuse.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "cpp-reader-ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    """The parity checker itself, memory- and UB-clean on exact-size buffers."""
+    exe = str(tmp_path / "test_oracle_asan")
+    flags = ["-std=c11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra"]
+    srcs = [os.path.join(ROOT, "tests", "native", "test_oracle_asan.c"), os.path.join(ROOT, "oracle", "buzhash_oracle.c"),
+            os.path.join(ROOT, "oracle", "sha256_oracle.c")]
+    subprocess.run(["gcc", *flags, *srcs, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "oracle-asan-ok" in out.stdout, out.stdout + out.stderr
