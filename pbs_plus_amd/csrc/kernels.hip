@@ -173,10 +173,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
 #ifndef PBS_SCAN_WPS
 #define PBS_SCAN_WPS 2
 #endif
+#ifndef PBS_SCAN_NBUF
+#define PBS_SCAN_NBUF 2
+#endif
 template <int LINES, int NBUF>
 __global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    static_assert(NBUF == 2 || NBUF == 3, "2 or 3 rotating line buffers");
+    static_assert(NBUF >= 1 && NBUF <= 3, "1 (no register prefetch), 2 or 3 rotating line buffers");
     static_assert(LINES % NBUF == 0, "strip must be a whole number of buffer rotations");
     constexpr uint32_t SL = LINES * 128;          // strip bytes per lane
     constexpr uint64_t TILE = 64ull * SL;         // bytes per wave tile
@@ -304,7 +307,14 @@ __global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanPa
         };
 
         if (sbase < A) {
-            if constexpr (NBUF == 2) {
+            if constexpr (NBUF == 1) {  // no register prefetch: latency is hidden by the other waves on the SIMD
+                uint4 L0[8];
+#pragma unroll 1
+                for (uint32_t line = 0; line < (uint32_t)LINES; ++line) {
+                    load_line(L0, line);
+                    process_line(L0, line);
+                }
+            } else if constexpr (NBUF == 2) {
                 uint4 L0[8], L1[8];
                 load_line(L0, 0);
 #pragma unroll 1
@@ -340,7 +350,7 @@ template <int LINES, int NBUF>
 static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st) {
     // counters + pad (64 KiB table is static): keeps SHA workgroups off this CU; 15 KiB lets two 384-thread
     // workgroups share a CU
-    constexpr size_t lds = 64 + ((PBS_SCAN_THREADS == 512) ? (16u << 10) : (15u << 10));
+    constexpr size_t lds = 64 + ((PBS_SCAN_THREADS == 384) ? (15u << 10) : (16u << 10));
     {   // per launch, not once per process: the attribute is per device
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan2<LINES, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -348,7 +358,7 @@ static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st)
     }
     constexpr unsigned wpb = PBS_SCAN_THREADS / 64;
     uint64_t blocks = (p.ntiles + wpb - 1) / wpb;
-    const uint64_t maxb = (uint64_t)num_cus * ((PBS_SCAN_THREADS == 512) ? 1 : 2);
+    const uint64_t maxb = (uint64_t)num_cus * ((PBS_SCAN_THREADS == 384) ? 2 : 1);
     if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL((k_scan2<LINES, NBUF>), dim3((unsigned)blocks), dim3(PBS_SCAN_THREADS), lds, st, p);
     return hipGetLastError();
@@ -374,7 +384,8 @@ uint32_t scan_tile_bytes(uint64_t nbytes) {
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
     if (p.ntiles == 0) return hipSuccess;
-    if (p.tile_bytes == 64u * 34u * 128u) return launch_scan2<34, 2>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 34u * 128u)
+        return (PBS_SCAN_NBUF == 1) ? launch_scan2<34, 1>(p, num_cus, st) : launch_scan2<34, 2>(p, num_cus, st);
     if (p.tile_bytes == 64u * 36u * 128u) return launch_scan2<36, 3>(p, num_cus, st);
     if (p.tile_bytes == 64u * 66u * 128u) return launch_scan2<66, 2>(p, num_cus, st);
     if (p.tile_bytes == 64u * 72u * 128u) return launch_scan2<72, 3>(p, num_cus, st);
