@@ -13,6 +13,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -29,7 +30,7 @@ static int scan_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("PBSGPU_SCAN_MODE");
-        mode = (e && e[0] == 'l') ? 0 : 1;
+        mode = (e && e[0] == 'l') ? 0 : (e && e[0] == 'c') ? 2 : 1;  // lds | coop | (default) stream
     }
     return mode;
 }
@@ -364,6 +365,223 @@ static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st)
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------------
+// Candidate scan, cooperative-load form. k_scan2's per-lane streaming is bound by the texture addresser
+// (64 distinct 128-byte lines per load instruction: 4.14 TB/s for pure loads, profiles/
+// r01_ubench_load_pattern_ceiling.log), so here the four lanes of a quad fetch 64 CONTIGUOUS bytes of one
+// strip per instruction (16 lines per instruction; 6.0 TB/s ceiling) and a small per-wave LDS stage
+// transposes each 64-byte half-line back to "one lane = one strip": 4 ds_write_b128 at
+// [strip][piece] with an 80-byte strip pitch, 4 ds_read_b128 of the lane's own row (pitch 5 slots, odd:
+// conflict-free). A half-line is exactly one revolution of the 64-entry prefix ring, so ring indices
+// stay static. D half-lines per wave are kept in flight (D x 4 KiB: memory-level parallelism). Everything
+// else (ring, pre-rotated 64x replicated table, batched lookups, slots) as k_scan2.
+#define PBS_LOOKUP3(w, k) \
+    (*reinterpret_cast<const uint32_t *>(lds0 + __builtin_amdgcn_perm((w), lane4, 0x0c0c0400u | ((uint32_t)(k) << 8))))
+
+// one tile of k_scan3. INTERIOR = the whole tile and its 64-byte warm-up lie inside the buffer (wave-uniform by
+// construction): the check-free instantiation
+template <int LINES, int D, bool INTERIOR>
+__device__ __forceinline__ void scan3_tile(const ScanParams &p, const uint64_t t_idx, const uint64_t A, const int lane,
+                                           const uint8_t *lds0, uint8_t *stage, uint32_t *wcnt) {
+    constexpr uint32_t SL = LINES * 128;
+    constexpr uint64_t TILE = 64ull * SL;
+    constexpr int PITCH = 80;
+    constexpr int HALVES = LINES * 2;
+    const uint64_t wbase = t_idx * TILE;
+    const uint64_t sbase = wbase + (uint64_t)lane * SL;
+    const uint32_t thr = p.thr;
+    const uint32_t lane4 = (uint32_t)lane << 2;
+    const int q4 = lane & ~3, ql = lane & 3;
+
+    // quad-cooperative fetch of half-line `hl` (64-byte units from the strip start; -1 = warm-up window):
+    // instruction j serves strip q4 + j, this lane brings piece ql of it
+    auto gfetch = [&](uint4 (&G)[4], const int hl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t a = (int64_t)wbase + (int64_t)(q4 + j) * SL + (int64_t)hl * 64 + ql * 16;
+            if constexpr (INTERIOR) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(p.data_al + a);
+                G[j] = make_uint4(v.x, v.y, v.z, v.w);
+            } else {  // branch-free (a branch per load would force vmcnt(0) waits): clamp the address, select zero
+                const bool in = a >= 0 && (uint64_t)a < A;
+                const uint4 v = *reinterpret_cast<const uint4 *>(p.data_al + (in ? a : 0));
+                G[j] = make_uint4(in ? v.x : 0u, in ? v.y : 0u, in ? v.z : 0u, in ? v.w : 0u);
+            }
+        }
+    };
+    // LDS transpose: [strip][piece] in, own row out (LDS operations of one wave execute in order)
+    auto transpose = [&](const uint4 (&G)[4], uint4 (&X)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4 *>(stage + (q4 + j) * PITCH + ql * 16) = G[j];
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X[k] = *reinterpret_cast<const uint4 *>(stage + lane * PITCH + k * 16);
+        wave_sync();
+    };
+
+    // Rolling form (window 64 == two 32-bit turns, so the outgoing term needs no rotation):
+    //   h_i = rotl(h_{i-1}, 1) ^ t_i ^ t_{i-64},   t = pre-rotated table value of the byte
+    // The table values of the previous 64 bytes live in a register ring; a half-line is exactly one turn of it,
+    // so two rings alternate roles per half-line (lookups land directly in the "new" ring, no copies) and a
+    // byte costs: 1 v_perm (LDS address) + 1 ds_read + 1 rotate + 1 three-input xor + 1/2 max3.
+    uint32_t ring[2][64];
+    uint32_t hc = 0;
+    uint4 G[D][4], X[4];
+    gfetch(G[0], -1);
+    transpose(G[0], X);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        gfetch(G[d], d);
+        __builtin_amdgcn_sched_barrier(0);  // keep stage order: the loop's vmcnt waits assume oldest stage first
+    }
+    {   // warm-up over the 64 bytes before the strip (plays half-line -1: fills ring[1])
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t w[4] = {X[g].x, X[g].y, X[g].z, X[g].w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t t = PBS_LOOKUP3(w[k >> 2], k & 3);
+                ring[1][g * 16 + k] = t;
+                hc = __builtin_rotateleft32(hc, 1) ^ t;
+            }
+        }
+    }
+    // one half-line: transpose stage d, (REFILL) put the stage's next half-line in flight, hash 64 bytes per lane
+    auto half = [&](const int d, const int hl, auto refill_c) {
+        uint32_t(&rn)[64] = ring[d & 1];        // hl and d have the same parity (D and the loop step are even)
+        const uint32_t(&ro)[64] = ring[(d & 1) ^ 1];
+        transpose(G[d], X);
+        if constexpr (decltype(refill_c)::value) gfetch(G[d], hl + D);
+        auto issue = [&](const int batch) {
+            const uint4 &v = X[batch >> 1];
+            const uint32_t w0 = (batch & 1) ? v.z : v.x, w1 = (batch & 1) ? v.w : v.y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rn[batch * 8 + k] = PBS_LOOKUP3(w0, k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rn[batch * 8 + 4 + k] = PBS_LOOKUP3(w1, k);
+        };
+        issue(0);
+        uint32_t h[16];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int batch = 0; batch < 8; ++batch) {
+            if (batch < 7) {
+                issue(batch + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC87F);  // lgkmcnt(8)
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const int pos = batch * 8 + k;  // byte within the half-line == ring index
+                const uint32_t h0 = __builtin_amdgcn_bitop3_b32(__builtin_rotateleft32(hc, 1), rn[pos], ro[pos], 0x96);
+                const uint32_t h1 = __builtin_amdgcn_bitop3_b32(__builtin_rotateleft32(h0, 1), rn[pos + 1], ro[pos + 1], 0x96);
+                h[pos & 15] = h0;
+                h[(pos + 1) & 15] = h1;
+                hc = h1;
+                asm("v_max3_u32 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(h0), "v"(h1));  // the compiler splits half of these
+            }
+            if (batch & 1) {
+                if (__builtin_expect(acc >= thr, 0)) {  // rare: compact (mask + ctz loop), the hot loop has to stay small
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m |= (h[k] >= thr) ? (1u << k) : 0u;
+                    while (m) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint64_t ea = sbase + (uint64_t)hl * 64u + (uint32_t)((batch >> 1) * 16) + k + 1u;
+                        if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
+                            const uint32_t slot = atomicAdd(wcnt, 1u);
+                            if (slot < p.cap) p.tile_slots[t_idx * p.cap + slot] = (uint32_t)(ea - wbase);
+                        }
+                    }
+                }
+                acc = 0;
+            }
+        }
+    };
+    // steady state: every stage is refilled unconditionally (a conditional refill makes the compiler's vmcnt
+    // bookkeeping pessimistic: it then waits for younger stages too); the last D half-lines are peeled
+#pragma unroll 1
+    for (int hl0 = 0; hl0 < HALVES - D; hl0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) half(d, hl0 + d, std::true_type{});
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) half(d, HALVES - D + d, std::false_type{});
+}
+
+template <int LINES, int D>
+__global__ __launch_bounds__(512, 2) void k_scan3(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ __attribute__((aligned(1024))) uint32_t tab[256 * 64];  // [entry][lane]
+    constexpr uint32_t SL = LINES * 128;
+    constexpr uint64_t TILE = 64ull * SL;
+    constexpr int PITCH = 80;
+    static_assert((LINES * 2) % D == 0 && D % 2 == 0, "the half-line loop is unrolled by the (even) prefetch depth");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *counters = reinterpret_cast<uint32_t *>(smem);
+    uint8_t *stage = smem + 64 + wave * (64 * PITCH);
+    for (int i = tid; i < 256 * 64; i += 512) tab[i] = p.table_rot[i >> 6];
+    __syncthreads();
+
+    uint32_t *wcnt = counters + wave;
+    const uint64_t A = p.nbytes + p.lead;
+    const uint8_t *lds0 = reinterpret_cast<const uint8_t *>(tab);
+
+    for (;;) {
+        unsigned long long g0 = 0;
+        if (lane == 0) g0 = atomicAdd(p.tile_queue, 1ull);
+        const uint64_t t_idx = __shfl(g0, 0, 64);
+        if (t_idx >= p.ntiles) break;
+        const uint64_t wbase = t_idx * TILE;
+        if (lane == 0) *wcnt = 0;
+        wave_sync();
+        if ((wbase >= 64) && (wbase + TILE <= A))
+            scan3_tile<LINES, D, true>(p, t_idx, A, lane, lds0, stage, wcnt);
+        else
+            scan3_tile<LINES, D, false>(p, t_idx, A, lane, lds0, stage, wcnt);
+        wave_sync();
+        if (lane == 0) p.tile_cnt[t_idx] = *wcnt;
+        wave_sync();
+    }
+}
+#undef PBS_LOOKUP3
+
+template <int LINES, int D>
+static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st) {
+    constexpr size_t lds = 64 + 8 * 64 * 80;  // counters + 8 per-wave stages (40 KiB: also keeps SHA workgroups off this CU)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan3<LINES, D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    uint64_t blocks = (p.ntiles + 7) / 8;
+    if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;
+    hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
+// PBSGPU_SCAN_DEPTH (coop mode): half-lines in flight per wave, 2 (default) | 4 (even: the two rings alternate)
+static int scan_depth() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("PBSGPU_SCAN_DEPTH");
+        v = e ? atoi(e) : 2;
+        if (v != 2 && v != 4) v = 2;
+    }
+    return v;
+}
+
+template <int LINES>
+static hipError_t launch_scan3_any(const ScanParams &p, int num_cus, hipStream_t st) {
+    switch (scan_depth()) {
+    case 4: return launch_scan3<LINES, 4>(p, num_cus, st);
+    default: return launch_scan3<LINES, 2>(p, num_cus, st);
+    }
+}
+
 // PBSGPU_SCAN_VARIANT (experiments): 0 = 34 lines/2 buffers, 1 = 36/3, 2 = 66/2, 3 = 72/3
 static int scan_variant() {
     static int v = -1;
@@ -384,12 +602,15 @@ uint32_t scan_tile_bytes(uint64_t nbytes) {
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
     if (p.ntiles == 0) return hipSuccess;
-    if (p.tile_bytes == 64u * 34u * 128u)
+    if (p.tile_bytes == 64u * 34u * 128u) {
+        if (scan_mode() == 2) return launch_scan3_any<34>(p, num_cus, st);
         return (PBS_SCAN_NBUF == 1) ? launch_scan2<34, 1>(p, num_cus, st) : launch_scan2<34, 2>(p, num_cus, st);
+    }
     if (p.tile_bytes == 64u * 36u * 128u) return launch_scan2<36, 3>(p, num_cus, st);
     if (p.tile_bytes == 64u * 66u * 128u) return launch_scan2<66, 2>(p, num_cus, st);
     if (p.tile_bytes == 64u * 72u * 128u) return launch_scan2<72, 3>(p, num_cus, st);
-    if (p.tile_bytes == 64u * 4u * 128u) return launch_scan2<4, 2>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 4u * 128u)
+        return (scan_mode() == 2) ? launch_scan3_any<4>(p, num_cus, st) : launch_scan2<4, 2>(p, num_cus, st);
     constexpr int S = kScanStrip, W = kScanWaves;
     constexpr size_t lds = 256 * 32 * 4 + (size_t)W * (kWindow + 64 * S) + W * 4 + 32;
     {
