@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight batch: ROCm's default of 4 would make engine streams share queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -39,13 +39,13 @@ CHAIN_US_PER_BLOCK = 1.6    # floor of the serial chain: 64 rounds x 14 instr x 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gib", type=float, default=64.0, help="stream size per GPU in GiB (config 2: 64)")
     ap.add_argument("--avg", type=int, default=4 << 20)
-    ap.add_argument("--inflight", type=int, default=4,
-                    help="batches in flight on separate HIP streams (default 4: 4 x 64 GiB fits the 288 GB HBM); "
-                         "1 = strictly serial steps")
+    ap.add_argument("--inflight", type=int, default=8,
+                    help="batches in flight on separate HIP streams (default 8 = the engine's slot count; every "
+                         "step is a full pass over the same HBM-resident stream); 1 = strictly serial steps")
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2)
@@ -137,9 +137,9 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
             tj = json.load(f)
         traffic["sha"] = int(tj["kernels"]["k_sha256_pair<RecordSource>"]["read_ratio_vs_algorithmic"] * nbytes)
-        traffic["scan"] = int(tj["kernels"]["k_scan2<34>"]["read_ratio_vs_algorithmic"] * nbytes)
+        traffic["scan"] = int(tj["kernels"]["k_scan3<34,4>"]["read_ratio_vs_algorithmic"] * nbytes)
         traffic["note"] = "HBM read bytes per launch = measured FETCH_SIZE ratio (x2 gfx950 correction) x bytes; " \
-                          "PMC passes in profiles/r01_pmc_fetch_size_bench8g.csv"
+                          "PMC passes in profiles/r01_pmc_fetch_size_bench8g.csv, r01_pmc_fetch_size_scan3_bench8g.csv"
     except Exception:
         pass
 
@@ -188,7 +188,7 @@ def main():
                 "valu_frac": round(sha_gbs / (VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE), 4),
                 "algorithmic_bytes_per_launch": nbytes,
                 "kernel_ms": round(sha_ms, 3),
-                "scan_kernel": {"kernel": "k_scan2<34>", "bound": "hbm", "achieved": round(scan_gbs, 1),
+                "scan_kernel": {"kernel": "k_scan3<34,4>", "bound": "hbm", "achieved": round(scan_gbs, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
                                 "kernel_ms": round(scan_ms, 3), "traffic": traffic["scan"]},
                 "resolve_ms": round(resolve_ms, 3),

@@ -9,6 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 
+// The engine runs up to 8 batches on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+// (default 4) and reads the variable when the HIP runtime initialises, i.e. at the first HIP call of the process.
+// Setting a default when this library is loaded covers hosts that bind the C ABI directly (cgo, JNI, ctypes)
+// without going through the Python package; an explicit setting of the host always wins.
+__attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 namespace pbse {
 std::atomic<int> g_last_hip_error{0};
 }
@@ -127,7 +133,7 @@ int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
     HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
-                              sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, s.stream));
+                              sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, e->sha_slack_pct, s.stream));
     HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
                                        s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
@@ -401,6 +407,11 @@ int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight
         if (hipMalloc(reinterpret_cast<void **>(&e->d_table_rot), sizeof(rot)) != hipSuccess) { st = PBSGPU_E_NOMEM; break; }
         if (hipMemcpy(e->d_table_rot, rot, sizeof(rot), hipMemcpyHostToDevice) != hipSuccess) { st = PBSGPU_E_HIP; break; }
         e->slots.resize(inflight);
+        e->sha_slack_pct = inflight > 4 ? 0u : 25u;
+        if (const char *sl = getenv("PBSGPU_SHA_SLACK_PCT")) {  // experiments
+            const int v = atoi(sl);
+            if (v >= 0 && v <= 400) e->sha_slack_pct = (uint32_t)v;
+        }
         for (auto &s : e->slots) {
             if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { st = PBSGPU_E_HIP; break; }
             for (auto &ev : s.ev)

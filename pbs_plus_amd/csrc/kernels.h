@@ -63,9 +63,11 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
                                  const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
                                  const uint32_t *wg_limit, int num_cus, hipStream_t st);
-// longest-first queue order (counting sort by size class) + workgroup budget for the SHA kernel
+// longest-first queue order (counting sort by size class) + workgroup budget for the SHA kernel:
+// lanes = (1 + slack_pct/100) x total blocks / longest chunk's blocks
 hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
-                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, hipStream_t st);
+                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
+                        hipStream_t st);
 // SHA-256 of whole segments (verification path): digests[32*i] for segs[i]
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
                                   uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);

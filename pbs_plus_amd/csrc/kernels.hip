@@ -25,12 +25,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// PBSGPU_SCAN_MODE=lds selects the LDS-tiled scan kernel (A/B measurements); default = register streaming
+// PBSGPU_SCAN_MODE selects the scan kernel for A/B measurements: default = cooperative loads (k_scan3);
+// "stream" = per-lane register streaming (k_scan2); "lds" = LDS-tiled (k_scan)
 static int scan_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("PBSGPU_SCAN_MODE");
-        mode = (e && e[0] == 'l') ? 0 : (e && e[0] == 'c') ? 2 : 1;  // lds | coop | (default) stream
+        mode = (e && e[0] == 'l') ? 0 : (e && e[0] == 's') ? 1 : 2;  // lds | stream | (default) coop
     }
     return mode;
 }
@@ -563,13 +564,13 @@ static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st)
     return hipGetLastError();
 }
 
-// PBSGPU_SCAN_DEPTH (coop mode): half-lines in flight per wave, 2 (default) | 4 (even: the two rings alternate)
+// PBSGPU_SCAN_DEPTH (coop mode): half-lines in flight per wave, 4 (default) | 2 (even: the two rings alternate)
 static int scan_depth() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("PBSGPU_SCAN_DEPTH");
-        v = e ? atoi(e) : 2;
-        if (v != 2 && v != 4) v = 2;
+        v = e ? atoi(e) : 4;
+        if (v != 2 && v != 4) v = 4;
     }
     return v;
 }
@@ -577,8 +578,8 @@ static int scan_depth() {
 template <int LINES>
 static hipError_t launch_scan3_any(const ScanParams &p, int num_cus, hipStream_t st) {
     switch (scan_depth()) {
-    case 4: return launch_scan3<LINES, 4>(p, num_cus, st);
-    default: return launch_scan3<LINES, 2>(p, num_cus, st);
+    case 2: return launch_scan3<LINES, 2>(p, num_cus, st);
+    default: return launch_scan3<LINES, 4>(p, num_cus, st);
     }
 }
 
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
 // streams). Counting sort by size class (no comparison sort needed for a scheduling order).
 __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const uint32_t *nrec_p, uint32_t shift,
                                                 uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs,
-                                                const uint32_t *maxcnt, uint32_t cap) {
+                                                const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct) {
     // a scan tile overflowed its slot list: this pass will be re-run with a larger capacity, so do not
     // spend a SHA pass on its (incomplete) cut list
     if (maxcnt && *maxcnt > cap) {
@@ -1315,9 +1316,9 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int i = 0; i < BINS; ++i) { base[i] = run; run += hist[i]; }
-        // lanes needed so that total work / lanes stays below the longest chain (25 % slack)
+        // lanes needed so that total work / lanes stays below the longest chain (slack_pct, default 25 %)
         const unsigned long long lg = longest ? longest : 1;
-        unsigned long long lanes = (tot_blocks * 5 / 4 + lg - 1) / lg;
+        unsigned long long lanes = (tot_blocks * (100 + slack_pct) / 100 + lg - 1) / lg;
         uint32_t wgs = (uint32_t)((lanes + 127) / 128);
         const uint32_t need = (n + 127) / 128;
         if (wgs > need) wgs = need;
@@ -1335,11 +1336,12 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
 }
 
 hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
-                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, hipStream_t st) {
+                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
+                        hipStream_t st) {
     uint32_t shift = 0;
     while (((uint64_t)max_chunk >> shift) >= 1024) ++shift;
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus,
-                       maxcnt, cap);
+                       maxcnt, cap, slack_pct);
     return hipGetLastError();
 }
 

@@ -1,7 +1,7 @@
 """A/B of the candidate-scan kernels: parity against the oracle on small inputs, then the uncontended
 kernel time on a large device-resident stream. Mode comes from PBSGPU_SCAN_MODE (read once per process).
 
-  PBSGPU_SCAN_MODE=coop python scripts/ab_scan.py [GiB]
+  PBSGPU_SCAN_MODE=stream python scripts/ab_scan.py [GiB]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ from oracle import oracle as O  # noqa: E402  (checker only)
 from pbs_plus_amd import Engine, buzhash  # noqa: E402
 from tests.helpers import records_equal  # noqa: E402
 
-mode = os.environ.get("PBSGPU_SCAN_MODE", "stream")
+mode = os.environ.get("PBSGPU_SCAN_MODE", "coop") + os.environ.get("PBSGPU_SCAN_DEPTH", "")
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 16.0
 for avg, n, kind in ((4096, 3_000_001, 3), (4096, 70_001, 0), (65536, 9_000_123, 1), (4 << 20, 80 << 20, 0),
                      (4 << 20, (200 << 20) + 77, 3)):

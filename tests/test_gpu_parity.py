@@ -421,8 +421,8 @@ def test_xxh3_many_matches_xxhash_library(engines):
 
 
 def test_alternate_kernels_stay_bit_exact(gpu_lib):
-    """The A/B kernels (single-wave SHA-256, LDS-tiled scan) are selected by environment variables read
-    once per process: run a small parity check in a subprocess with both switched."""
+    """The A/B kernels (single-wave SHA-256; LDS-tiled and per-lane streaming scans; scan prefetch depth 2) are
+    selected by environment variables read once per process: run a small parity check in subprocesses."""
     import subprocess
     import sys
 
@@ -438,9 +438,11 @@ def test_alternate_kernels_stay_bit_exact(gpu_lib):
         "    assert records_equal(eng.chunk_and_digest(data), O.chunk_and_digest(O.new_config(avg), data)), avg\n"
         "    eng.close()\n"
         "print('alt-ok')\n" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-    env = dict(__import__("os").environ, PBSGPU_SHA_MODE="lane", PBSGPU_SCAN_MODE="lds")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
-    assert "alt-ok" in out.stdout, out.stdout + out.stderr
+    for alt in (dict(PBSGPU_SHA_MODE="lane", PBSGPU_SCAN_MODE="lds"), dict(PBSGPU_SCAN_MODE="stream"),
+                dict(PBSGPU_SCAN_DEPTH="2")):
+        env = dict(__import__("os").environ, **alt)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert "alt-ok" in out.stdout, str(alt) + out.stdout + out.stderr
 
 
 def test_engine_is_safe_from_many_threads(engines, O):
