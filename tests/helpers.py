@@ -92,3 +92,56 @@ def scan_lane_model(data, table, mask, break_min, strip=4352):
             if h >= thr and e >= 64:
                 out.append(e)
     return np.asarray(out, dtype=np.uint64)
+
+
+def scan_coop_model(data, table, mask, break_min, lines=4):
+    """numpy/python statement of kernels.hip k_scan3's dataflow for one buffer (no GPU):
+      * wave tiles of 64 strips x (lines*128) bytes, a strip per lane, 64-byte half-lines;
+      * quad-cooperative fetch: load j of a half-line gives lane (q, ql) piece ql (16 B) of strip 4q+j, zero outside
+        the buffer; the per-wave stage [strip][piece] hands every lane its own 64 bytes back (the LDS transpose);
+      * rolling hash h(i) = rotl(h(i-1),1) ^ t(i) ^ t(i-64) with TWO 64-entry rings of table values that swap roles
+        every half-line (warm-up plays half-line -1 and fills ring[1]; half-line hl writes ring[hl & 1]);
+      * pre-rotated table, one unsigned compare.
+    Returns ascending candidate END offsets; must equal oracle.candidates()."""
+    data = np.asarray(data, dtype=np.uint8)
+    bits = int(mask + 1).bit_length() - 1
+    r = (32 - bits) & 31
+    T = np.asarray(table, dtype=np.uint64)
+    Trot = ((((T << r) | (T >> (32 - r))) & 0xFFFFFFFF) if r else T.copy()).astype(np.uint64)
+    thr = (int(break_min) << r) & 0xFFFFFFFF
+    n = data.size
+    SL = lines * 128
+    TILE = 64 * SL
+    out = []
+
+    def piece(a):  # 16 bytes at stream offset a, zeros outside [0, n)
+        if a >= n or a + 16 <= 0:
+            return np.zeros(16, dtype=np.uint8)
+        v = np.zeros(16, dtype=np.uint8)
+        lo, hi = max(a, 0), min(a + 16, n)
+        v[lo - a:hi - a] = data[lo:hi]
+        return v
+
+    for wbase in range(0, n, TILE):
+        ring = np.zeros((64, 2, 64), dtype=np.uint64)   # [lane][which][pos]
+        h = np.zeros(64, dtype=np.uint64)
+        for hl in range(-1, 2 * lines):
+            stage = np.zeros((64, 4, 16), dtype=np.uint8)     # [strip][piece][byte]
+            for lane in range(64):                            # the 4 loads of every lane
+                q4, ql = lane & ~3, lane & 3
+                for j in range(4):
+                    stage[q4 + j, ql] = piece(wbase + (q4 + j) * SL + hl * 64 + ql * 16)
+            rows = stage.reshape(64, 64)                      # lane's own row after the transpose
+            new, old = (hl & 1), (hl & 1) ^ 1
+            for pos in range(64):
+                t = Trot[rows[:, pos]]
+                hrot = ((h << np.uint64(1)) | (h >> np.uint64(31))) & np.uint64(0xFFFFFFFF)
+                if hl < 0:
+                    h = hrot ^ t                              # warm-up: no leaving term yet
+                else:
+                    h = hrot ^ t ^ ring[:, old, pos]
+                    ends = wbase + np.arange(64) * SL + hl * 64 + pos + 1
+                    hit = (h >= thr) & (ends >= 64) & (ends <= n)
+                    out.extend(int(e) for e in ends[hit])
+                ring[:, new, pos] = t
+    return np.asarray(sorted(out), dtype=np.uint64)

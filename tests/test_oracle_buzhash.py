@@ -179,3 +179,16 @@ def test_scan_kernel_algebra_model_equals_rolling_hash(O, avg, n, kind, strip):
     data = O.fill(n, 31 + avg, kind)
     got = scan_lane_model(data, O.default_table(), cfg.mask, cfg.break_min, strip=strip)
     assert np.array_equal(got, O.candidates(cfg, data))
+
+
+@pytest.mark.parametrize("avg,n,kind,lines", [(256, 40_000, 0, 1), (4096, 90_001, 0, 4), (4096, 70_000, 3, 2)])
+def test_coop_scan_dataflow_model_equals_rolling_hash(O, avg, n, kind, lines):
+    """k_scan3's dataflow (quad-cooperative pieces, staged transpose, rolling hash over two alternating rings of
+    table values, warm-up as half-line -1) restated in numpy and checked against the oracle: the index algebra
+    of the default scan kernel can be validated without a GPU."""
+    from helpers import scan_coop_model
+
+    cfg = O.new_config(avg)
+    data = O.fill(n, 77 + avg, kind)
+    got = scan_coop_model(data, O.default_table(), cfg.mask, cfg.break_min, lines=lines)
+    assert np.array_equal(got, O.candidates(cfg, data))
