@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight batch: ROCm's default of 4 would make engine streams share queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -39,13 +39,13 @@ CHAIN_US_PER_BLOCK = 1.6    # floor of the serial chain: 64 rounds x 14 instr x 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gib", type=float, default=64.0, help="stream size per GPU in GiB (config 2: 64)")
     ap.add_argument("--avg", type=int, default=4 << 20)
-    ap.add_argument("--inflight", type=int, default=8,
-                    help="batches in flight on separate HIP streams (default 8 = the engine's slot count; every "
-                         "step is a full pass over the same HBM-resident stream); 1 = strictly serial steps")
+    ap.add_argument("--inflight", type=int, default=16,
+                    help="batches in flight on separate HIP streams (default 16 = the engine's maximum slot count; "
+                         "every step is a full pass over the same HBM-resident stream); 1 = strictly serial steps")
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2)
@@ -78,7 +78,7 @@ def main():
 
     nbytes = int(a.gib * GiB) & ~7
     cfg = buzhash.NewConfig(a.avg)
-    inflight = max(1, min(a.inflight, 8))
+    inflight = max(1, min(a.inflight, 16))
     eng = Engine(cfg, device=local_rank, inflight=max(inflight, 1))
     data = torch.empty(nbytes, dtype=torch.uint8, device=dev)   # the corpus: resident in HBM
     eng.fill(data.data_ptr(), nbytes, seed=a.seed + rank, kind=0)

@@ -106,7 +106,7 @@ typedef struct pbsgpu_segment {
 typedef struct pbsgpu_engine pbsgpu_engine;
 
 /* `device` = HIP ordinal; `inflight` = number of batches that may be in
- * flight at once (1..8; 0 -> default 2). */
+ * flight at once (1..16; 0 -> default 2). */
 int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight, pbsgpu_engine **out);
 void pbsgpu_engine_destroy(pbsgpu_engine *eng);
 int pbsgpu_engine_config(const pbsgpu_engine *eng, pbsgpu_config *out);

@@ -14,11 +14,11 @@ Everything executes in the gfx950 kernels of ``lib/libpbsgpu.so``; there is no C
 """
 import os as _os
 
-# The engine overlaps batches on separate HIP streams (up to 8 slots + copy streams); ROCm's default of 4
+# The engine overlaps batches on separate HIP streams (up to 16 slots + copy streams); ROCm's default of 4
 # hardware queues would make them share queues, and with 8 two of eight slots still collide (measured: a
 # pair of batches then runs back to back). Must be set before the HIP runtime initialises (import this
 # package first).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from . import buzhash  # noqa: F401,E402
 from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401,E402

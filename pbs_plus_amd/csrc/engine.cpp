@@ -9,11 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 
-// The engine runs up to 8 batches on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+// The engine runs up to 16 batches on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
 // (default 4) and reads the variable when the HIP runtime initialises, i.e. at the first HIP call of the process.
 // Setting a default when this library is loaded covers hosts that bind the C ABI directly (cgo, JNI, ctypes)
 // without going through the Python package; an explicit setting of the host always wins.
-__attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+__attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 namespace pbse {
 std::atomic<int> g_last_hip_error{0};
@@ -370,7 +370,7 @@ int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight
     if (cfg->break_min > cfg->mask) return PBSGPU_E_INVALID;
     if (cfg->min < pbsk::kWindow || cfg->max <= cfg->min || cfg->max < 128) return PBSGPU_E_INVALID;
     if (inflight == 0) inflight = 2;
-    if (inflight > 8) return PBSGPU_E_INVALID;
+    if (inflight > 16) return PBSGPU_E_INVALID;
 
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
