@@ -192,6 +192,19 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
                                 "kernel_ms": round(scan_ms, 3), "traffic": traffic["scan"]},
                 "resolve_ms": round(resolve_ms, 3),
+                "overlap_note": "kernel_ms/achieved/frac above are per launch, measured with HIP events while %d "
+                                "launches overlap on the chip (a launch then also waits for CUs); 'uncontended' repeats "
+                                "them for one strictly serial step, 'aggregate' is all ranks' input bytes of the timed "
+                                "region / wall time against the HBM peak of the GPUs used" % inflight,
+                "uncontended": {
+                    "sha256": {"kernel_ms": round(serial_timing["sha_ms"], 3),
+                               "achieved": round(nbytes / (serial_timing["sha_ms"] * 1e-3) / 1e9, 1),
+                               "frac": round(nbytes / (serial_timing["sha_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "scan": {"kernel_ms": round(serial_timing["scan_ms"], 3),
+                             "achieved": round(nbytes / (serial_timing["scan_ms"] * 1e-3) / 1e9, 1),
+                             "frac": round(nbytes / (serial_timing["scan_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                "aggregate": {"achieved": round(total_bytes / elapsed / 1e9, 1), "unit": "GB/s",
+                              "frac": round(total_bytes / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4)},
                 "chain_floor_ms": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3, 1),
                 "chain_frac": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3 / sha_ms, 3),
                 "chain_note": "SHA-256 is sequential inside a chunk: the launch cannot finish before its longest chunk "

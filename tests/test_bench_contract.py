@@ -1,0 +1,154 @@
+"""bench.py's output contract, exercised on CPU: the engine is replaced by a stand-in that answers with the
+oracle's records (tests may use the oracle; the product path never does), torch.cuda calls are stubbed, and the
+one JSON line is checked for every field the driver and the judge read. This is a test of bench.py's host
+logic and JSON assembly, not of the kernels (those are the -m gpu tests)."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _FakeEngine:
+    """Same surface as pbs_plus_amd.Engine as far as bench.py uses it."""
+
+    def __init__(self, config, device=0, inflight=2):
+        from oracle import oracle as O
+
+        self.O, self.avg, self.inflight = O, config.AvgSize, inflight
+        self.tickets, self.next, self.filled = {}, 1, None
+
+    def fill(self, dptr, nbytes, seed, kind=0, stream_off=0):
+        self.filled = (nbytes, seed, kind)
+
+    def submit(self, data, segments=None, nbytes=None):
+        assert len(self.tickets) < self.inflight, "bench submitted more batches than engine slots"
+        n, seed, kind = self.filled
+        assert nbytes == n
+        host = self.O.fill(n, seed, kind)
+        t = self.next
+        self.next += 1
+        self.tickets[t] = self.O.chunk_and_digest(self.O.new_config(self.avg), host)
+        return t
+
+    def timing(self, t):
+        return {"h2d_ms": 0.0, "scan_ms": 2.0, "resolve_ms": 0.5, "sha_ms": 40.0, "total_ms": 42.5,
+                "ncandidates": 10, "nrecords": int(self.tickets[t].size), "retries": 0}
+
+    def collect(self, t):
+        return self.tickets.pop(t)
+
+    def dedup(self, records):
+        """first-occurrence duplicate flags, like pbsgpu_dedup_host"""
+        seen, dup = set(), np.zeros(records.size, dtype=np.uint8)
+        for i, d in enumerate(records["digest"]):
+            k = d.tobytes()
+            dup[i] = k in seen
+            seen.add(k)
+        return dup, {"nrecords": int(records.size), "nunique": len(seen)}
+
+    def close(self):
+        assert not self.tickets, "bench left tickets uncollected"
+
+
+def _patched_main(argv):
+    """bench.main() with the GPU pieces stubbed (also the entry point of the 2-rank subprocesses below)."""
+    import torch
+
+    import pbs_plus_amd
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    real_empty = torch.empty
+    torch.empty = lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "device"})
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.device_count = lambda: 1
+    pbs_plus_amd.Engine = _FakeEngine
+    sys.argv = ["bench.py"] + list(argv)
+    bench.main()
+
+
+@pytest.mark.parametrize("inflight,steps", [(16, 5), (1, 2), (3, 7)])
+def test_bench_json_line_contract(monkeypatch, inflight, steps):
+    import torch
+
+    import pbs_plus_amd
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "device"}))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(pbs_plus_amd, "Engine", _FakeEngine)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gib", str(16 / 1024), "--avg", "65536", "--steps", str(steps),
+                                      "--warmup", "1", "--inflight", str(inflight), "--cpu-sample-gib", str(8 / 1024)])
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main()
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "GiB/s" and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["inflight_batches"] == inflight
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "scan_kernel", "uncontended",
+                "aggregate"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= d["config"]["bytes_per_gpu"]
+    assert set(r["uncontended"]) == {"sha256", "scan"}
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0
+    assert c["prefix_records_match_gpu"] is True
+
+
+def test_bench_two_ranks_gloo_prints_one_aggregate_line(tmp_path):
+    """The N>1 branch of bench.py (barrier, per-step digest-set all-gather, MAX-over-ranks timing, rank 0 prints)
+    with world_size 2 over gloo on CPU — the launch shape the driver uses with RCCL on the GPU node."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_bench_contract import _patched_main\n"
+            "_patched_main(['--gpus', '2', '--gib', str(16 / 1024), '--avg', '65536', '--steps', '4', '--warmup', '1',"
+            " '--inflight', '3', '--no-cpu-baseline'])\n" % (ROOT, os.path.join(ROOT, "tests")))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PBS_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    json_lines = [[ln for ln in o.splitlines() if ln.startswith("{")] for o, _ in outs]
+    assert len(json_lines[0]) == 1 and len(json_lines[1]) == 0, json_lines   # rank 0 only
+    d = json.loads(json_lines[0][0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    one_rank_bytes = d["config"]["bytes_per_gpu"]
+    # whole-job aggregate: both ranks' bytes over the (max over ranks) wall time
+    assert abs(d["value"] - 2 * 4 * one_rank_bytes / (1 << 30) / (d["ms_per_step"] * 4e-3)) / d["value"] < 0.02
+    assert "cpu_baseline" not in d  # rank 0 at N=1 only
