@@ -373,9 +373,11 @@ static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st)
 // strip per instruction (16 lines per instruction; 6.0 TB/s ceiling) and a small per-wave LDS stage
 // transposes each 64-byte half-line back to "one lane = one strip": 4 ds_write_b128 at
 // [strip][piece] with an 80-byte strip pitch, 4 ds_read_b128 of the lane's own row (pitch 5 slots, odd:
-// conflict-free). A half-line is exactly one revolution of the 64-entry prefix ring, so ring indices
-// stay static. D half-lines per wave are kept in flight (D x 4 KiB: memory-level parallelism). Everything
-// else (ring, pre-rotated 64x replicated table, batched lookups, slots) as k_scan2.
+// conflict-free). A half-line is exactly one revolution of the 64-entry window ring, so ring indices
+// stay static. D half-lines per wave are kept in flight (D x 4 KiB: memory-level parallelism). The hash
+// runs in rolling form over two alternating rings of table values (see scan3_tile); pre-rotated 64x
+// replicated table, batched lookups and slot lists as in k_scan2.
+// Index algebra restated on CPU: tests/helpers.py::scan_coop_model.
 #define PBS_LOOKUP3(w, k) \
     (*reinterpret_cast<const uint32_t *>(lds0 + __builtin_amdgcn_perm((w), lane4, 0x0c0c0400u | ((uint32_t)(k) << 8))))
 
@@ -402,7 +404,7 @@ __device__ __forceinline__ void scan3_tile(const ScanParams &p, const uint64_t t
             const int64_t a = (int64_t)wbase + (int64_t)(q4 + j) * SL + (int64_t)hl * 64 + ql * 16;
             if constexpr (INTERIOR) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(p.data_al + a);
-                G[j] = make_uint4(v.x, v.y, v.z, v.w);
+                G[j] = make_uint4(v.x, v.y, v.z, v.w);  // component-wise: a whole-struct store keeps G[][] in scratch
             } else {  // branch-free (a branch per load would force vmcnt(0) waits): clamp the address, select zero
                 const bool in = a >= 0 && (uint64_t)a < A;
                 const uint4 v = *reinterpret_cast<const uint4 *>(p.data_al + (in ? a : 0));
