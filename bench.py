@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--inflight", type=int, default=16,
                     help="batches in flight on separate HIP streams (default 16 = the engine's maximum slot count; "
                          "every step is a full pass over the same HBM-resident stream); 1 = strictly serial steps")
+    ap.add_argument("--collect", choices=("fifo", "any"), default="fifo",
+                    help="which in-flight step to collect when all slots are busy: the oldest (fifo) or whichever "
+                         "has finished on the device (any; pbsgpu_ticket_done)")
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2)
@@ -84,13 +87,22 @@ def main():
     eng.fill(data.data_ptr(), nbytes, seed=a.seed + rank, kind=0)
     torch.cuda.synchronize()
 
+    def next_to_collect(pending):
+        if a.collect == "fifo" or len(pending) == 1:
+            return 0
+        while True:  # whichever ticket has finished on the device; records are per step, their order is irrelevant
+            for i, t in enumerate(pending):
+                if eng.done(t):
+                    return i
+            time.sleep(0.0005)
+
     def run_steps(k, timings=None):
         """k passes; with inflight > 1 consecutive passes overlap on separate HIP streams."""
         pending = []
         nrec, recs = 0, None
         for _ in range(k):
             if len(pending) == inflight:
-                t = pending.pop(0)
+                t = pending.pop(next_to_collect(pending))
                 if timings is not None:
                     timings.append(eng.timing(t))
                 recs = eng.collect(t)
@@ -168,7 +180,7 @@ def main():
                 "workload": f"single {a.gib:g} GiB stream per GPU, Buzhash CDC avg 4 MiB (min 1 MiB, max 16 MiB) "
                             f"+ SHA-256 per chunk (BASELINE.json configs[1])",
                 "bytes_per_gpu": nbytes, "avg_chunk": a.avg, "chunks_per_gpu": int(nrec),
-                "inflight_batches": inflight,
+                "inflight_batches": inflight, "collect": a.collect,
                 "parallelism": f"segments sharded, {world} rank(s), digest-set all-gather" if world > 1 else "1 GPU",
             },
             "roofline": {

@@ -123,6 +123,10 @@ int pbsgpu_submit_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
                        const pbsgpu_segment *segs, uint32_t nseg, uint64_t *ticket);
 /* Block until the ticket's work is done; report its record count. */
 int pbsgpu_wait(pbsgpu_engine *eng, uint64_t ticket, uint64_t *nrecords);
+/* Non-blocking: *done = 1 when everything enqueued for the ticket has finished on the device (collect will not
+ * wait, except for the rare density retry), 0 while it is still running. Lets a host that keeps several
+ * tickets in flight collect whichever finishes first instead of first-in-first-out. */
+int pbsgpu_ticket_done(pbsgpu_engine *eng, uint64_t ticket, int *done);
 /* Wait, copy the records out (PBSGPU_E_CAPACITY + *nrecords if cap is too
  * small; the ticket stays valid), release the ticket. */
 int pbsgpu_collect(pbsgpu_engine *eng, uint64_t ticket, pbsgpu_record *out, uint64_t cap,

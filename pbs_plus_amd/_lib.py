@@ -103,6 +103,7 @@ SYMBOLS = {
     "pbsgpu_submit_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
     "pbsgpu_submit_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
     "pbsgpu_wait": (C.c_int, [_P, C.c_uint64, _U64P]),
+    "pbsgpu_ticket_done": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int)]),
     "pbsgpu_collect": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P]),
     "pbsgpu_ticket_timing": (C.c_int, [_P, C.c_uint64, C.POINTER(Timing)]),
     "pbsgpu_candidates_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _U64P]),

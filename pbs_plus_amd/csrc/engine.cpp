@@ -476,6 +476,27 @@ int pbsgpu_wait(pbsgpu_engine *e, uint64_t ticket, uint64_t *nrecords) {
     return PBSGPU_OK;
 }
 
+int pbsgpu_ticket_done(pbsgpu_engine *e, uint64_t ticket, int *done) {
+    if (!e || !done) return PBSGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(e->mu);
+    CHK(set_device(e));
+    Slot *s = find_ticket(e, ticket);
+    if (!s) return PBSGPU_E_TICKET;
+    if (s->synced) {
+        *done = 1;
+        return PBSGPU_OK;
+    }
+    const hipError_t q = hipStreamQuery(s->stream);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *done = 0;
+        return PBSGPU_OK;
+    }
+    HIPCHK(q);
+    *done = 1;
+    return PBSGPU_OK;
+}
+
 int pbsgpu_collect(pbsgpu_engine *e, uint64_t ticket, pbsgpu_record *out, uint64_t cap, uint64_t *nrecords) {
     if (!e) return PBSGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(e->mu);

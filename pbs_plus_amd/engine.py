@@ -129,6 +129,12 @@ class Engine:
         check(self._L.pbsgpu_wait(self._h, ticket, C.byref(n)), "wait")
         return n.value
 
+    def done(self, ticket: int) -> bool:
+        """Non-blocking: has everything enqueued for the ticket finished on the device?"""
+        d = C.c_int(0)
+        check(self._L.pbsgpu_ticket_done(self._h, int(ticket), C.byref(d)), "ticket_done")
+        return bool(d.value)
+
     def timing(self, ticket: int) -> dict:
         t = _lib.Timing()
         check(self._L.pbsgpu_ticket_timing(self._h, ticket, C.byref(t)), "ticket_timing")

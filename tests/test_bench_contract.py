@@ -40,6 +40,9 @@ class _FakeEngine:
         return {"h2d_ms": 0.0, "scan_ms": 2.0, "resolve_ms": 0.5, "sha_ms": 40.0, "total_ms": 42.5,
                 "ncandidates": 10, "nrecords": int(self.tickets[t].size), "retries": 0}
 
+    def done(self, t):
+        return t == max(self.tickets)   # the newest ticket "finishes" first: out of order, always progress
+
     def collect(self, t):
         return self.tickets.pop(t)
 
@@ -75,8 +78,8 @@ def _patched_main(argv):
     bench.main()
 
 
-@pytest.mark.parametrize("inflight,steps", [(16, 5), (1, 2), (3, 7)])
-def test_bench_json_line_contract(monkeypatch, inflight, steps):
+@pytest.mark.parametrize("inflight,steps,collect", [(16, 5, "fifo"), (1, 2, "fifo"), (3, 7, "any")])
+def test_bench_json_line_contract(monkeypatch, inflight, steps, collect):
     import torch
 
     import pbs_plus_amd
@@ -93,7 +96,8 @@ def test_bench_json_line_contract(monkeypatch, inflight, steps):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gib", str(16 / 1024), "--avg", "65536", "--steps", str(steps),
-                                      "--warmup", "1", "--inflight", str(inflight), "--cpu-sample-gib", str(8 / 1024)])
+                                      "--warmup", "1", "--inflight", str(inflight), "--cpu-sample-gib", str(8 / 1024),
+                                      "--collect", collect])
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench.main()
@@ -107,7 +111,7 @@ def test_bench_json_line_contract(monkeypatch, inflight, steps):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "GiB/s" and d["value"] > 0 and d["ms_per_step"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["inflight_batches"] == inflight
+    assert d["config"]["inflight_batches"] == inflight and d["config"]["collect"] == collect
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "scan_kernel", "uncontended",
                 "aggregate"):
