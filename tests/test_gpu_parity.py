@@ -731,3 +731,27 @@ def test_single_stream_split_over_two_ranks(gpu_lib, O):
     T = (40 << 20) + 12345
     want = O.chunk_and_digest(O.new_config(65536), O.fill(T, 4242, 3))
     assert records_equal(r0, want), describe_mismatch(r0, want)
+
+
+@pytest.mark.gpu
+def test_ticket_done_lets_the_host_collect_out_of_order(engines, O):
+    """pbsgpu_ticket_done: non-blocking completion query, so a host with several tickets in flight can collect
+    whichever finishes first (bench.py --collect any). A small ticket submitted after a large one is collected
+    first; both equal the oracle."""
+    import time
+
+    eng = engines(65536)
+    big, small = O.fill(96 << 20, 91, 0), O.fill(1 << 20, 92, 0)
+    t_big = eng.submit(big)
+    t_small = eng.submit(small)
+    deadline = time.time() + 60
+    while not eng.done(t_small):
+        assert time.time() < deadline, "ticket never reported done"
+        time.sleep(0.001)
+    got_small = eng.collect(t_small)
+    got_big = eng.collect(t_big)
+    cfg = O.new_config(65536)
+    assert records_equal(got_small, O.chunk_and_digest(cfg, small))
+    assert records_equal(got_big, O.chunk_and_digest(cfg, big))
+    with pytest.raises(Exception):
+        eng.done(t_small)  # released ticket
