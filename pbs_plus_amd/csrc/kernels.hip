@@ -951,7 +951,10 @@ struct SegmentSource {
 // ~1700 VALU ops of the compression even with a single wave on the SIMD.
 template <typename Source>
 __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
-                                               uint32_t *queue) {
+                                               uint32_t *queue, const uint32_t *wg_limit) {
+    // k_order's budget counts 128-lane workgroups of the pair kernel = two of these waves; waves beyond it leave
+    // their SIMD slot to the other batches in flight (the queue is dynamic, the remaining waves drain it)
+    if (wg_limit && blockIdx.x >= *wg_limit * 2u) return;
     const int lane = threadIdx.x & 63;
     const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
 
@@ -1392,7 +1395,7 @@ hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs
         hipError_t e = allow_lds(&k_sha256<RecordSource>, pad);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u), dim3(64), pad, st, src, nrec, 0u,
-                           queue);
+                           queue, wg_limit);
     }
     return hipGetLastError();
 }
@@ -1420,7 +1423,7 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
         grid = (unsigned)num_cus * 4u;
         if (grid > need) grid = need;
         hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), pad, st, src, (const uint32_t *)nullptr,
-                           nseg, queue);
+                           nseg, queue, (const uint32_t *)nullptr);
     }
     return hipGetLastError();
 }
