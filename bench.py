@@ -1,24 +1,38 @@
 #!/usr/bin/env python3
 """bench.py — GiB/s ingested through Buzhash CDC + per-chunk SHA-256 on MI355X.
 
-Workload (BASELINE.json configs[1]): one 64 GiB synthetic random stream per GPU, resident in
-HBM before the timed region, cut with buzhash.NewConfig(4 << 20) (the reference's production
-parameter: internal/pxarmount/commit_orchestrate.go:144, internal/tapeio/converter.go:248)
-and every chunk hashed with SHA-256. A "step" = one full pass of the hot path over that
-stream: candidate scan -> compaction/resolve -> SHA-256 of every chunk -> records on the host.
+A "step" = one full pass of the hot path over one HBM-resident batch: candidate scan ->
+compaction/resolve -> SHA-256 of every chunk -> (end, digest) records on the host. Chunker
+parameters are the reference's production ones, buzhash.NewConfig(4 << 20)
+(internal/pxarmount/commit_orchestrate.go:144, internal/tapeio/converter.go:248).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — every rank
-owns its own 64 GiB stream (segments are independent, so the data path has no collective);
-the only exchange is the digest-set all-gather + device dedup after each step.
+Every in-flight slot owns DIFFERENT bytes: the corpus is cut into `--slots` resident batches
+(4 x 64 GiB for the default workload, i.e. the whole HBM) and a batch is resubmitted only after its
+previous pass has been collected, exactly as a deployment would refill a buffer. (`--reread N`
+reproduces round 1's protocol of N overlapping passes over the same bytes, for comparison only.)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
-dominant kernel (SHA-256) and `cpu_baseline` (the C oracle, SHA-NI, one thread, on a bounded
-prefix of the same stream).
+Workloads (BASELINE.json configs):
+  stream64g   configs[1]  one 64 GiB random stream per batch                         (default)
+  manyfiles   configs[2]  2048 x 64 MiB files per 128 GiB device batch, entropy class = file % 4
+  corpus_dup  configs[3]  this GPU's 128 GiB share of the 1 TiB corpus, 40 % of the 64 MiB segments are
+                          copies of an earlier segment; digest-set reduce (all-gather + device dedup) per pass
+  rechunk     configs[4]  the same share after 2 % byte edits (overwrite / insert / delete extents),
+                          re-chunked; reports the re-used chunk fraction vs the base corpus
+  hostfeed    the drop-in's real feed: host buffers written through pbsgpu_stream_write by several
+              producer threads (PCIe-inclusive; never the headline value)
+  verify      A8/A9: whole-file SHA-256 / XXH3-64 batches (verification.HashFile)
+
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): every rank owns its own batches (segments and
+streams are independent, no data-path collective); the only exchange is the digest-set all-gather.
+
+Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` (the C oracle, SHA-NI, one host
+thread, on a bounded sample of the same workload, which also re-checks the GPU records bit for bit).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,29 +44,438 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GiB = 1 << 30
+MiB = 1 << 20
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_TOPS = 39.3       # measured: one wave64 integer op per ~4.2 cycles per SIMD (profiles/r01_ubench_int_valu_issue.log)
-SHA_OPS_PER_BYTE = 22.0     # ~1400 VALU instructions per 64-byte block (14 per round + ~10 per schedule word)
-CHAIN_US_PER_BLOCK = 1.6    # floor of the serial chain: 64 rounds x 14 instr x ~4.2 cycles at 2.4 GHz
+HBM_BYTES = 288e9           # spec capacity
+# Integer VALU issue ceiling for the SHA-256 instruction mix (v_alignbit / v_bitop3 / v_add3 / v_bfi, all VOP3):
+# 620 G wave64-instructions/s chip-wide at 8 waves/SIMD (profiles/r01_ubench_int_valu_issue.log) = 39.7 T lane-ops/s
+VALU_PEAK_TOPS = 39.7
+SHA_OPS_PER_BYTE = 21.9     # 1400 VALU instructions per 64-byte block (64 x 14 rounds + 48 x 10 schedule + 16 perm + 8)
+SHA_VALU_GBS = VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE
+CHAIN_US_PER_BLOCK = 1.655  # measured serial chain of the wave-pair kernel: 64 rounds x 14 instr x 4.25 cycles at 2.4 GHz
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--gib", type=float, default=64.0, help="stream size per GPU in GiB (config 2: 64)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="stream64g",
+                    choices=("stream64g", "manyfiles", "corpus_dup", "rechunk", "hostfeed", "verify"))
+    ap.add_argument("--gib", type=float, default=None, help="bytes per batch in GiB (default: 64; manyfiles 128)")
+    ap.add_argument("--slots", type=int, default=None, help="resident batches = batches in flight (default 4; manyfiles 2)")
+    ap.add_argument("--file-mib", type=float, default=64.0, help="segment size of the many-file / corpus workloads")
     ap.add_argument("--avg", type=int, default=4 << 20)
-    ap.add_argument("--inflight", type=int, default=16,
-                    help="batches in flight on separate HIP streams (default 16 = the engine's maximum slot count; "
-                         "every step is a full pass over the same HBM-resident stream); 1 = strictly serial steps")
-    ap.add_argument("--collect", choices=("fifo", "any"), default="fifo",
-                    help="which in-flight step to collect when all slots are busy: the oldest (fifo) or whichever "
-                         "has finished on the device (any; pbsgpu_ticket_done)")
+    ap.add_argument("--reread", type=int, default=0,
+                    help="round-1 protocol: this many overlapping passes over ONE resident batch (not the default)")
+    ap.add_argument("--collect", choices=("fifo", "any"), default="any")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="corpus workloads at N > 1: weak = every rank owns a full share; strong = one share split over the ranks")
+    ap.add_argument("--producers", type=int, default=8, help="hostfeed: producer threads (one stream each)")
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2)
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------
+# corpus description: every batch is a list of fills (offset, nbytes, seed, kind) so that the oracle can
+# regenerate any sampled range on the host (oracle.fill is the CPU twin of pbsgpu_fill_device)
+# ---------------------------------------------------------------------------------------------------
+class Batch:
+    def __init__(self, buf, nbytes, segs=None, fills=None, label=""):
+        self.buf, self.nbytes, self.label = buf, int(nbytes), label
+        self.segs = None if segs is None else np.ascontiguousarray(segs, dtype=np.uint64).reshape(-1, 2)
+        self.fills = fills or []
+        self.ticket = None
+        self.last = None      # records of the most recent collected pass
+
+    @property
+    def nseg(self):
+        return 1 if self.segs is None else int(self.segs.shape[0])
+
+
+def splitmix64(x):
+    x = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def alloc_batches(eng, nbytes, want):
+    """`want` device buffers of nbytes each; fewer when HBM (288 GB) cannot hold them (reported in config)."""
+    from pbs_plus_amd import PbsGpuError
+    bufs = []
+    for _ in range(want):
+        try:
+            bufs.append(eng.alloc(nbytes))
+        except PbsGpuError:
+            break
+    if not bufs:
+        raise SystemExit("bench: could not allocate even one batch")
+    return bufs
+
+
+class Workload:
+    name = "?"
+    scaling = "weak"
+
+    def __init__(self, a, eng, rank, world):
+        self.a, self.eng, self.rank, self.world = a, eng, rank, world
+        self.batches = []
+        self.extra = {}
+
+    def describe(self):
+        return {}
+
+    def after_collect(self, batch, recs, ctx):
+        pass
+
+    def finish(self, ctx):
+        pass
+
+    def cpu_sample(self):
+        """(host bytes, segments, gpu records of exactly those segments or None) for the oracle leg."""
+        raise NotImplementedError
+
+    def free(self):
+        for b in self.batches:
+            if hasattr(b.buf, "free"):
+                b.buf.free()
+
+
+class Stream64g(Workload):
+    name = "stream64g"
+
+    def __init__(self, a, eng, rank, world):
+        super().__init__(a, eng, rank, world)
+        gib = 64.0 if a.gib is None else a.gib
+        nbytes = int(gib * GiB) & ~7
+        slots = 1 if a.reread else (4 if a.slots is None else a.slots)
+        for i, buf in enumerate(alloc_batches(eng, nbytes, slots)):
+            seed = a.seed + 1000 * rank + i
+            eng.fill(buf.ptr, nbytes, seed=seed, kind=0)
+            self.batches.append(Batch(buf, nbytes, None, [(0, nbytes, seed, 0)], f"stream{i}"))
+        self.gib = gib
+
+    def describe(self):
+        return {"workload": f"single {self.gib:g} GiB random stream per batch, Buzhash CDC avg {self.a.avg >> 20} MiB "
+                            f"(min avg/4, max 4*avg) + SHA-256 per chunk (BASELINE.json configs[1])"}
+
+    def after_collect(self, batch, recs, ctx):
+        if ctx.dist is not None:   # cross-stream duplicate detection over all ranks' files of this step
+            from pbs_plus_amd.dist import global_dedup
+            _, stats, _ = global_dedup(self.eng, recs, device=ctx.comm_dev, cap_records=ctx.rec_cap)
+            self.extra["dedup_last_step"] = {k: int(v) for k, v in stats.items()}
+
+    def cpu_sample(self):
+        from oracle import oracle as O
+        b = self.batches[0]
+        n = int(min(self.a.cpu_sample_gib * GiB, b.nbytes)) & ~7
+        return O.fill(n, b.fills[0][2], 0), [(0, n)], b.last, "prefix"
+
+
+class ManyFiles(Workload):
+    """configs[2]: 10 000 x 64 MiB files streamed through 128 GiB device batches; two batches (4096 files,
+    256 GiB) are resident and alternate. Entropy class by file index % 4: random / all-zero /
+    repeating 4 KiB block / random with 30 % zero extents. Fresh chunker state per file, forced cut at file end."""
+    name = "manyfiles"
+
+    def __init__(self, a, eng, rank, world):
+        super().__init__(a, eng, rank, world)
+        gib = 128.0 if a.gib is None else a.gib
+        fbytes = int(a.file_mib * MiB) & ~7
+        nfiles = max(1, int(gib * GiB) // fbytes)
+        nbytes = nfiles * fbytes
+        slots = 2 if a.slots is None else a.slots
+        for i, buf in enumerate(alloc_batches(eng, nbytes, slots)):
+            fills, segs = [], np.zeros((nfiles, 2), dtype=np.uint64)
+            for f in range(nfiles):
+                g = (rank * slots + i) * nfiles + f           # global file index
+                seed, kind = a.seed + 7919 * g + 1, g % 4
+                eng.fill(buf.ptr + f * fbytes, fbytes, seed=seed, kind=kind)
+                fills.append((f * fbytes, fbytes, seed, kind))
+                segs[f] = (f * fbytes, fbytes)
+            self.batches.append(Batch(buf, nbytes, segs, fills, f"files{i}"))
+        self.nfiles, self.fbytes = nfiles, fbytes
+
+    def describe(self):
+        return {"workload": f"{self.nfiles} x {self.fbytes / MiB:g} MiB mixed-entropy files per device batch "
+                            f"(10 000-file job streamed batch by batch; BASELINE.json configs[2])",
+                "files_per_batch": self.nfiles, "file_bytes": self.fbytes,
+                "entropy_classes": "file % 4: random / zeros / repeating 4 KiB / random with 30 % zero extents"}
+
+    def cpu_sample(self):
+        return sample_segments(self, self.batches[0], per_class=max(1, int(self.a.cpu_sample_gib * GiB / self.fbytes) // 4))
+
+
+def sample_segments(w, b, per_class=4, classes=4):
+    """Regenerate a few segments of batch b on the host (oracle.fill) and pick the GPU's records for them."""
+    from oracle import oracle as O
+    idx = []
+    for c in range(classes):
+        idx += [i for i in range(c, b.nseg, classes)][:per_class]
+    idx = sorted(set(idx))
+    total = sum(b.fills[i][1] for i in idx)
+    host = np.empty(total, dtype=np.uint8)
+    segs, off = [], 0
+    for i in idx:
+        _, n, seed, kind = b.fills[i]
+        O.fill(n, seed, kind, out=host[off:off + n])
+        segs.append((off, n))
+        off += n
+    gpu = None
+    if b.last is not None:
+        parts = []
+        for k, i in enumerate(idx):
+            r = b.last[b.last["segment"] == i].copy()
+            r["segment"] = k
+            parts.append(r)
+        gpu = np.concatenate(parts) if parts else None
+    return host, segs, gpu, "segments"
+
+
+def dup_roots(nseg_total, seed, pct=40):
+    """Content id of every corpus segment: `pct` % of the segments are exact copies of an EARLIER segment chosen
+    by a seeded hash; copies of copies resolve to the original."""
+    g = np.arange(nseg_total, dtype=np.uint64)
+    r = splitmix64(g * np.uint64(2) + np.uint64(seed) * np.uint64(0x10001))
+    is_dup = ((r % np.uint64(100)) < np.uint64(pct)) & (g > 0)
+    src = splitmix64(r) % np.maximum(g, np.uint64(1))
+    root = g.copy()
+    for i in range(nseg_total):          # ascending: the source's root is already final
+        if is_dup[i]:
+            root[i] = root[int(src[i])]
+    return root
+
+
+class CorpusDup(Workload):
+    """configs[3]: 1 TiB = 16 384 x 64 MiB segments, 40 % exact copies; this rank's share (128 GiB = 2048
+    segments) is cut into resident batches. Digest-set reduce once per pass over the share."""
+    name = "corpus_dup"
+
+    def __init__(self, a, eng, rank, world):
+        super().__init__(a, eng, rank, world)
+        self.scaling = a.scaling
+        fbytes = int(a.file_mib * MiB) & ~7
+        share_gib = 128.0 if a.gib is None else a.gib
+        share = max(1, int(share_gib * GiB) // fbytes)           # segments per rank (weak) / in total (strong)
+        if a.scaling == "strong":
+            total = share
+            mine = np.arange(rank, total, world)                 # round-robin sharding (SURVEY.md 8d)
+        else:
+            total = share * world
+            mine = np.arange(rank * share, (rank + 1) * share)
+        self.root = dup_roots(total, a.seed + 4)
+        slots = 2 if a.slots is None else a.slots
+        per = -(-len(mine) // slots)
+        for i in range(slots):
+            ids = mine[i * per:(i + 1) * per]
+            if len(ids) == 0:
+                continue
+            nbytes = len(ids) * fbytes
+            buf = alloc_batches(eng, nbytes, 1)[0]
+            fills, segs = [], np.zeros((len(ids), 2), dtype=np.uint64)
+            for f, g in enumerate(ids):
+                seed = a.seed + 104729 * int(self.root[g]) + 5
+                eng.fill(buf.ptr + f * fbytes, fbytes, seed=seed, kind=0)
+                fills.append((f * fbytes, fbytes, seed, 0))
+                segs[f] = (f * fbytes, fbytes)
+            bt = Batch(buf, nbytes, segs, fills, f"share{i}")
+            bt.ids = ids
+            self.batches.append(bt)
+        self.total, self.mine, self.fbytes = total, mine, fbytes
+        self.pass_recs = {}
+        # expected duplicate bytes among the segments the job holds (all ranks): a segment is a duplicate when an
+        # earlier segment of the job has the same content id
+        held = np.arange(total)
+        _, first = np.unique(self.root[held], return_index=True)
+        self.expected_dup_frac = 1.0 - len(first) / len(held)
+
+    def describe(self):
+        return {"workload": f"{len(self.mine)} x {self.fbytes / MiB:g} MiB segments per GPU of a {self.total}-segment corpus, "
+                            f"40 % of the segments exact copies of an earlier one; digest-set all-gather + device dedup "
+                            f"once per pass (BASELINE.json configs[3])",
+                "segments_per_gpu": int(len(self.mine)), "corpus_segments": int(self.total)}
+
+    def after_collect(self, batch, recs, ctx):
+        self.pass_recs[id(batch)] = recs
+        if len(self.pass_recs) == len(self.batches):     # one pass over the share is complete: digest-set reduce
+            from pbs_plus_amd.dist import global_dedup
+            local = np.concatenate([self.pass_recs[id(b)] for b in self.batches])
+            self.pass_recs = {}
+            if ctx.dist is not None:
+                _, stats, _ = global_dedup(self.eng, local, device=ctx.comm_dev, cap_records=ctx.rec_cap * len(self.batches))
+            else:
+                _, stats = self.eng.dedup(local)
+            tb = max(int(stats["total_bytes"]), 1)
+            self.extra["dedup"] = {"records": int(stats["nrecords"]), "unique": int(stats["nunique"]),
+                                   "duplicate_bytes_frac": round(1.0 - int(stats["unique_bytes"]) / tb, 4),
+                                   "expected_duplicate_frac": round(self.expected_dup_frac, 4)}
+
+    def cpu_sample(self):
+        return sample_segments(self, self.batches[0], per_class=max(1, int(self.a.cpu_sample_gib * GiB / self.fbytes)),
+                               classes=1)
+
+
+def edit_plan(seg_len, rng, frac=0.02):
+    """Piece table of one edited segment: extents with log-uniform length 4 KiB-4 MiB, 1/3 overwrite / insert /
+    delete, totalling ~frac of the bytes. Offsets and lengths are multiples of 8.
+    Returns [(kind, src_off, len)] with kind 0 = copy from the base segment, 1 = new random bytes."""
+    budget = int(seg_len * frac)
+    edits = []
+    while budget > 0:
+        ln = int(np.exp(rng.uniform(np.log(4096), np.log(4 << 20)))) & ~7
+        ln = max(8, min(ln, budget + 8))
+        pos = int(rng.integers(0, max(1, seg_len - ln))) & ~7
+        edits.append((pos, ln, int(rng.integers(0, 3))))
+        budget -= ln
+    edits.sort()
+    pieces, cur = [], 0
+    for pos, ln, kind in edits:
+        if pos < cur:
+            continue                                   # overlapping extent: skipped
+        if pos > cur:
+            pieces.append((0, cur, pos - cur))
+        if kind == 0:                                  # overwrite
+            pieces.append((1, 0, ln))
+            cur = pos + ln
+        elif kind == 1:                                # insert
+            pieces.append((1, 0, ln))
+            cur = pos
+        else:                                          # delete
+            cur = pos + ln
+    if cur < seg_len:
+        pieces.append((0, cur, seg_len - cur))
+    return pieces
+
+
+class Rechunk(Workload):
+    """configs[4]: this GPU's share of the corpus after edits totalling 2 % of the bytes, re-chunked. The base share
+    (64 GiB by default so that base + edited batches fit in HBM together with 4 distinct in-flight batches) is chunked
+    once outside the timed region; the timed steps pass over the EDITED batches; `reused_chunk_bytes_frac` = share of
+    the edited corpus' bytes that fall in chunks whose digest already exists in the base snapshot."""
+    name = "rechunk"
+
+    def __init__(self, a, eng, rank, world):
+        super().__init__(a, eng, rank, world)
+        fbytes = int(a.file_mib * MiB) & ~7
+        share_gib = 128.0 if a.gib is None else a.gib
+        nseg = max(1, int(share_gib * GiB) // fbytes)
+        slots = 4 if a.slots is None else a.slots
+        per = -(-nseg // slots)
+        rng = np.random.default_rng(a.seed + 5 + 977 * rank)
+        base = alloc_batches(eng, per * fbytes, 1)[0]     # one base batch at a time: build, chunk, derive the edit
+        newbuf = alloc_batches(eng, max(8, int(per * fbytes * 0.03)) + (8 << 20), 1)[0]
+        self.base_digests = []
+        self.base_bytes = 0
+        for i in range(slots):
+            n = min(per, nseg - i * per)
+            if n <= 0:
+                break
+            bsegs = np.zeros((n, 2), dtype=np.uint64)
+            fills = []
+            for f in range(n):
+                g = (rank * slots + i) * per + f
+                seed = a.seed + 15485863 * g + 9
+                eng.fill(base.ptr + f * fbytes, fbytes, seed=seed, kind=0)
+                bsegs[f] = (f * fbytes, fbytes)
+                fills.append((seed, fbytes))
+            brecs = eng.chunk_and_digest(base, bsegs, nbytes=n * fbytes)
+            self.base_digests.append(brecs["digest"].copy())
+            self.base_bytes += n * fbytes
+            # edited batch: piece table -> device gather; new bytes come from a random pool
+            eng.fill(newbuf.ptr, newbuf.nbytes & ~7, seed=a.seed + 31 * (rank * slots + i) + 77, kind=0)
+            items, esegs, plan, pos, npos = [], np.zeros((n, 2), dtype=np.uint64), [], 0, 0
+            for f in range(n):
+                start = pos
+                pieces = edit_plan(fbytes, rng)
+                for kind, so, ln in pieces:
+                    if kind == 0:
+                        items.append((0, f * fbytes + so, pos, ln))
+                    else:
+                        items.append((1, npos, pos, ln))
+                        npos += ln
+                    pos += ln
+                esegs[f] = (start, pos - start)
+                plan.append(pieces)
+            assert npos <= newbuf.nbytes, (npos, newbuf.nbytes)
+            ebuf = alloc_batches(eng, pos + 64, 1)[0]
+            it = np.array(items, dtype=np.uint64).reshape(-1, 4)
+            for kind, src in ((0, base), (1, newbuf)):
+                sel = it[it[:, 0] == kind][:, 1:]
+                if len(sel):
+                    eng.gather(src, ebuf, sel)
+            bt = Batch(ebuf, pos, esegs, None, f"edited{i}")
+            bt.plan, bt.base_fills, bt.new_seed = plan, fills, a.seed + 31 * (rank * slots + i) + 77
+            self.batches.append(bt)
+        base.free()
+        newbuf.free()
+        self.nseg, self.fbytes = nseg, fbytes
+        self.base_set = None
+
+    def describe(self):
+        return {"workload": f"{self.nseg} x {self.fbytes / MiB:g} MiB segments per GPU after byte edits totalling 2 % "
+                            f"(log-uniform 4 KiB-4 MiB extents, 1/3 overwrite / insert / delete), re-chunked "
+                            f"(BASELINE.json configs[4])", "segments_per_gpu": int(self.nseg)}
+
+    def finish(self, ctx):
+        if self.base_set is None:
+            d = np.concatenate(self.base_digests)
+            self.base_set = set(map(bytes, d))
+        reused = total = 0
+        for b in self.batches:
+            if b.last is None:
+                continue
+            hit = np.fromiter((bytes(x) in self.base_set for x in b.last["digest"]), dtype=bool, count=b.last.size)
+            reused += int(b.last["size"][hit].sum())
+            total += int(b.last["size"].sum())
+        if total:
+            self.extra["reused_chunk_bytes_frac"] = round(reused / total, 4)
+            self.extra["edited_bytes"] = total
+
+    def cpu_sample(self):
+        """Rebuild a few edited segments on the host from their piece tables and run the oracle on them."""
+        from oracle import oracle as O
+        b = self.batches[0]
+        k = max(1, min(b.nseg, int(self.a.cpu_sample_gib * GiB / self.fbytes)))
+        newpool_needed = 0
+        for f in range(b.nseg):       # offsets into the new-bytes pool are cumulative over the whole batch
+            for kind, so, ln in b.plan[f]:
+                if kind == 1:
+                    newpool_needed += ln
+            if f + 1 == k:
+                break
+        pool = O.fill((newpool_needed + 7) & ~7, b.new_seed, 0)
+        parts, segs, off, npos = [], [], 0, 0
+        for f in range(k):
+            seed, n = b.base_fills[f]
+            base = O.fill(n, seed, 0)
+            seg = []
+            for kind, so, ln in b.plan[f]:
+                if kind == 0:
+                    seg.append(base[so:so + ln])
+                else:
+                    seg.append(pool[npos:npos + ln])
+                    npos += ln
+            s = np.concatenate(seg)
+            parts.append(s)
+            segs.append((off, s.size))
+            off += s.size
+        gpu = None
+        if b.last is not None:
+            gpu = b.last[b.last["segment"] < k].copy()
+        return np.concatenate(parts), segs, gpu, "segments"
+
+
+WORKLOADS = {"stream64g": Stream64g, "manyfiles": ManyFiles, "corpus_dup": CorpusDup, "rechunk": Rechunk}
+
+
+class Ctx:
+    dist = None
+    comm_dev = None
+    rec_cap = 0
 
 
 def main():
@@ -60,208 +483,273 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    ctx = Ctx()
+    backend = os.environ.get("PBS_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; gloo only for CPU tests / 1-GPU debugging
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("PBS_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; gloo only for 1-GPU debugging
+        ngpu0 = torch.cuda.device_count()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            torch.cuda.set_device(local_rank % max(ngpu0, 1))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank % max(ngpu0, 1)}"))
         else:
             dist.init_process_group(backend)
+        ctx.dist = dist
     ngpu = torch.cuda.device_count()
-    if world > 1 and os.environ.get("PBS_BENCH_BACKEND", "nccl") != "nccl":
+    if world > 1 and backend != "nccl":
         local_rank = local_rank % max(ngpu, 1)  # debug: several ranks share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    comm_dev = dev if os.environ.get("PBS_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    ctx.comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    from pbs_plus_amd import Engine, buzhash
-    from pbs_plus_amd.dist import global_dedup
+    if a.workload == "hostfeed":
+        return hostfeed_main(a, rank, local_rank, world, ctx)
+    if a.workload == "verify":
+        return verify_main(a, rank, local_rank, world, ctx)
 
-    nbytes = int(a.gib * GiB) & ~7
+    import pbs_plus_amd
+    from pbs_plus_amd import buzhash
+
     cfg = buzhash.NewConfig(a.avg)
-    inflight = max(1, min(a.inflight, 16))
-    eng = Engine(cfg, device=local_rank, inflight=max(inflight, 1))
-    data = torch.empty(nbytes, dtype=torch.uint8, device=dev)   # the corpus: resident in HBM
-    eng.fill(data.data_ptr(), nbytes, seed=a.seed + rank, kind=0)
+    want_slots = {"stream64g": 4, "manyfiles": 2, "corpus_dup": 2, "rechunk": 4}[a.workload]
+    nslots = max(1, a.reread) if a.reread else (want_slots if a.slots is None else a.slots)
+    eng = pbs_plus_amd.Engine(cfg, device=local_rank, inflight=min(16, max(nslots, 1)))
+    w = WORKLOADS[a.workload](a, eng, rank, world)
     torch.cuda.synchronize()
+    batches = w.batches
+    ctx.rec_cap = max(b.nbytes // max(cfg.MinSize, 65) + 2 * b.nseg + 16 for b in batches)
+    if ctx.dist is not None:       # the one-collective all-gather needs a record capacity every rank agrees on
+        rc = torch.tensor([ctx.rec_cap], dtype=torch.int64, device=ctx.comm_dev)
+        ctx.dist.all_reduce(rc, op=ctx.dist.ReduceOp.MAX)
+        ctx.rec_cap = int(rc.item())
+    inflight = max(1, a.reread) if a.reread else len(batches)
 
-    def next_to_collect(pending):
-        if a.collect == "fifo" or len(pending) == 1:
-            return 0
-        while True:  # whichever ticket has finished on the device; records are per step, their order is irrelevant
-            for i, t in enumerate(pending):
-                if eng.done(t):
-                    return i
-            time.sleep(0.0005)
+    def collect(b, t, timings):
+        if timings is not None:
+            timings.append(eng.timing(t))
+        recs = eng.collect(t)
+        b.last = recs
+        w.after_collect(b, recs, ctx)
+        return recs
+
+    # with several ranks every rank must issue its collectives in the same sequence: first-in-first-out there
+    collect_any = a.collect == "any" and ctx.dist is None
 
     def run_steps(k, timings=None):
-        """k passes; with inflight > 1 consecutive passes overlap on separate HIP streams."""
-        pending = []
-        nrec, recs = 0, None
+        """k passes; passes overlap on separate HIP streams, one resident batch per slot. A batch is resubmitted
+        only after its previous pass has been collected (its buffer is "refilled")."""
+        pending = []                 # (batch, ticket) in submission order
+        idle = list(batches)         # batches not in flight
+        nbytes_done = 0
+
+        def pop_one():
+            i = 0
+            if collect_any and len(pending) > 1:
+                while True:          # whichever pass has finished on the device
+                    done = [j for j, (_, t) in enumerate(pending) if eng.done(t)]
+                    if done:
+                        i = done[0]
+                        break
+                    time.sleep(0.0003)
+            pb, t = pending.pop(i)
+            collect(pb, t, timings)
+            return pb
+
         for _ in range(k):
-            if len(pending) == inflight:
-                t = pending.pop(next_to_collect(pending))
-                if timings is not None:
-                    timings.append(eng.timing(t))
-                recs = eng.collect(t)
-                nrec = recs.size
-                if dist is not None:
-                    global_dedup(eng, recs, device=comm_dev)
-            pending.append(eng.submit(data, None, nbytes))
-        for t in pending:
-            if timings is not None:
-                timings.append(eng.timing(t))
-            recs = eng.collect(t)
-            nrec = recs.size
-            if dist is not None:
-                global_dedup(eng, recs, device=comm_dev)
-        return nrec, recs
+            if a.reread:
+                if len(pending) == inflight:
+                    pop_one()
+                b = batches[0]
+            else:
+                b = idle.pop(0) if idle else pop_one()
+            pending.append((b, eng.submit(b.buf, b.segs, b.nbytes)))
+            nbytes_done += b.nbytes
+        while pending:
+            pb = pop_one()
+            if not a.reread:
+                idle.append(pb)
+        return nbytes_done
 
     run_steps(a.warmup)
-    if dist is not None:
-        dist.barrier()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
     torch.cuda.synchronize()
     timings = []
     t0 = time.perf_counter()
-    nrec, recs = run_steps(a.steps, timings)
+    my_bytes = run_steps(a.steps, timings)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    total_bytes = float(my_bytes)
+    if ctx.dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.comm_dev)
+        ctx.dist.all_reduce(tt, op=ctx.dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        tb = torch.tensor([total_bytes], dtype=torch.float64, device=ctx.comm_dev)
+        ctx.dist.all_reduce(tb, op=ctx.dist.ReduceOp.SUM)
+        total_bytes = float(tb.item())
+    w.finish(ctx)
 
-    # one strictly serial step for reference (uncontended kernel times), outside the timed region
+    # one strictly serial pass (uncontended kernel times, single-batch latency), outside the timed region
     torch.cuda.synchronize()
+    b0 = batches[0]
     ts0 = time.perf_counter()
-    tk = eng.submit(data, None, nbytes)
+    tk = eng.submit(b0.buf, b0.segs, b0.nbytes)
     serial_timing = eng.timing(tk)
-    eng.collect(tk)
+    b0.last = eng.collect(tk)
     serial_s = time.perf_counter() - ts0
 
-    # HBM traffic per launch: measured read/algorithmic ratios from the committed PMC passes
-    traffic = {"sha": None, "scan": None, "note": None}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            tj = json.load(f)
-        traffic["sha"] = int(tj["kernels"]["k_sha256_pair<RecordSource>"]["read_ratio_vs_algorithmic"] * nbytes)
-        traffic["scan"] = int(tj["kernels"]["k_scan3<34,4>"]["read_ratio_vs_algorithmic"] * nbytes)
-        traffic["note"] = "HBM read bytes per launch = measured FETCH_SIZE ratio (x2 gfx950 correction) x bytes; " \
-                          "PMC passes in profiles/r01_pmc_fetch_size_bench8g.csv, r01_pmc_fetch_size_scan3_bench8g.csv"
-    except Exception:
-        pass
-
     if rank == 0:
-        total_bytes = float(nbytes) * world * a.steps
-        value = total_bytes / GiB / elapsed
-        sha_ms = float(np.mean([t["sha_ms"] for t in timings]))
-        scan_ms = float(np.mean([t["scan_ms"] for t in timings]))
-        resolve_ms = float(np.mean([t["resolve_ms"] for t in timings]))
-        sha_gbs = nbytes / (sha_ms * 1e-3) / 1e9
-        scan_gbs = nbytes / (scan_ms * 1e-3) / 1e9
-        out = {
-            "metric": "GiB/s ingested through CDC+SHA-256",
-            "value": round(value, 2),
-            "unit": "GiB/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic (splitmix64 random bytes generated on device, resident in HBM)",
-            "config": {
-                "workload": f"single {a.gib:g} GiB stream per GPU, Buzhash CDC avg 4 MiB (min 1 MiB, max 16 MiB) "
-                            f"+ SHA-256 per chunk (BASELINE.json configs[1])",
-                "bytes_per_gpu": nbytes, "avg_chunk": a.avg, "chunks_per_gpu": int(nrec),
-                "inflight_batches": inflight, "collect": a.collect,
-                "parallelism": f"segments sharded, {world} rank(s), digest-set all-gather" if world > 1 else "1 GPU",
-            },
-            "roofline": {
-                "kernel": "k_sha256_pair<RecordSource> (dominant: %.0f%% of device time)" % (
-                    100.0 * sha_ms / max(sha_ms + scan_ms + resolve_ms, 1e-9)),
-                "bound": "hbm",
-                "achieved": round(sha_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(sha_gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic["sha"],
-                "traffic_note": traffic["note"],
-                "note": "SHA-256 never touches the HBM roofline: ~%.0f integer VALU ops/B cap the chip at %.0f GB/s "
-                        "(valu_frac = achieved/that), and one launch cannot finish before the serial chain of its "
-                        "longest chunk (chain_frac = chain_floor_ms / kernel_ms)" % (
-                            SHA_OPS_PER_BYTE, VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE),
-                "valu_frac": round(sha_gbs / (VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE), 4),
-                "algorithmic_bytes_per_launch": nbytes,
-                "kernel_ms": round(sha_ms, 3),
-                "scan_kernel": {"kernel": "k_scan3<34,4>", "bound": "hbm", "achieved": round(scan_gbs, 1),
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
-                                "kernel_ms": round(scan_ms, 3), "traffic": traffic["scan"]},
-                "resolve_ms": round(resolve_ms, 3),
-                "overlap_note": "kernel_ms/achieved/frac above are per launch, measured with HIP events while %d "
-                                "launches overlap on the chip (a launch then also waits for CUs); 'uncontended' repeats "
-                                "them for one strictly serial step, 'aggregate' is all ranks' input bytes of the timed "
-                                "region / wall time against the HBM peak of the GPUs used" % inflight,
-                "uncontended": {
-                    "sha256": {"kernel_ms": round(serial_timing["sha_ms"], 3),
-                               "achieved": round(nbytes / (serial_timing["sha_ms"] * 1e-3) / 1e9, 1),
-                               "frac": round(nbytes / (serial_timing["sha_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                    "scan": {"kernel_ms": round(serial_timing["scan_ms"], 3),
-                             "achieved": round(nbytes / (serial_timing["scan_ms"] * 1e-3) / 1e9, 1),
-                             "frac": round(nbytes / (serial_timing["scan_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
-                "aggregate": {"achieved": round(total_bytes / elapsed / 1e9, 1), "unit": "GB/s",
-                              "frac": round(total_bytes / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4)},
-                "chain_floor_ms": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3, 1),
-                "chain_frac": round(int(max(recs["size"])) / 64 * CHAIN_US_PER_BLOCK * 1e-3 / sha_ms, 3),
-                "chain_note": "SHA-256 is sequential inside a chunk: the launch cannot finish before its longest chunk "
-                              "(max 16 MiB = 262144 compressions x >=1.6 us at one wave64 integer op per ~4.2 cycles)",
-            },
-            "serial_value": round(nbytes / GiB / serial_s, 2),
-            "serial_step_ms": {"total": round(serial_s * 1e3, 2), "scan": round(serial_timing["scan_ms"], 3),
-                               "resolve": round(serial_timing["resolve_ms"], 3),
-                               "sha256": round(serial_timing["sha_ms"], 3)},
-        }
+        out = assemble(a, w, cfg, world, inflight, elapsed, total_bytes, timings, serial_timing, serial_s)
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a, recs)
+            out["cpu_baseline"] = cpu_baseline(a, w)
         print(json.dumps(out), flush=True)
-
+    w.free()
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
 
 
-def cpu_baseline(a, gpu_recs):
-    """The oracle (C restatement; SHA-NI like Go's crypto/sha256) on ONE host thread — the
-    reference's writer is a single goroutine (internal/tapeio/converter.go:672-680) — over a
-    bounded prefix of the same stream. Also cross-checks the GPU records on that prefix."""
+def load_traffic():
+    """HBM bytes per launch / algorithmic bytes, from the committed PMC passes (FETCH_SIZE, gfx950 x2 correction)."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tj = json.load(f)
+            k = tj["kernels"]
+            return {"sha": float(k["k_sha256_pair<RecordSource>"]["read_ratio_vs_algorithmic"]),
+                    "scan": float(k["k_scan3<34,4>"]["read_ratio_vs_algorithmic"]), "file": "profiles/" + name}
+        except Exception:
+            continue
+    return None
+
+
+def assemble(a, w, cfg, world, inflight, elapsed, total_bytes, timings, serial_timing, serial_s):
+    b0 = w.batches[0]
+    nb0 = b0.nbytes
+    value = total_bytes / GiB / elapsed
+    agg_gbs = total_bytes / elapsed / 1e9
+    sha_ms = float(np.mean([t["sha_ms"] for t in timings]))
+    scan_ms = float(np.mean([t["scan_ms"] for t in timings]))
+    resolve_ms = float(np.mean([t["resolve_ms"] for t in timings]))
+    mean_bytes = total_bytes / world / max(len(timings), 1)
+    tr = load_traffic()
+    longest = int(max(int(b.last["size"].max()) for b in w.batches if b.last is not None and b.last.size))
+    chain_ms = longest / 64 * CHAIN_US_PER_BLOCK * 1e-3
+    resident = float(sum(b.nbytes for b in w.batches))
+    lat_s = (serial_timing["total_ms"] * 1e-3) or serial_s
+    cfgd = {"bytes_per_batch": nb0, "resident_batches": len(w.batches), "resident_bytes_per_gpu": int(resident),
+            "avg_chunk": a.avg, "chunks_per_batch": int(b0.last.size), "inflight_batches": inflight, "collect": a.collect,
+            "distinct_data_per_slot": not a.reread,
+            "parallelism": f"{world} rank(s), one per GPU, batches independent, digest-set all-gather" if world > 1 else "1 GPU"}
+    cfgd.update(w.describe())
+    if a.reread:
+        cfgd["workload"] += f" — REREAD protocol: {a.reread} overlapping passes over the same resident batch"
+    out = {
+        "metric": "GiB/s ingested through CDC+SHA-256",
+        "value": round(value, 2),
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": w.scaling,
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic (splitmix64 bytes generated on device, resident in HBM; every in-flight slot owns different bytes)",
+        "config": cfgd,
+        "roofline": {
+            # path level: all input bytes of the timed region / wall time. What bounds it is integer VALU issue
+            # (SHA-256, ~22 ops/B; the scan adds 3.5 ops/B), never HBM — and, below that ceiling, the serial chain of
+            # the longest chunk times the bytes HBM can hold (latency_bound)
+            "kernel": "whole path (k_scan3 + resolve + k_sha256_pair); dominant kernel k_sha256_pair<RecordSource>: "
+                      "%.0f%% of device time" % (100.0 * sha_ms / max(sha_ms + scan_ms + resolve_ms, 1e-9)),
+            "bound": "valu",
+            "achieved": round(agg_gbs / world, 1),
+            "peak": round(SHA_VALU_GBS, 1),
+            "unit": "GB/s",
+            "frac": round(agg_gbs / world / round(SHA_VALU_GBS, 1), 4),
+            "peak_note": "%.1f T integer lane-ops/s (620 G wave64 VOP3 instr/s measured, profiles/r01_ubench_int_valu_issue.log) "
+                         "/ %.1f ops per byte of SHA-256" % (VALU_PEAK_TOPS, SHA_OPS_PER_BYTE),
+            "hbm": {"peak": HBM_PEAK_GBS, "frac": round(agg_gbs / world / HBM_PEAK_GBS, 4),
+                    "note": "same achieved figure against the HBM3E peak (BASELINE.json quotes % of HBM roofline); the path "
+                            "reads every byte twice (scan, SHA-256): real traffic = 2 x achieved"},
+            "traffic": None if tr is None else int((tr["sha"] + tr["scan"]) * mean_bytes),
+            "traffic_note": None if tr is None else
+                "HBM read bytes per step = (scan %.2fx + SHA %.2fx) x algorithmic bytes, FETCH_SIZE PMC passes (%s)" % (
+                    tr["scan"], tr["sha"], tr["file"]),
+            "algorithmic_bytes_per_step": int(mean_bytes),
+            "latency_bound": {
+                "longest_chunk": longest, "chain_ms": round(chain_ms, 1),
+                "serial_pass_ms": round(lat_s * 1e3, 1),
+                "resident_bytes": int(resident),
+                "bound_GiBps": round(resident / GiB / max(lat_s, 1e-9), 1),
+                "frac_of_bound": round(value / world / max(resident / GiB / max(lat_s, 1e-9), 1e-9), 3),
+                "note": "SHA-256 is serial inside a chunk (max-size chunk = %d compressions x %.3f us): a batch cannot "
+                        "complete sooner than serial_pass_ms, and its bytes stay resident that long, so with distinct data "
+                        "per slot throughput <= resident bytes / pass latency (Little's law; 288 GB / 0.43 s = 670 GB/s "
+                        "even with all of HBM in flight)" % (longest // 64, CHAIN_US_PER_BLOCK)},
+            "kernels": {
+                "k_sha256_pair<RecordSource>": {
+                    "bound": "valu (serial chain per chunk)", "kernel_ms": round(sha_ms, 3),
+                    "achieved": round(mean_bytes / (sha_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                    "valu_frac": round(mean_bytes / (sha_ms * 1e-3) / 1e9 / SHA_VALU_GBS, 4),
+                    "hbm_frac": round(mean_bytes / (sha_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "uncontended_ms": round(serial_timing["sha_ms"], 3),
+                    "chain_frac": round(chain_ms / max(serial_timing["sha_ms"], 1e-9), 3),
+                    "traffic": None if tr is None else int(tr["sha"] * mean_bytes)},
+                "k_scan3<34,4>": {
+                    "bound": "hbm", "kernel_ms": round(scan_ms, 3),
+                    "achieved": round(mean_bytes / (scan_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(mean_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "uncontended_ms": round(serial_timing["scan_ms"], 3),
+                    "uncontended_frac": round(nb0 / (serial_timing["scan_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": None if tr is None else int(tr["scan"] * mean_bytes)},
+                "resolve_chain": {"kernel_ms": round(resolve_ms, 3), "uncontended_ms": round(serial_timing["resolve_ms"], 3)},
+                "note": "kernel_ms = mean per launch over the timed region, HIP events on the engine's own streams while %d "
+                        "passes overlap (a launch then also waits for CUs); uncontended_ms = one strictly serial pass" % inflight,
+            },
+        },
+        "serial_value": round(nb0 / GiB / serial_s, 2),
+        "serial_step_ms": {"total": round(serial_s * 1e3, 2), "scan": round(serial_timing["scan_ms"], 3),
+                           "resolve": round(serial_timing["resolve_ms"], 3), "sha256": round(serial_timing["sha_ms"], 3)},
+    }
+    if w.extra:
+        out["results"] = w.extra
+    return out
+
+
+def cpu_baseline(a, w):
+    """The oracle (C restatement; SHA-NI like Go's crypto/sha256) on ONE host thread — the reference's writer is a
+    single goroutine (internal/tapeio/converter.go:672-680) — over a bounded sample of the same workload. The same
+    sample re-checks the GPU's records bit for bit (prefix causality for a stream, whole segments otherwise)."""
     from oracle import oracle as O
 
     O.build()
-    n = int(min(a.cpu_sample_gib, a.gib) * GiB) & ~7
-    host = O.fill(n, a.seed, 0)
+    host, segs, gpu, how = w.cpu_sample()
     cfg = O.new_config(a.avg)
     t0 = time.perf_counter()
-    recs = O.chunk_and_digest(cfg, host, [(0, n)], impl=1)
+    recs = O.chunk_and_digest(cfg, host, segs, impl=1)
     dt = time.perf_counter() - t0
-    # causality: cuts before the prefix end depend only on the prefix -> all but the tail must match
-    k = recs.size - 1
-    same = bool(k > 0 and gpu_recs.size >= k and np.array_equal(recs["end"][:k], gpu_recs["end"][:k])
-                and np.array_equal(recs["digest"][:k], gpu_recs["digest"][:k]))
-    # informational: the same port on many host cores at once (one independent 256 MiB stream per thread;
-    # ctypes releases the GIL). The single-thread figure above stays the baseline: the reference's writer is
-    # one goroutine.
+    n = int(sum(s[1] for s in segs))
+    same, k = False, 0
+    if gpu is not None:
+        if how == "prefix":      # cuts before the prefix end depend only on the prefix -> all but the tail must match
+            k = recs.size - 1
+            same = bool(k > 0 and gpu.size >= k and np.array_equal(recs["end"][:k], gpu["end"][:k])
+                        and np.array_equal(recs["digest"][:k], gpu["digest"][:k]))
+        else:
+            k = recs.size
+            same = bool(gpu.size == k and np.array_equal(recs["end"], gpu["end"]) and np.array_equal(recs["digest"], gpu["digest"])
+                        and np.array_equal(recs["segment"], gpu["segment"]))
     many = None
-    try:
-        import threading
+    try:   # informational: the same port on many host cores at once (independent 256 MiB streams; ctypes drops the GIL)
         nthreads = max(1, min(64, (os.cpu_count() or 1)))
-        per = 256 << 20
-        bufs = [O.fill(per, a.seed + 100 + i, 0) for i in range(min(nthreads, 8))]  # 8 distinct buffers, reused
+        per = min(256 << 20, max(1 << 20, int(a.cpu_sample_gib * GiB) // 8))
+        bufs = [O.fill(per, a.seed + 100 + i, 0) for i in range(min(nthreads, 8))]
+
         def work(i):
             O.chunk_and_digest(cfg, bufs[i % len(bufs)], [(0, per)], impl=1)
         ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
@@ -272,17 +760,187 @@ def cpu_baseline(a, gpu_recs):
             t.join()
         dtm = time.perf_counter() - t1
         many = {"value": round(nthreads * per / GiB / dtm, 2), "unit": "GiB/s", "cores": nthreads,
-                "sample": f"{nthreads} threads x 256 MiB independent streams"}
+                "sample": f"{nthreads} threads x {per >> 20} MiB independent random streams"}
     except Exception as exc:  # pragma: no cover
         many = {"error": repr(exc)}
     return {
         "many_core": many,
-        "value": round(n / GiB / dt, 4), "unit": "GiB/s", "cores": 1,
-        "kind": "port",
-        "sample": f"first {n / GiB:g} GiB of the same stream, oracle chunk_and_digest (byte-serial Buzhash + SHA-NI), "
-                  f"{os.cpu_count()} host cores present",
-        "prefix_records_match_gpu": same, "prefix_records": int(k),
+        "value": round(n / GiB / dt, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+        "sample": f"{n / GiB:.3g} GiB of the same workload ({how}: {len(segs)} segment(s)), oracle chunk_and_digest "
+                  f"(byte-serial Buzhash + SHA-NI), {os.cpu_count()} host cores present",
+        "records_match_gpu": same, "records_checked": int(k),
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+# host-fed ingest: what the cgo drop-in actually sees (io.Reader bytes arrive in host memory)
+# ---------------------------------------------------------------------------------------------------
+def hostfeed_main(a, rank, local_rank, world, ctx):
+    import pbs_plus_amd
+    from pbs_plus_amd import buzhash
+
+    cfg = buzhash.NewConfig(a.avg)
+    eng = pbs_plus_amd.Engine(cfg, device=local_rank, inflight=2)
+    P = max(1, a.producers)
+    per_gib = 1.0 if a.gib is None else a.gib            # bytes each producer writes per step
+    per = int(per_gib * GiB) & ~7
+    from oracle import oracle as O                        # only to synthesise host bytes + the cpu_baseline leg
+    O.build()
+    src = [O.fill(min(per, 1 << 30), a.seed + 17 * (rank * P + i), 0) for i in range(P)]
+    wsize = 32 << 20
+    h2d = eng.h2d_bandwidth(1 << 30) if hasattr(eng, "h2d_bandwidth") else None
+
+    # one long-lived stream per producer (an archive being written): its device window ring and pinned staging are
+    # allocated while it warms up, the timed phase is steady-state ingest and ends with finish() (all records delivered)
+    warm_steps = max(1, a.warmup // 2)
+    gate = threading.Barrier(P + 1)
+    out = [None] * P
+    errs = []
+
+    def producer(i):
+        try:
+            st = pbs_plus_amd.PayloadStream(eng, 256 << 20)
+            nrec = 0
+
+            def feed(steps):
+                nonlocal nrec
+                for _ in range(steps):
+                    off = 0
+                    while off < per:
+                        o = off % src[i].size
+                        n = min(wsize, per - off, src[i].size - o)
+                        st.write(src[i][o:o + n])
+                        off += n
+                        if (off // wsize) % 8 == 0:
+                            nrec += st.poll(4096).size
+            feed(warm_steps)
+            gate.wait()          # warm-up written
+            gate.wait()          # timed phase starts
+            b0 = st.bytes_written()
+            feed(a.steps)
+            st.finish()
+            nrec += st.poll().size
+            out[i] = (nrec, st.bytes_written() - b0)
+            st.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(repr(exc))
+            gate.abort()
+
+    ths = [threading.Thread(target=producer, args=(i,)) for i in range(P)]
+    for t in ths:
+        t.start()
+    gate.wait()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gate.wait()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if errs:
+        raise SystemExit("hostfeed producer failed: " + "; ".join(errs))
+    total = float(sum(o[1] for o in out))
+    if ctx.dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.comm_dev)
+        ctx.dist.all_reduce(tt, op=ctx.dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([total], dtype=torch.float64, device=ctx.comm_dev)
+        ctx.dist.all_reduce(tb, op=ctx.dist.ReduceOp.SUM)
+        total = float(tb.item())
+    # parity spot check: one producer's stream cut again through the batch path must give the same records
+    chk = pbs_plus_amd.PayloadStream(eng, 64 << 20)
+    n_chk = min(src[0].size, 256 << 20)
+    chk.write(src[0][:n_chk])
+    chk.finish()
+    srecs = chk.poll()
+    chk.close()
+    orecs = O.chunk_and_digest(O.new_config(a.avg), src[0][:n_chk], [(0, n_chk)], impl=1)
+    same = bool(srecs.size == orecs.size and np.array_equal(srecs["end"], orecs["end"])
+                and np.array_equal(srecs["digest"], orecs["digest"]))
+    if rank == 0:
+        gbs = total / elapsed / 1e9
+        outj = {
+            "metric": "GiB/s ingested through CDC+SHA-256 (host-fed, PCIe-inclusive)",
+            "value": round(total / GiB / elapsed, 2), "unit": "GiB/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic random bytes in HOST memory, written through pbsgpu_stream_write (pinned staging -> H2D)",
+            "config": {"workload": f"host-fed payload streams: {P} producer threads x {per_gib:g} GiB per step, "
+                                   f"32 MiB writes, 256 MiB device windows (the WriteEntryReader seam)",
+                       "producers": P, "avg_chunk": a.avg, "records": int(sum(o[0] for o in out))},
+            "roofline": {"kernel": "H2D copy engine (PCIe Gen5 x16)", "bound": "pcie", "achieved": round(gbs / world, 1),
+                         "peak": 63.0, "unit": "GB/s", "frac": round(gbs / world / 63.0, 4), "traffic": None,
+                         "measured_h2d_GBps": h2d,
+                         "frac_of_measured_h2d": None if not h2d else round(gbs / world / h2d, 3)},
+            "stream_records_match_oracle": same,
+        }
+        print(json.dumps(outj), flush=True)
+    eng.close()
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------
+# verification batches (A8 / A9): whole-file SHA-256 and XXH3-64
+# ---------------------------------------------------------------------------------------------------
+def verify_main(a, rank, local_rank, world, ctx):
+    import hashlib
+
+    import pbs_plus_amd
+    from pbs_plus_amd import buzhash
+
+    eng = pbs_plus_amd.Engine(buzhash.NewConfig(a.avg), device=local_rank, inflight=2)
+    fbytes = int(a.file_mib * MiB) & ~7
+    gib = 16.0 if a.gib is None else a.gib
+    nfiles = max(1, int(gib * GiB) // fbytes)
+    buf = eng.alloc(nfiles * fbytes)
+    eng.fill(buf.ptr, nfiles * fbytes, seed=a.seed + rank, kind=0)
+    segs = np.array([(i * fbytes, fbytes) for i in range(nfiles)], dtype=np.uint64)
+    res = {}
+    for name, fn in (("sha256", eng.sha256_many), ("xxh3", eng.xxh3_many)):
+        fn(buf, segs[: max(1, nfiles // 8)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            outv = fn(buf, segs)
+        dt = (time.perf_counter() - t0) / a.steps
+        res[name] = {"GiBps": round(nfiles * fbytes / GiB / dt, 2), "ms": round(dt * 1e3, 2), "files": nfiles}
+        res[name + "_out0"] = bytes(outv[0]).hex() if name == "sha256" else int(outv[0])
+    # the reference keeps 4 files in flight (internal/server/verification/job.go:493): 4 large files
+    big = min(nfiles * fbytes // 4, 1 << 30) & ~7
+    segs4 = np.array([(i * big, big) for i in range(4)], dtype=np.uint64)
+    for name, fn in (("sha256_4x", eng.sha256_many), ("xxh3_4x", eng.xxh3_many)):
+        t0 = time.perf_counter()
+        fn(buf, segs4)
+        dt = time.perf_counter() - t0
+        res[name] = {"GiBps": round(4 * big / GiB / dt, 3), "ms": round(dt * 1e3, 1), "file_bytes": big}
+    # CPU side: hashlib (OpenSSL, SHA-NI) on one core, and the check of file 0
+    host = buf.download(0, fbytes)
+    t0 = time.perf_counter()
+    want = hashlib.sha256(host.tobytes()).hexdigest()
+    cpu_dt = time.perf_counter() - t0
+    res["sha256_file0_matches_hashlib"] = (want == res["sha256_out0"])
+    if rank == 0:
+        outj = {"metric": "GiB/s whole-file SHA-256 (verification.HashFile batches)", "value": res["sha256"]["GiBps"],
+                "unit": "GiB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": res["sha256"]["ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u32", "data": "synthetic random files resident in HBM",
+                "config": {"workload": f"{nfiles} files x {fbytes / MiB:g} MiB hashed whole (A8/A9), plus 4 files x {big / MiB:g} MiB"},
+                "roofline": {"kernel": "k_sha256_pair<SegmentSource>", "bound": "valu",
+                             "achieved": round(res["sha256"]["GiBps"] * 1.073741824, 1), "peak": round(SHA_VALU_GBS, 1),
+                             "unit": "GB/s", "frac": round(res["sha256"]["GiBps"] * 1.073741824 / SHA_VALU_GBS, 4), "traffic": None},
+                "cpu_baseline": {"value": round(fbytes / GiB / cpu_dt, 3), "unit": "GiB/s", "cores": 1, "kind": "port",
+                                 "sample": f"hashlib.sha256 (OpenSSL SHA-NI) of one {fbytes / MiB:g} MiB file"},
+                "results": res}
+        print(json.dumps(outj), flush=True)
+    buf.free()
+    eng.close()
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -12,9 +12,13 @@
  * Conventions: plain pointers and sizes only; every function returns an int
  * status (PBSGPU_OK == 0, negative = error, text via pbsgpu_strerror); opaque
  * handles; no thread-local state — a handle may be used from any OS thread
- * (cgo calls arrive on arbitrary threads) but calls on ONE handle must be
- * serialised by the caller, like a Go writer owned by one goroutine
- * (internal/tapeio/converter.go:672-680). Host memory passed in is never
+ * (cgo calls arrive on arbitrary threads). An ENGINE may be used from several
+ * threads at once (submit / collect / helper calls / any number of streams and
+ * chunkers created from it: the library never holds a lock across a device
+ * wait or a copy, and helper calls queue for a work context instead of failing);
+ * calls on ONE stream or chunker handle must be serialised by the caller, like
+ * a Go writer owned by one goroutine (internal/tapeio/converter.go:672-680).
+ * Streams and chunkers keep their engine alive: destroy order does not matter. Host memory passed in is never
  * retained after the call returns (cgo pointer rule): it is copied into
  * library-owned pinned staging first. Device pointers are borrowed until the
  * ticket they were submitted under has been collected.
@@ -32,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSGPU_ABI_VERSION 1
+#define PBSGPU_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------- */
 #define PBSGPU_OK 0
@@ -41,7 +45,7 @@ extern "C" {
 #define PBSGPU_E_HIP (-3)          /* a HIP call failed (see pbsgpu_last_hip_error) */
 #define PBSGPU_E_NOMEM (-4)        /* host or device allocation failed */
 #define PBSGPU_E_CAPACITY (-5)     /* caller's output buffer too small (needed size reported) */
-#define PBSGPU_E_BUSY (-6)         /* all in-flight slots used: collect a ticket first */
+#define PBSGPU_E_BUSY (-6)         /* pbsgpu_submit_*: all in-flight tickets used, collect one first (nothing else returns it) */
 #define PBSGPU_E_TICKET (-7)       /* unknown / already collected ticket */
 #define PBSGPU_E_DENSITY (-8)      /* candidate density exceeded every retry capacity */
 #define PBSGPU_E_STATE (-9)        /* call not valid in the handle's current state */
@@ -121,6 +125,20 @@ int pbsgpu_submit_device(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes,
                          const pbsgpu_segment *segs, uint32_t nseg, uint64_t *ticket);
 int pbsgpu_submit_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
                        const pbsgpu_segment *segs, uint32_t nseg, uint64_t *ticket);
+/* The same with SUGGESTED BOUNDARIES (the payload chunker of the Proxmox lineage: cut at a suggested offset — a file
+ * start in the .ppxar stream, internal/pxarmount/commit_types.go:24-32, commit_reuse.go:265 — when the open chunk
+ * would then be within [min, max]; otherwise keep scanning). suggested[suggested_index[s] .. suggested_index[s+1])
+ * are the ascending boundaries of segment s, relative to its start; suggested_index has nseg + 1 entries (2 when
+ * segs == NULL). Definition = the serial payload chunker fed byte by byte (oracle_payload_chunker_scan): after a
+ * cut at s the next cut is the EARLIER of the hash/max cut and the first suggested b with min <= b - s <= max;
+ * boundaries closer than min to s are dropped. Whether github.com/pbs-plus/pxar v0.34.0 cuts at suggested
+ * boundaries is open: the plain entry points above never do. */
+int pbsgpu_submit_device_suggested(pbsgpu_engine *eng, const void *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
+                                   uint32_t nseg, const uint64_t *suggested, const uint32_t *suggested_index,
+                                   uint64_t *ticket);
+int pbsgpu_submit_host_suggested(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes, const pbsgpu_segment *segs,
+                                 uint32_t nseg, const uint64_t *suggested, const uint32_t *suggested_index,
+                                 uint64_t *ticket);
 /* Block until the ticket's work is done; report its record count. */
 int pbsgpu_wait(pbsgpu_engine *eng, uint64_t ticket, uint64_t *nrecords);
 /* Non-blocking: *done = 1 when everything enqueued for the ticket has finished on the device (collect will not
@@ -195,7 +213,15 @@ int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes);
 int pbsgpu_stream_finish(pbsgpu_stream *s);
 /* Pop up to `cap` finished records (in stream order). */
 int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint64_t *n);
-int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *bytes_written);
+/* Encoder().PayloadPosition() (commit_reuse.go:265): bytes written PLUS bytes injected so far — the coordinate
+ * system of the records' `end` and of PAYLOAD_REF offsets (InjectChunks advances the position by the injected
+ * sizes: keepLast_chunk_test.go mock, enc.Advance(total)). */
+int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *position);
+/* Bytes handed to write/commit only (no injected bytes). */
+int pbsgpu_stream_bytes_written(const pbsgpu_stream *s, uint64_t *bytes_written);
+/* Suggest a chunk boundary at absolute payload position `offset` (same coordinates as pbsgpu_stream_position;
+ * typically the current position = "a file starts here"). Ascending; see pbsgpu_submit_device_suggested. */
+int pbsgpu_stream_suggest(pbsgpu_stream *s, uint64_t offset);
 
 /* ---- whole-stream SHA-256 batch ---------------------------------------------
  * verification.HashFile (internal/agent/verification/handler.go:36-68) and
@@ -291,6 +317,20 @@ int pbsgpu_reuse_should(const pbsgpu_record *idx, uint64_t n, uint64_t range_sta
  * and `dptr` must be 8-byte aligned. */
 int pbsgpu_fill_device(pbsgpu_engine *eng, void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed,
                        uint32_t kind);
+
+/* Piece-table copy inside device memory: dst[dst_off .. +len) = src[src_off .. +len) for every item (items may be
+ * given in any order; destination ranges must not overlap). Builds the edited corpus of BASELINE.json configs[4]
+ * (overwrite / insert / delete extents applied to a resident base corpus) without a host round trip. */
+typedef struct pbsgpu_copy_item {
+    uint64_t src_off;
+    uint64_t dst_off;
+    uint64_t len;
+} pbsgpu_copy_item;
+int pbsgpu_gather_device(pbsgpu_engine *eng, const void *src, uint64_t src_bytes, void *dst, uint64_t dst_bytes,
+                         const pbsgpu_copy_item *items, uint32_t nitems);
+
+/* Host -> device copy rate of this box through pinned memory, in GB/s (what bounds every host-fed entry point). */
+int pbsgpu_measure_h2d(pbsgpu_engine *eng, uint64_t nbytes, double *gb_per_s);
 
 /* Library-owned device buffers for callers without their own allocator. */
 int pbsgpu_device_alloc(pbsgpu_engine *eng, uint64_t nbytes, void **dptr);

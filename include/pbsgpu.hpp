@@ -251,11 +251,19 @@ class PayloadWriter {
         if (st != PBSGPU_OK) return errorf("inject chunks", st);
         return drain();
     }
-    // Encoder().PayloadPosition(): bytes of payload accepted so far (commit_reuse.go:265)
+    // Encoder().PayloadPosition() (commit_reuse.go:265): payload bytes written PLUS bytes injected so far — the
+    // coordinate system of PAYLOAD_REF offsets and of the records' End (InjectChunks advances the position:
+    // keepLast_chunk_test.go mock, enc.Advance(total))
     uint64_t PayloadPosition() const {
         uint64_t n = 0;
         pbsgpu_stream_position(s_, &n);
         return n;
+    }
+    // payload chunker: suggest a chunk boundary at the current position ("a file starts here"); taken when the open
+    // chunk is then within [min, max], see pbsgpu_submit_device_suggested
+    std::string SuggestBoundary() {
+        const int st = pbsgpu_stream_suggest(s_, PayloadPosition());
+        return st == PBSGPU_OK ? std::string() : errorf("suggest boundary", st);
     }
     std::string Finish() {
         const int st = pbsgpu_stream_finish(s_);

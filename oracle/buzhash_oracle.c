@@ -16,6 +16,7 @@
  */
 #include "oracle.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 static const uint32_t k_default_table[256] = {
@@ -162,6 +163,118 @@ size_t oracle_chunk_and_digest(const oracle_config *cfg, const uint8_t *base,
             n++;
             start = end;
         }
+    }
+    return n;
+}
+
+/* ---- payload chunker: suggested boundaries ------------------------------------------------------
+ * Restatement of the published Proxmox `PayloadChunker::scan` (pbs-datastore/src/chunker.rs; EXTERNAL, recalled
+ * — whether github.com/pbs-plus/pxar v0.34.0 ports it is open). The caller (upstream's
+ * ChunkStream) passes ctx.base = stream offset of the current chunk's first byte and ctx.total = bytes of the
+ * current chunk accumulated so far INCLUDING `data`. A suggested boundary b (absolute stream offset = the END
+ * of the chunk it would close) is taken when it falls inside the bytes seen so far and the resulting chunk size
+ * b - base lies in [min, max]; a boundary that would give a chunk < min is dropped, one in the past is dropped,
+ * one still in the future or too far (> max) leaves the decision to the hash scan. */
+void oracle_payload_chunker_init(oracle_payload_chunker *p, const oracle_config *cfg, const uint64_t *sugg, size_t nsugg) {
+    oracle_chunker_init(&p->c, cfg);
+    p->sugg = sugg;
+    p->nsugg = nsugg;
+    p->next = 0;
+    p->have_cur = 0;
+    p->cur = 0;
+}
+
+size_t oracle_payload_chunker_scan(oracle_payload_chunker *p, const uint8_t *data, size_t len, uint64_t base,
+                                   uint64_t total) {
+    const uint64_t pos = total - (uint64_t)len; /* bytes of the current chunk before `data` */
+    for (;;) {
+        if (p->have_cur) {
+            const uint64_t b = p->cur;
+            if (b < base + pos) { /* boundary in the past: ignore */
+                p->have_cur = 0;
+                continue;
+            }
+            if (b > base + total) /* boundary in the future: cannot decide yet */
+                return oracle_chunker_scan(&p->c, data, len);
+            const uint64_t chunk_size = b - base;
+            if (chunk_size < p->c.cfg.min) { /* chunk too small: ignore the boundary */
+                p->have_cur = 0;
+                continue;
+            }
+            if (chunk_size <= p->c.cfg.max) {
+                p->have_cur = 0;
+                const uint64_t n = chunk_size - pos; /* boundary relative to the start of `data` */
+                if (n == 0) return oracle_chunker_scan(&p->c, data, len); /* passed: previous scan did not know it yet */
+                p->c.h = 0; /* chunker.reset() */
+                p->c.chunk_size = 0;
+                p->c.window_size = 0;
+                return (size_t)n;
+            }
+            /* chunk too big: regular scan decides (the boundary stays pending) */
+            return oracle_chunker_scan(&p->c, data, len);
+        }
+        if (p->next < p->nsugg) { /* try_recv */
+            p->cur = p->sugg[p->next++];
+            p->have_cur = 1;
+        } else {
+            return oracle_chunker_scan(&p->c, data, len);
+        }
+    }
+}
+
+/* Cut one stream with suggested boundaries, handing the chunker `feed` bytes per scan call (0 = everything that
+ * is left, like upstream's whole-buffer test; 1 = byte-serial, the feed-independent limit the engine implements:
+ * an earlier hash cut wins over a later suggested boundary). */
+size_t oracle_chunk_stream_suggested(const oracle_config *cfg, const uint8_t *data, size_t len, const uint64_t *sugg,
+                                     size_t nsugg, size_t feed, uint64_t *ends, size_t cap) {
+    oracle_payload_chunker p;
+    oracle_payload_chunker_init(&p, cfg, sugg, nsugg);
+    size_t n = 0;
+    uint64_t base = 0, pos = 0;
+    while (pos < len) {
+        size_t take = (feed == 0 || feed > len - pos) ? (size_t)(len - pos) : feed;
+        size_t k = oracle_payload_chunker_scan(&p, data + pos, take, base, (pos - base) + take);
+        if (k == 0) {
+            pos += take;
+            continue;
+        }
+        pos += k;
+        base = pos;
+        if (n < cap) ends[n] = pos;
+        n++;
+    }
+    if (base < len) {
+        if (n < cap) ends[n] = len;
+        n++;
+    }
+    return n;
+}
+
+size_t oracle_chunk_and_digest_suggested(const oracle_config *cfg, const uint8_t *base, const oracle_segment *segs,
+                                         uint32_t nseg, const uint64_t *sugg, const uint32_t *sugg_idx,
+                                         oracle_record *out, size_t cap, int sha_impl) {
+    size_t n = 0;
+    for (uint32_t s = 0; s < nseg; s++) {
+        const uint8_t *p = base + segs[s].offset;
+        const uint64_t len = segs[s].length;
+        size_t ecap = (size_t)(len / (cfg->min ? cfg->min : 1)) + 4;
+        uint64_t *ends = (uint64_t *)malloc(ecap * sizeof(uint64_t));
+        if (!ends) return 0;
+        const uint64_t *sl = sugg ? sugg + sugg_idx[s] : NULL;
+        const size_t ns = sugg ? (size_t)(sugg_idx[s + 1] - sugg_idx[s]) : 0;
+        size_t k = oracle_chunk_stream_suggested(cfg, p, (size_t)len, sl, ns, 1, ends, ecap);
+        uint64_t start = 0;
+        for (size_t i = 0; i < k && i < ecap; i++) {
+            if (n < cap) {
+                out[n].end = ends[i];
+                out[n].segment = s;
+                out[n].size = (uint32_t)(ends[i] - start);
+                oracle_sha256(p + start, ends[i] - start, out[n].digest, sha_impl);
+            }
+            n++;
+            start = ends[i];
+        }
+        free(ends);
     }
     return n;
 }

@@ -78,6 +78,22 @@ size_t oracle_chunker_scan(oracle_chunker *c, const uint8_t *data, size_t len);
 size_t oracle_chunk_stream(const oracle_config *cfg, const uint8_t *data, size_t len,
                            uint64_t *ends, size_t cap);
 
+/* Payload chunker = ChunkerImpl + suggested boundaries (published Proxmox PayloadChunker; EXTERNAL, recalled). */
+typedef struct oracle_payload_chunker {
+    oracle_chunker c;
+    const uint64_t *sugg; /* the channel: absolute stream offsets in send order */
+    size_t nsugg, next;
+    int have_cur;
+    uint64_t cur;
+} oracle_payload_chunker;
+void oracle_payload_chunker_init(oracle_payload_chunker *p, const oracle_config *cfg, const uint64_t *sugg, size_t nsugg);
+/* base = stream offset of the current chunk's first byte, total = bytes of the current chunk so far INCLUDING data */
+size_t oracle_payload_chunker_scan(oracle_payload_chunker *p, const uint8_t *data, size_t len, uint64_t base,
+                                   uint64_t total);
+/* one stream, `feed` bytes per scan call (0 = all that is left; 1 = byte-serial = the engine's definition) */
+size_t oracle_chunk_stream_suggested(const oracle_config *cfg, const uint8_t *data, size_t len, const uint64_t *sugg,
+                                     size_t nsugg, size_t feed, uint64_t *ends, size_t cap);
+
 /* Raw candidates: every END offset e (64 <= e <= len) whose 64-byte window [e-64, e)
  * passes the break test (no min/max, no resets), ascending. Returns the count. */
 size_t oracle_candidates(const oracle_config *cfg, const uint8_t *data, size_t len, uint64_t *out, size_t cap);
@@ -116,6 +132,12 @@ typedef struct oracle_segment {
 size_t oracle_chunk_and_digest(const oracle_config *cfg, const uint8_t *base,
                                const oracle_segment *segs, uint32_t nseg,
                                oracle_record *out, size_t cap, int sha_impl);
+
+/* ... with suggested boundaries per segment (byte-serial feed): sugg[sugg_idx[s] .. sugg_idx[s+1]) are the
+ * ascending boundaries of segment s, relative to its start. sugg == NULL -> none. */
+size_t oracle_chunk_and_digest_suggested(const oracle_config *cfg, const uint8_t *base, const oracle_segment *segs,
+                                         uint32_t nseg, const uint64_t *sugg, const uint32_t *sugg_idx,
+                                         oracle_record *out, size_t cap, int sha_impl);
 
 /* Deterministic synthetic byte generator shared with the engine's device fill
  * kernel (pbsgpu_fill): 8 bytes per counter via splitmix64(seed, index),

@@ -84,6 +84,12 @@ def lib() -> C.CDLL:
         L.oracle_chunk_and_digest.argtypes = [C.POINTER(Config), C.c_void_p, C.POINTER(Segment), C.c_uint32,
                                               C.c_void_p, C.c_size_t, C.c_int]
         L.oracle_chunk_and_digest.restype = C.c_size_t
+        L.oracle_chunk_stream_suggested.argtypes = [C.POINTER(Config), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                    C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle_chunk_stream_suggested.restype = C.c_size_t
+        L.oracle_chunk_and_digest_suggested.argtypes = [C.POINTER(Config), C.c_void_p, C.POINTER(Segment), C.c_uint32,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.oracle_chunk_and_digest_suggested.restype = C.c_size_t
         L.oracle_fill.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
         L.oracle_fill.restype = None
         _lib = L
@@ -134,6 +140,20 @@ def chunk_stream(cfg: Config, data) -> np.ndarray:
     return ends[:n].copy()
 
 
+def chunk_stream_suggested(cfg: Config, data, suggested, feed: int = 1) -> np.ndarray:
+    """Chunk END offsets of `data` cut as one stream by the payload chunker (ChunkerImpl + suggested boundaries,
+    absolute offsets in send order). feed = bytes handed to each scan call: 1 = byte-serial (the engine's
+    definition), 0 = the whole remaining buffer at once (upstream's second test loop)."""
+    a = _buf(data)
+    sg = np.ascontiguousarray(suggested, dtype=np.uint64)
+    cap = max(16, a.size // max(1, cfg.min) + 2 + sg.size)
+    ends = np.empty(cap, dtype=np.uint64)
+    n = lib().oracle_chunk_stream_suggested(C.byref(cfg), a.ctypes.data, a.size, sg.ctypes.data if sg.size else None,
+                                            sg.size, feed, ends.ctypes.data, cap)
+    assert n <= cap
+    return ends[:n].copy()
+
+
 def candidates(cfg: Config, data) -> np.ndarray:
     """Raw Buzhash candidate END offsets (no min/max rules) — parity target of the scan kernel."""
     a = _buf(data)
@@ -164,6 +184,25 @@ def chunk_and_digest(cfg: Config, data, segments=None, impl: int = 1) -> np.ndar
     out = np.zeros(cap, dtype=RECORD_DTYPE)
     n = lib().oracle_chunk_and_digest(C.byref(cfg), a.ctypes.data, segs, len(segments),
                                       out.ctypes.data, cap, impl)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def chunk_and_digest_suggested(cfg: Config, data, segments, suggested, impl: int = 1) -> np.ndarray:
+    """Like chunk_and_digest, with per-segment suggested boundaries: `suggested` = list (one entry per segment) of
+    ascending offsets relative to the segment start."""
+    a = _buf(data)
+    segs = (Segment * max(1, len(segments)))(*[Segment(int(o), int(n)) for o, n in segments])
+    flat = np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in suggested]) if len(suggested) else np.zeros(0, np.uint64)
+    flat = np.ascontiguousarray(flat, dtype=np.uint64)
+    idx = np.zeros(len(segments) + 1, dtype=np.uint32)
+    idx[1:] = np.cumsum([len(x) for x in suggested])
+    total = sum(int(n) for _, n in segments)
+    cap = total // max(1, cfg.min) + 2 * len(segments) + flat.size + 16
+    out = np.zeros(cap, dtype=RECORD_DTYPE)
+    n = lib().oracle_chunk_and_digest_suggested(C.byref(cfg), a.ctypes.data, segs, len(segments),
+                                                flat.ctypes.data if flat.size else None, idx.ctypes.data,
+                                                out.ctypes.data, cap, impl)
     assert n <= cap
     return out[:n].copy()
 

@@ -102,6 +102,8 @@ SYMBOLS = {
     "pbsgpu_engine_config": (C.c_int, [_P, C.POINTER(Config)]),
     "pbsgpu_submit_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
     "pbsgpu_submit_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
+    "pbsgpu_submit_device_suggested": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, _P, _U64P]),
+    "pbsgpu_submit_host_suggested": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, _P, _U64P]),
     "pbsgpu_wait": (C.c_int, [_P, C.c_uint64, _U64P]),
     "pbsgpu_ticket_done": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int)]),
     "pbsgpu_collect": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P]),
@@ -121,6 +123,8 @@ SYMBOLS = {
     "pbsgpu_stream_finish": (C.c_int, [_P]),
     "pbsgpu_stream_poll": (C.c_int, [_P, _P, C.c_uint64, _U64P]),
     "pbsgpu_stream_position": (C.c_int, [_P, _U64P]),
+    "pbsgpu_stream_bytes_written": (C.c_int, [_P, _U64P]),
+    "pbsgpu_stream_suggest": (C.c_int, [_P, C.c_uint64]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
@@ -136,6 +140,8 @@ SYMBOLS = {
     "pbsgpu_reuse_lookup": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_uint64, _U64P, _U64P, _U64P]),
     "pbsgpu_reuse_should": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, C.c_double, C.POINTER(C.c_int)]),
     "pbsgpu_fill_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "pbsgpu_gather_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, _P, C.c_uint32]),
+    "pbsgpu_measure_h2d": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_double)]),
     "pbsgpu_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
     "pbsgpu_device_free": (C.c_int, [_P, _P]),
     "pbsgpu_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_uint64]),

@@ -1,12 +1,24 @@
 // Internal declarations shared by the libpbsgpu translation units (not part of the C ABI).
+//
+// Concurrency model (cgo calls arrive on arbitrary OS threads, several goroutines may share one engine):
+//   * pbsgpu_engine::mu guards only bookkeeping — which pool slot is free, the ticket table, the aux leases, the
+//     child count. It is NEVER held across a HIP synchronisation, a memcpy or a kernel enqueue.
+//   * a Slot (device work context: HIP stream, events, work buffers, pinned staging) is owned by exactly one
+//     logical user at a time: a batch ticket (pool slots), one synchronous helper call (aux slots, leased; callers
+//     WAIT for a lease instead of failing), or one stream / chunker handle (private slot, never shared).
+//   * Slot::op serialises concurrent operations on the same ticket (wait / collect / timing from two threads).
+//   * streaming writers hash through the engine-wide HashDispatcher (own mutex): chunks of many windows and many
+//     streams share SHA-256 launches, so the number of concurrent kernels stays bounded however many streams feed.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -36,11 +48,20 @@ extern std::atomic<int> g_last_hip_error;
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+        return *this;
+    }
     int ensure(size_t bytes) {
         if (bytes <= cap) return PBSGPU_OK;
         if (p) {
-            (void)hipFree(p);
+            (void)hipFree(p);  // device-wide wait: see PinnedBuf::ensure
             p = nullptr;
+            bytes = std::max(bytes, std::min<size_t>(cap * 2, cap + (256u << 20)));
             cap = 0;
         }
         size_t want = bytes + bytes / 8 + 256;
@@ -52,6 +73,7 @@ struct DevBuf {
         }
         if (e != hipSuccess) {
             g_last_hip_error.store((int)e);
+            (void)hipGetLastError();
             p = nullptr;
             return PBSGPU_E_NOMEM;
         }
@@ -69,14 +91,25 @@ struct DevBuf {
 struct PinnedBuf {
     void *p = nullptr;
     size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    PinnedBuf(PinnedBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    // NOTE: hipHostFree / hipFree wait for the whole device to go idle — a regrow while another stream's 0.4 s SHA
+    // launch is running stalls the caller that long (measured on the streaming writer). Hot paths therefore size their
+    // buffers once for the largest case (ensure_once / presize) and growth doubles.
     int ensure(size_t bytes) {
         if (bytes <= cap) return PBSGPU_OK;
-        if (p) (void)hipHostFree(p);
+        if (p) {
+            (void)hipHostFree(p);
+            bytes = std::max(bytes, cap * 2);
+        }
         p = nullptr;
         cap = 0;
         hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
         if (e != hipSuccess) {
             g_last_hip_error.store((int)e);
+            (void)hipGetLastError();
             p = nullptr;
             return PBSGPU_E_NOMEM;
         }
@@ -97,15 +130,25 @@ enum : int { SC_NCAND = 0, SC_NREC = 1, SC_MAXCNT = 2, SC_QUEUE = 3, SC_WGLIMIT 
 
 enum : int { EV_BEGIN = 0, EV_SCAN0, EV_SCAN1, EV_RESOLVE1, EV_SHA1, EV_COUNT };
 
+constexpr size_t kStageBytes = 32u << 20;
+
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     DevBuf data;  // staged copy of host submits
     DevBuf tile_cnt, tile_off, tile_slots, dense, scan_tmp, scalars, segs, seg_cnt, seg_off, recs, order;
-    PinnedBuf h_scalars;  // readback of SC_*
-    PinnedBuf h_segs;     // pinned copy of the segment table
-    // in-flight state
-    bool busy = false;
+    DevBuf sugg, sugg_idx;  // suggested boundaries (optional)
+    PinnedBuf h_scalars;    // readback of SC_*
+    PinnedBuf h_segs;       // pinned copy of the segment table
+    PinnedBuf h_sugg;       // pinned copy of suggested offsets + index
+    PinnedBuf h_recs;       // mapped pinned copy of the finished records (published by kernel, not by the copy engine)
+    bool recs_published = false;
+    PinnedBuf stage[2];     // host -> device staging of this slot (lazily allocated)
+    hipEvent_t stage_ev[2] = {};
+    std::mutex op;          // serialises operations on the ticket that owns this slot
+    // in-flight state (owner only)
+    bool busy = false;      // under engine mu
+    bool ready = false;     // ticket published (under engine mu)
     bool synced = false;
     uint64_t ticket = 0;
     const uint8_t *dptr = nullptr;
@@ -113,9 +156,39 @@ struct Slot {
     uint32_t nseg = 0;
     uint32_t cap = 0;
     uint64_t rec_cap = 0;
+    uint64_t nsugg = 0;     // suggested offsets staged for this batch (0 = none)
     bool host_submit = false;
     uint32_t retries = 0;
     uint64_t nrec = 0, ncand = 0;
+
+    int init();      // stream + events
+    void destroy();  // frees everything (device must be current)
+};
+
+// ---- shared SHA-256 jobs of the streaming writers -------------------------------------------------------------
+// A job collects the chunk descriptors of every window flushed (by any stream of the engine) since the previous
+// launch and hashes them in ONE k_sha256_pair launch on one of a few hash lanes (HIP streams). A launch lasts as
+// long as its longest chunk's serial chain (up to ~0.43 s for 16 MiB), so lanes are the scarce resource, not CUs.
+struct HashJob {
+    // host side (pinned: uploaded / downloaded asynchronously)
+    std::vector<pbsk::HashDesc> descs;  // accumulated while the job is open
+    PinnedBuf h_desc, h_order, h_dig;
+    DevBuf d_desc, d_order, d_queue;
+    hipEvent_t done = nullptr;
+    uint32_t n = 0;          // descriptors launched
+    int lane = -1;
+    enum State { OPEN, LAUNCHED } state = OPEN;
+    std::atomic<int> refs{0};  // windows that still have to read their digests
+    const uint8_t *digest(uint32_t i) const { return h_dig.as<uint8_t>() + (size_t)i * 32; }
+};
+
+struct HashDispatcher {
+    std::mutex mu;
+    std::vector<hipStream_t> lanes;
+    std::vector<HashJob *> lane_job;              // job running (or last run) on each lane
+    std::vector<std::unique_ptr<HashJob>> jobs;   // pool (all jobs ever created)
+    HashJob *open = nullptr;                      // accumulating
+    int num_cus = 256;
 };
 
 }  // namespace pbse
@@ -131,31 +204,58 @@ struct pbsgpu_engine {
     uint32_t thr = 0;      // break_min << (32 - bits)
     uint32_t effmin = 0;   // max(min, 65)
     uint32_t *d_table_rot = nullptr;
-    std::vector<pbse::Slot> slots;
+    std::vector<std::unique_ptr<pbse::Slot>> slots;  // batch-ticket pool
+    std::vector<std::unique_ptr<pbse::Slot>> aux;    // leased to synchronous helper calls
+    std::vector<char> aux_busy;
     uint64_t next_ticket = 1;
-    uint32_t cap_hint = 0;       // per-tile slot capacity that a density retry settled on
-    uint32_t cap_hint_tile = 0;  // ... for this tile size
-    pbse::PinnedBuf stage[2];
-    hipEvent_t stage_ev[2] = {};
+    std::atomic<uint32_t> cap_hint{0};       // per-tile slot capacity that a density retry settled on
+    std::atomic<uint32_t> cap_hint_tile{0};  // ... for this tile size
     std::mutex mu;
+    std::condition_variable cv;  // an aux lease was returned
+    pbse::HashDispatcher hd;
+    int refs = 1;                // owner + live streams / chunkers (under mu); freed when it drops to 0
+    bool destroyed = false;      // pbsgpu_engine_destroy was called (children may still be alive)
 };
-
 
 namespace pbse {
 
 uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes);
 int set_device(const pbsgpu_engine *e);
-Slot *find_free_slot(pbsgpu_engine *e);
 bool is_device_pointer(const void *p);
+
+// leases one of the engine's aux slots for the duration of a synchronous helper call (waits for a free one)
+struct AuxLease {
+    pbsgpu_engine *e;
+    Slot *s = nullptr;
+    int idx = -1;
+    explicit AuxLease(pbsgpu_engine *eng);
+    ~AuxLease();
+    AuxLease(const AuxLease &) = delete;
+    AuxLease &operator=(const AuxLease &) = delete;
+};
+
+void engine_ref(pbsgpu_engine *e);
+void engine_unref(pbsgpu_engine *e);  // frees the engine when the last reference goes
+
+struct SuggestedHost {  // caller's suggested boundaries: offsets[index[s] .. index[s+1]) ascending, relative to segment s
+    const uint64_t *offsets = nullptr;
+    const uint32_t *index = nullptr;
+};
+
 int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint32_t cap,
                        uint64_t nseg_hint = 0);
-int staged_h2d(pbsgpu_engine *e, void *dst, const void *src, uint64_t nbytes, hipStream_t st);
-// synchronous helpers for the streaming front ends (caller holds e->mu)
+int staged_h2d(Slot &s, void *dst, const void *src, uint64_t nbytes, hipStream_t st);
+int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32_t nseg, uint64_t nbytes,
+                   const SuggestedHost *sg);
+// synchronous helpers for the streaming front ends (the caller owns the slot)
 int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint64_t *count);
-int batch_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
-               uint32_t nseg, uint64_t *nrec);
 int cut_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
-             uint32_t nseg, uint64_t *nrec);
-int hash_async(pbsgpu_engine *e, Slot &s, uint64_t nhash);
+             uint32_t nseg, const SuggestedHost *sg, uint64_t *nrec);
+// size every buffer a single-segment cut of up to max_bytes can touch, so that steady-state windows never reallocate
+int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes);
+
+// hash dispatcher (stream.cpp)
+int hd_init(pbsgpu_engine *e);
+void hd_destroy(pbsgpu_engine *e);
 
 }  // namespace pbse

@@ -46,17 +46,24 @@ hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, co
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
                           uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st);
 
+// optional suggested boundaries (payload chunker): offsets[index[s] .. index[s+1]) ascending, relative to segment s
+struct Suggested {
+    const uint64_t *offsets = nullptr;  // device
+    const uint32_t *index = nullptr;    // device, nseg + 1 entries
+    uint32_t cmin = 0;                  // the config's true min (a suggested cut needs chunk_size >= min, not >= 65)
+};
+
 // min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt,
-                                hipStream_t st);
+                                const Suggested &sg, hipStream_t st);
 hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
-                                pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st);
+                                pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st);
 
 hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
-                                 pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st);
+                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st);
 
 // SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
 // `queue` is a device uint32 that must be zero at launch.
@@ -68,6 +75,14 @@ hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs
 hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
                         uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
                         hipStream_t st);
+// SHA-256 of explicit (pointer, length) descriptors — the shared hash jobs of the streaming writers. digests[32*i]
+// for descs[i]; `order` = longest-first permutation (may be null); `workgroups` = CU budget of the launch.
+struct HashDesc {
+    const uint8_t *ptr;
+    uint64_t len;
+};
+hipError_t launch_sha256_descs(const HashDesc *descs, uint32_t n, const uint32_t *order, uint8_t *digests,
+                               uint32_t *queue, unsigned workgroups, hipStream_t st);
 // SHA-256 of whole segments (verification path): digests[32*i] for segs[i]
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
                                   uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);
@@ -75,6 +90,11 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
 // XXH3-64 (seed 0) of whole segments: out[i] for segs[i]; `queue` zero at launch
 hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
                        int num_cus, hipStream_t st);
+
+// device -> mapped pinned host memory by kernel (never through the shared SDMA copy queues; see kernels.hip)
+hipError_t launch_publish(void *dst_host_mapped, const void *src, uint64_t nbytes, hipStream_t st);
+hipError_t launch_publish_records(pbsgpu_record *dst_host_mapped, const pbsgpu_record *src, const uint32_t *nrec,
+                                  uint64_t cap, hipStream_t st);
 
 hipError_t launch_fill(void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed, uint32_t kind,
                        hipStream_t st);

@@ -11,6 +11,7 @@
 // Integer/byte work only: no MFMA anywhere.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -741,11 +742,32 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const
     const uint32_t *sl = tile_slots + t * cap;
     const uint64_t base = tile_off[t];
     const uint64_t tbase = t * (uint64_t)tile_bytes;
+    if (c <= 48) {  // the normal case (a handful of candidates per tile): rank by comparison
+        for (uint32_t j = 0; j < c; ++j) {
+            const uint32_t vj = sl[j];
+            uint32_t rank = 0;
+            for (uint32_t i = 0; i < c; ++i) rank += (sl[i] < vj) ? 1u : 0u;  // offsets within a tile are distinct
+            if (base + rank < dense_cap) dense[base + rank] = tbase + vj - lead;
+        }
+        return;
+    }
+    // Dense tile (periodic / crafted input; the capacity-retry path): linear-time stable counting sort by lane strip.
+    // A lane appends its own hits in ascending order (it walks its strip forwards and its LDS atomics execute in
+    // program order), so the slot list is ascending WITHIN each strip and only interleaved ACROSS strips.
+    const uint32_t strip = tile_bytes / 64u;
+    uint32_t cnt[64];
+    for (int i = 0; i < 64; ++i) cnt[i] = 0;
+    for (uint32_t j = 0; j < c; ++j) cnt[min((sl[j] - 1u) / strip, 63u)]++;  // END offsets: 1..tile_bytes
+    uint32_t run = 0;
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t k = cnt[i];
+        cnt[i] = run;
+        run += k;
+    }
     for (uint32_t j = 0; j < c; ++j) {
         const uint32_t vj = sl[j];
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < c; ++i) rank += (sl[i] < vj) ? 1u : 0u;  // offsets within a tile are distinct
-        if (base + rank < dense_cap) dense[base + rank] = tbase + vj - lead;
+        const uint32_t pos = cnt[min((vj - 1u) / strip, 63u)]++;
+        if (base + pos < dense_cap) dense[base + pos] = tbase + vj - lead;
     }
 }
 
@@ -767,11 +789,17 @@ hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, co
 // next cut is the first end e with (e - s >= max) or (e - s >= max(min, 65) and e is a
 // candidate); the stream end closes the last chunk. The break test only runs in the
 // rolling loop, i.e. from chunk_size 65 on, hence the 65.
+// Suggested boundaries (payload chunker, SURVEY.md Appendix A note 3 / E.3; oracle_payload_chunker_scan fed byte by
+// byte): a second ascending list per segment. After a cut at s the next cut is the EARLIER of the hash/max cut and
+// the first suggested boundary b with min <= b - s <= max; boundaries with b - s < min are dropped for good. For
+// min >= 65 they behave exactly like extra candidates; the separate list keeps the min = 64 corner (hash cuts need
+// chunk_size >= 65, a suggested one only >= min) exact.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const uint32_t *ncand_p,
                                                  const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
                                                  uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
-                                                 pbsgpu_record *recs, uint64_t rec_cap) {
+                                                 pbsgpu_record *recs, uint64_t rec_cap, const uint64_t *sugg,
+                                                 const uint32_t *sugg_idx, uint32_t cmin) {
     const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (seg >= nseg) return;
@@ -791,6 +819,10 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
     }
     uint64_t wb = lo;  // window base: lane holds cands[wb + lane]
     uint64_t cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
+    // suggested boundaries of this segment (relative to A): same wave-wide window walk
+    const uint64_t sbeg = sugg ? sugg_idx[seg] : 0, send = sugg ? sugg_idx[seg + 1] : 0;
+    uint64_t swb = sbeg;
+    uint64_t sv = (swb + lane < send) ? A + sugg[swb + lane] : ~0ull;
 
     while (s < B) {
         const uint64_t tlo = s + effmin, thi = s + maxsz;
@@ -807,6 +839,20 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
         }
         uint64_t e = (c < thi) ? c : thi;
         if (e > B) e = B;
+        if (send > sbeg) {  // segment-uniform
+            const uint64_t slo = s + cmin;
+            uint64_t b;
+            for (;;) {
+                const unsigned long long m = __ballot(sv >= slo);  // lanes past the list hold ~0: always terminates
+                if (m) {
+                    b = __shfl(sv, __ffsll((long long)m) - 1, 64);
+                    break;
+                }
+                swb += 64;
+                sv = (swb + lane < send) ? A + sugg[swb + lane] : ~0ull;
+            }
+            if (b < e) e = b;  // b >= s + min and b < e <= s + max: a legal chunk
+        }
         if (WRITE) {
             if (lane == 0 && rbase + k < rec_cap) {
                 pbsgpu_record *r = recs + rbase + k;
@@ -822,30 +868,32 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
 }
 
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
-                                uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt, hipStream_t st) {
+                                uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt, const Suggested &sg,
+                                hipStream_t st) {
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
-                       maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0);
+                       maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0, sg.offsets,
+                       sg.index, sg.cmin);
     return hipGetLastError();
 }
 
 hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
-                                pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st) {
+                                pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
-                       maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap);
+                       maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin);
     return hipGetLastError();
 }
 
 // one segment: its records start at index 0, so a single walk writes them and the count (-> *nrec)
 hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
-                                 pbsgpu_record *recs, uint64_t rec_cap, hipStream_t st) {
+                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec,
-                       zero_off, recs, rec_cap);
+                       zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin);
     return hipGetLastError();
 }
 
@@ -941,6 +989,20 @@ struct SegmentSource {
     __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
         ptr = data + segs[i].offset;
         len = segs[i].length;
+        dst = digests + (uint64_t)i * 32;
+    }
+};
+
+// explicit (pointer, length) descriptors: the shared hash jobs of the streaming writers (chunks of many windows and
+// many streams in one launch); digest i lands at digests + 32 * i
+struct DescSource {
+    const HashDesc *d;
+    uint8_t *digests;
+    const uint32_t *order;  // queue position -> descriptor index (longest first), may be null
+    __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
+        if (order) i = order[i];
+        ptr = d[i].ptr;
+        len = d[i].len;
         dst = digests + (uint64_t)i * 32;
     }
 };
@@ -1400,6 +1462,21 @@ hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs
     return hipGetLastError();
 }
 
+hipError_t launch_sha256_descs(const HashDesc *descs, uint32_t n, const uint32_t *order, uint8_t *digests,
+                               uint32_t *queue, unsigned workgroups, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    DescSource src{descs, digests, order};
+    const size_t pad = sha_lds_pad(8u << 10);
+    hipError_t e = allow_lds(&k_sha256_pair<DescSource>, pad);
+    if (e != hipSuccess) return e;
+    const unsigned need = (n + 127) / 128;
+    if (workgroups > need) workgroups = need;
+    if (workgroups < 1) workgroups = 1;
+    hipLaunchKernelGGL((k_sha256_pair<DescSource>), dim3(workgroups), dim3(256), pad, st, src, (const uint32_t *)nullptr,
+                       n, queue, (const uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests,
                                   uint32_t *queue, int num_cus, hipStream_t st) {
     if (nseg == 0) return hipSuccess;
@@ -1425,6 +1502,44 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
         hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), pad, st, src, (const uint32_t *)nullptr,
                            nseg, queue, (const uint32_t *)nullptr);
     }
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// small device -> host publication without the copy engines
+// =====================================================================================
+// hipMemcpyAsync(D2H) rides an SDMA queue that HIP streams share: a copy that has to wait for the kernel in front of
+// it on ITS stream (e.g. "scalars after the 0.4 s SHA launch") parks at the head of that queue and every later copy
+// of every other stream — another batch's segment-table upload, a stream window's record readback — waits behind it
+// (measured: 380-430 ms stalls of a 3 KB readback while another stream's SHA kernel ran). Results that a host thread
+// waits for are therefore WRITTEN by a kernel straight into mapped pinned host memory.
+__global__ __launch_bounds__(256) void k_publish(uint32_t *dst, const uint32_t *src, uint64_t nwords) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) dst[i] = src[i];
+}
+
+// count-dependent form: publishes recs[0 .. *nrec) (12 words each, capped at cap records)
+__global__ __launch_bounds__(256) void k_publish_records(uint32_t *dst, const uint32_t *src, const uint32_t *nrec,
+                                                         uint64_t cap) {
+    const uint64_t n = min((uint64_t)*nrec, cap) * (sizeof(pbsgpu_record) / 4);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+hipError_t launch_publish(void *dst_host_mapped, const void *src, uint64_t nbytes, hipStream_t st) {
+    if (nbytes == 0) return hipSuccess;
+    const uint64_t nwords = (nbytes + 3) / 4;
+    unsigned blocks = (unsigned)std::min<uint64_t>((nwords + 255) / 256, 64);
+    hipLaunchKernelGGL(k_publish, dim3(blocks), dim3(256), 0, st, (uint32_t *)dst_host_mapped, (const uint32_t *)src, nwords);
+    return hipGetLastError();
+}
+
+hipError_t launch_publish_records(pbsgpu_record *dst_host_mapped, const pbsgpu_record *src, const uint32_t *nrec,
+                                  uint64_t cap, hipStream_t st) {
+    if (cap == 0) return hipSuccess;
+    unsigned blocks = (unsigned)std::min<uint64_t>((cap * 12 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_publish_records, dim3(blocks), dim3(256), 0, st, (uint32_t *)dst_host_mapped, (const uint32_t *)src,
+                       nrec, cap);
     return hipGetLastError();
 }
 

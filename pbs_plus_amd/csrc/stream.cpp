@@ -8,6 +8,9 @@
 //  * pbsgpu_dedup_host — digest-set duplicate detection on the device.
 //  * pbsgpu_didx_*    — dynamic index encode/decode (commit_bottleneck_test.go:773-793).
 // All byte-stream work runs through the same HIP kernels as the batch path.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 
 #include "engine_internal.h"
@@ -15,168 +18,379 @@
 using namespace pbse;
 
 // -------------------------------------------------------------------------------------
-// streaming writer
+// shared SHA-256 jobs (engine-wide)
 // -------------------------------------------------------------------------------------
-// Windows of the stream are CUT synchronously (scan + resolve: milliseconds) because the next
-// window needs to know where the still-open chunk starts, but HASHED asynchronously: the SHA-256
-// kernel of a window is bounded below by the serial chain of its longest chunk (up to ~0.46 s for a
-// 16 MiB chunk), so several windows hash concurrently on their own engine slots / HIP streams while
-// the writer keeps accepting bytes. Records are delivered strictly in stream order.
+// Windows of every stream append their chunk descriptors to the engine's OPEN job; whoever finds a free hash lane
+// seals the job and launches it (one k_sha256_pair launch over all accumulated chunks, longest first). A launch
+// cannot finish before the serial chain of its longest chunk (up to ~0.43 s at 16 MiB), so with one launch per
+// window the number of concurrent kernels would grow with the ingest rate and exhaust the hardware queues; with
+// shared jobs it is bounded by the lane count while every chunk still starts within one lane-turnaround.
+namespace pbse {
+
+constexpr int kHashLanes = 8;
+
+int hd_init(pbsgpu_engine *e) {
+    HashDispatcher &hd = e->hd;
+    hd.num_cus = e->num_cus;
+    hd.lanes.assign(kHashLanes, nullptr);
+    hd.lane_job.assign(kHashLanes, nullptr);
+    for (auto &st : hd.lanes) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return PBSGPU_OK;
+}
+
+void hd_destroy(pbsgpu_engine *e) {
+    HashDispatcher &hd = e->hd;
+    for (auto st : hd.lanes)
+        if (st) (void)hipStreamSynchronize(st);
+    for (auto &j : hd.jobs) {
+        for (DevBuf *b : {&j->d_desc, &j->d_order, &j->d_queue}) b->release();
+        for (PinnedBuf *b : {&j->h_desc, &j->h_order, &j->h_dig}) b->release();
+        if (j->done) (void)hipEventDestroy(j->done);
+    }
+    hd.jobs.clear();
+    for (auto st : hd.lanes)
+        if (st) (void)hipStreamDestroy(st);
+    hd.lanes.clear();
+}
+
+}  // namespace pbse
+
 namespace {
 
+// hd.mu held: a job object that is neither open, running, nor still referenced by a window
+HashJob *hd_new_job(HashDispatcher &hd) {
+    for (auto &j : hd.jobs) {
+        if (j.get() == hd.open || j->refs.load() != 0) continue;
+        bool on_lane = false;
+        for (auto *lj : hd.lane_job) on_lane |= (lj == j.get());
+        if (on_lane) continue;
+        j->descs.clear();
+        j->n = 0;
+        j->lane = -1;
+        j->state = HashJob::OPEN;
+        return j.get();
+    }
+    std::unique_ptr<HashJob> j(new (std::nothrow) HashJob());
+    if (!j) return nullptr;
+    if (hipEventCreateWithFlags(&j->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    hd.jobs.push_back(std::move(j));
+    return hd.jobs.back().get();
+}
+
+// hd.mu held. Seal the open job and launch it if a lane is free. Returns PBSGPU_OK with *launched = false when every
+// lane is still busy (the caller may wait on *busy_ev, outside the lock, and retry).
+int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev) {
+    HashDispatcher &hd = e->hd;
+    *launched = false;
+    if (busy_ev) *busy_ev = nullptr;
+    HashJob *j = hd.open;
+    if (!j || j->descs.empty()) return PBSGPU_OK;
+    int lane = -1;
+    for (int i = 0; i < (int)hd.lanes.size() && lane < 0; ++i) {
+        HashJob *lj = hd.lane_job[i];
+        if (!lj) {
+            lane = i;
+        } else {
+            const hipError_t q = hipEventQuery(lj->done);
+            if (q == hipSuccess) {
+                hd.lane_job[i] = nullptr;
+                lane = i;
+            } else if (q != hipErrorNotReady) {
+                g_last_hip_error.store((int)q);
+                return PBSGPU_E_HIP;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    if (lane < 0) {
+        if (busy_ev) *busy_ev = hd.lane_job[0]->done;
+        return PBSGPU_OK;
+    }
+    const uint32_t n = (uint32_t)j->descs.size();
+    hipStream_t st = hd.lanes[lane];
+    const size_t room = std::max<size_t>(n, 8192);  // regrowing later would wait for the whole device (hipFree)
+    CHK(j->h_desc.ensure(room * sizeof(pbsk::HashDesc)));
+    CHK(j->h_order.ensure(room * 4));
+    CHK(j->h_dig.ensure(room * 32));
+    CHK(j->d_desc.ensure(room * sizeof(pbsk::HashDesc)));
+    CHK(j->d_order.ensure(room * 4));
+    CHK(j->d_queue.ensure(64));
+    std::memcpy(j->h_desc.p, j->descs.data(), (size_t)n * sizeof(pbsk::HashDesc));
+    // longest first (the launch lasts as long as its longest chain) + the CU budget that keeps the launch at that bound
+    uint32_t *ord = j->h_order.as<uint32_t>();
+    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
+    std::sort(ord, ord + n, [&](uint32_t a, uint32_t b) { return j->descs[a].len > j->descs[b].len; });
+    uint64_t total_blocks = 0, longest = 1;
+    for (const auto &d : j->descs) {
+        const uint64_t blocks = (d.len + 8) / 64 + 1;
+        total_blocks += blocks;
+        longest = std::max(longest, blocks);
+    }
+    uint64_t lanes_needed = (total_blocks * 125 / 100 + longest - 1) / longest;
+    unsigned wgs = (unsigned)std::min<uint64_t>((lanes_needed + 127) / 128, (uint64_t)hd.num_cus);
+    HIPCHK(hipMemcpyAsync(j->d_desc.p, j->h_desc.p, (size_t)n * sizeof(pbsk::HashDesc), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(j->d_order.p, j->h_order.p, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(j->d_queue.p, 0, 64, st));
+    // the digests are written by the kernel straight into mapped pinned memory: a D2H copy queued behind a 0.4 s kernel
+    // would block the copy queue it shares with every other stream (kernels.hip, k_publish)
+    HIPCHK(pbsk::launch_sha256_descs(j->d_desc.as<pbsk::HashDesc>(), n, j->d_order.as<uint32_t>(), j->h_dig.as<uint8_t>(),
+                                     j->d_queue.as<uint32_t>(), wgs, st));
+    HIPCHK(hipEventRecord(j->done, st));
+    j->n = n;
+    j->lane = lane;
+    j->state = HashJob::LAUNCHED;
+    hd.lane_job[lane] = j;
+    hd.open = nullptr;
+    *launched = true;
+    return PBSGPU_OK;
+}
+
+// append `n` descriptors to the open job; returns the job and the index of the first one. Tries to launch at once.
+int hd_append(pbsgpu_engine *e, const pbsk::HashDesc *d, uint32_t n, HashJob **job, uint32_t *first) {
+    HashDispatcher &hd = e->hd;
+    std::lock_guard<std::mutex> lk(hd.mu);
+    if (!hd.open) {
+        hd.open = hd_new_job(hd);
+        if (!hd.open) return PBSGPU_E_NOMEM;
+    }
+    HashJob *j = hd.open;
+    *first = (uint32_t)j->descs.size();
+    j->descs.insert(j->descs.end(), d, d + n);
+    j->refs.fetch_add(1);
+    *job = j;
+    bool launched;
+    return hd_try_launch_locked(e, &launched, nullptr);
+}
+
+// make sure `j` gets launched (it may still be the open job because every lane was busy when it was filled)
+int hd_ensure_launched(pbsgpu_engine *e, HashJob *j, bool block) {
+    HashDispatcher &hd = e->hd;
+    for (;;) {
+        hipEvent_t busy = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(hd.mu);
+            if (j->state == HashJob::LAUNCHED) return PBSGPU_OK;
+            bool launched = false;
+            CHK(hd_try_launch_locked(e, &launched, &busy));
+            if (launched || j->state == HashJob::LAUNCHED) return PBSGPU_OK;
+        }
+        if (!block) return PBSGPU_OK;
+        if (busy) HIPCHK(hipEventSynchronize(busy));  // a lane frees up when its job ends
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// streaming writer
+// -------------------------------------------------------------------------------------
+// A stream owns everything it touches on the cut side (a private work context, its window buffers, pinned staging, a
+// copy stream): several streams of one engine run concurrently from different threads without ever taking the
+// engine lock. Windows are CUT synchronously (scan + resolve: well under a millisecond of GPU time) because the
+// next window needs to know where the still-open chunk starts; their chunks are HASHED asynchronously through the
+// engine's shared jobs. Records are delivered strictly in stream order.
 struct WindowInFlight {
-    Slot *slot = nullptr;
     int buf = -1;
-    uint64_t base = 0;     // absolute stream offset of the window buffer's byte 0
-    uint32_t section = 0;
-    uint64_t nemit = 0;    // records to deliver (the open tail chunk of a non-final window is excluded)
+    HashJob *job = nullptr;
+    uint32_t first = 0;                  // index of this window's first descriptor in the job
+    std::vector<pbsgpu_record> recs;     // end (absolute) / size / section filled in; digests arrive with the job
 };
 
 constexpr size_t kStreamStage = 32u << 20;
+constexpr int kStreamStages = 3;
 
 }  // namespace
 
 struct pbsgpu_stream {
     pbsgpu_engine *eng = nullptr;
     uint64_t window = 0;           // new bytes per device window
+    size_t devcap = 0;
+    size_t max_bufs = 0;           // ring limit (back-pressure beyond it)
     std::vector<DevBuf> dev;       // window buffers: [carry | new bytes]
-    std::vector<char> dev_busy;    // held by a window that is still hashing
+    std::vector<char> dev_busy;    // held by a window whose chunks are still being hashed
     int cur = 0;
     uint64_t carry = 0;            // bytes of the still-open chunk at the front of dev[cur]
     uint64_t fill = 0;             // new bytes already copied behind the carry
+    Slot cut;                      // private cut context (never shared)
     hipStream_t copy_stream = nullptr;
-    PinnedBuf stage[2];
-    hipEvent_t stage_ev[2] = {};
+    hipEvent_t copied = nullptr;
+    PinnedBuf stage[kStreamStages];
+    hipEvent_t stage_ev[kStreamStages] = {};
     int stage_idx = 0;
     int reserved = -1;             // staging buffer handed out by pbsgpu_stream_reserve
-    uint64_t base = 0;             // absolute stream offset of dev[cur][0]
+    PinnedBuf h_recs;              // readback of a window's records
+    uint64_t base = 0;             // absolute stream offset (incl. injected bytes) of dev[cur][0]
     uint64_t written = 0;
     uint64_t inject_total = 0;
     uint32_t section = 0;
     bool finished = false;
+    std::deque<uint64_t> suggested;  // pending suggested boundaries (absolute offsets, ascending)
     std::deque<WindowInFlight> inflight;
     std::deque<pbsgpu_record> out;
-    std::vector<pbsgpu_record> tmp;
+    std::vector<pbsk::HashDesc> descs;
+    std::vector<uint64_t> sugg_rel;
 };
 
 namespace {
 
-// wait for the oldest hashing window, move its records to the output queue, release slot + buffer
-int stream_complete_oldest(pbsgpu_stream *s) {
-    WindowInFlight w = s->inflight.front();
-    HIPCHK(hipStreamSynchronize(w.slot->stream));
-    s->tmp.resize((size_t)w.nemit);
-    if (w.nemit) {
-        HIPCHK(hipMemcpy(s->tmp.data(), w.slot->recs.p, (size_t)w.nemit * sizeof(pbsgpu_record), hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < w.nemit; ++i) {
-            pbsgpu_record r = s->tmp[(size_t)i];
-            r.end += w.base;
-            r.segment = w.section;
-            s->out.push_back(r);
-        }
+// move the oldest window's records (now with digests) to the output queue, release its buffer
+int stream_complete_oldest(pbsgpu_stream *s, bool block) {
+    WindowInFlight &w = s->inflight.front();
+    CHK(hd_ensure_launched(s->eng, w.job, block));
+    {
+        std::lock_guard<std::mutex> lk(s->eng->hd.mu);
+        if (w.job->state != HashJob::LAUNCHED) return PBSGPU_E_BUSY;  // only when !block
     }
-    w.slot->busy = false;
+    if (block) {
+        HIPCHK(hipEventSynchronize(w.job->done));
+    } else {
+        const hipError_t q = hipEventQuery(w.job->done);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return PBSGPU_E_BUSY;
+        }
+        HIPCHK(q);
+    }
+    for (size_t i = 0; i < w.recs.size(); ++i) {
+        std::memcpy(w.recs[i].digest, w.job->digest(w.first + (uint32_t)i), 32);
+        s->out.push_back(w.recs[i]);
+    }
+    w.job->refs.fetch_sub(1);
     s->dev_busy[w.buf] = 0;
     s->inflight.pop_front();
     return PBSGPU_OK;
 }
 
-int stream_free_buffer(pbsgpu_stream *s) {
-    for (size_t i = 0; i < s->dev.size(); ++i)
-        if (!s->dev_busy[i] && (int)i != s->cur) return (int)i;
-    return -1;
+// a window buffer that is neither current nor still being hashed; grows the ring up to max_bufs, then waits
+int stream_free_buffer(pbsgpu_stream *s, int *out) {
+    for (;;) {
+        for (size_t i = 0; i < s->dev.size(); ++i)
+            if (!s->dev_busy[i] && (int)i != s->cur) {
+                *out = (int)i;
+                return s->dev[i].ensure(s->devcap);
+            }
+        if (s->dev.size() < s->max_bufs) {
+            s->dev.emplace_back();
+            s->dev_busy.push_back(0);
+            continue;
+        }
+        if (s->inflight.empty()) return PBSGPU_E_STATE;
+        CHK(stream_complete_oldest(s, true));  // back-pressure: the ingest outruns the hash jobs
+    }
 }
 
-// cut [carry | fill] of the current window; hash all complete chunks in the background; when not
-// `final` the tail chunk stays open and its bytes move to the front of the next window buffer (a cut
-// only depends on bytes before it, so re-examining them with more data reproduces the serial chunker)
+// cut [carry | fill] of the current window; hand all complete chunks to the shared hash jobs; when not `final` the
+// tail chunk stays open and its bytes move to the front of the next window buffer (a cut only depends on bytes before
+// it, so re-examining them with more data reproduces the serial chunker)
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int stream_flush(pbsgpu_stream *s, bool final) {
     pbsgpu_engine *e = s->eng;
     const uint64_t total = s->carry + s->fill;
     if (total == 0) return PBSGPU_OK;
-    std::lock_guard<std::mutex> lk(e->mu);
     CHK(set_device(e));
-    HIPCHK(hipStreamSynchronize(s->copy_stream));
-    Slot *slot = find_free_slot(e);
-    while (!slot) {
-        if (s->inflight.empty()) return PBSGPU_E_BUSY;  // slots held by other users of the engine
-        CHK(stream_complete_oldest(s));
-        slot = find_free_slot(e);
+    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
+    const double t0 = trace ? now_ms() : 0;
+    double t_cut = 0, t_rb = 0, t_app = 0;
+    // the cut waits for the window's copies on the device, not on the host
+    HIPCHK(hipEventRecord(s->copied, s->copy_stream));
+    HIPCHK(hipStreamWaitEvent(s->cut.stream, s->copied, 0));
+    uint8_t *const bufp = s->dev[s->cur].as<uint8_t>();  // raw pointer: the ring (a vector) may grow below
+    // suggested boundaries that can still matter: at or after the open chunk's start, inside this window
+    while (!s->suggested.empty() && s->suggested.front() <= s->base) s->suggested.pop_front();
+    s->sugg_rel.clear();
+    for (uint64_t b : s->suggested) {
+        if (b > s->base + total) break;
+        s->sugg_rel.push_back(b - s->base);
     }
-    DevBuf &buf = s->dev[s->cur];
+    const uint32_t sidx[2] = {0u, (uint32_t)s->sugg_rel.size()};
+    SuggestedHost sg{s->sugg_rel.data(), sidx};
     uint64_t nrec = 0;
     pbsgpu_segment seg{0, total};
-    CHK(cut_sync(e, *slot, buf.as<uint8_t>(), total, &seg, 1, &nrec));
+    CHK(cut_sync(e, s->cut, bufp, total, &seg, 1, s->sugg_rel.empty() ? nullptr : &sg, &nrec));
     const uint64_t nemit = final ? nrec : (nrec ? nrec - 1 : 0);
-    pbsgpu_record open{};
-    if (!final && nrec) {
-        HIPCHK(hipMemcpy(&open, slot->recs.as<pbsgpu_record>() + (nrec - 1), sizeof(open), hipMemcpyDeviceToHost));
+    if (trace) t_cut = now_ms();
+    if (nrec) {
+        CHK(s->h_recs.ensure((size_t)nrec * sizeof(pbsgpu_record)));
+        HIPCHK(pbsk::launch_publish(s->h_recs.p, s->cut.recs.p, (size_t)nrec * sizeof(pbsgpu_record), s->cut.stream));
+        HIPCHK(hipStreamSynchronize(s->cut.stream));
     }
+    const pbsgpu_record *hr = s->h_recs.as<pbsgpu_record>();
+    if (trace) t_rb = now_ms();
     if (nemit) {
-        CHK(hash_async(e, *slot, nemit));
-        slot->busy = true;
-        slot->ticket = ~0ull;  // owned by the stream, never collectable through the batch API
-        s->dev_busy[s->cur] = 1;
         WindowInFlight w;
-        w.slot = slot;
         w.buf = s->cur;
-        w.base = s->base;
-        w.section = s->section;
-        w.nemit = nemit;
-        s->inflight.push_back(w);
+        w.recs.resize((size_t)nemit);
+        s->descs.resize((size_t)nemit);
+        for (uint64_t i = 0; i < nemit; ++i) {
+            s->descs[(size_t)i] = pbsk::HashDesc{bufp + (hr[i].end - hr[i].size), hr[i].size};
+            pbsgpu_record r{};
+            r.end = hr[i].end + s->base;
+            r.size = hr[i].size;
+            r.segment = s->section;
+            w.recs[(size_t)i] = r;
+        }
+        CHK(hd_append(e, s->descs.data(), (uint32_t)nemit, &w.job, &w.first));
+        s->dev_busy[s->cur] = 1;
+        s->inflight.push_back(std::move(w));
     }
+    if (trace) t_app = now_ms();
     if (final || nrec == 0) {
         s->base += total;
         s->carry = 0;
-        if (nemit) {  // the buffer is still being read by the SHA kernel: continue in another one
-            int nb = stream_free_buffer(s);
-            while (nb < 0) {
-                CHK(stream_complete_oldest(s));
-                nb = stream_free_buffer(s);
-            }
+        if (nemit) {  // the buffer is still being read by a hash job: continue in another one
+            int nb = -1;
+            CHK(stream_free_buffer(s, &nb));
             s->cur = nb;
         }
     } else {
+        const pbsgpu_record &open = hr[nrec - 1];
         const uint64_t open_start = open.end - open.size;
-        int nb = stream_free_buffer(s);
-        while (nb < 0) {
-            CHK(stream_complete_oldest(s));
-            nb = stream_free_buffer(s);
-        }
-        HIPCHK(hipMemcpyAsync(s->dev[nb].p, buf.as<uint8_t>() + open_start, open.size, hipMemcpyDeviceToDevice,
+        int nb = -1;
+        CHK(stream_free_buffer(s, &nb));
+        // ordered on the copy stream in front of the next window's H2D pieces; the source buffer is either held by the
+        // window above or, if it emitted nothing, only ever rewritten by later copies on this same stream
+        HIPCHK(hipMemcpyAsync(s->dev[nb].p, bufp + open_start, open.size, hipMemcpyDeviceToDevice,
                               s->copy_stream));
-        HIPCHK(hipStreamSynchronize(s->copy_stream));
         s->base += open_start;
         s->carry = open.size;
         s->cur = nb;
     }
     s->fill = 0;
+    if (trace)
+        fprintf(stderr, "[pbsgpu] stream %p window %.1f MiB: cut %.2f ms, readback %.2f ms, hash append %.2f ms, next buffer "
+                        "%.2f ms; %zu windows in flight, ring %zu\n", (void *)s, total / 1048576.0, t_cut - t0, t_rb - t_cut,
+                t_app - t_rb, now_ms() - t_app, s->inflight.size(), s->dev.size());
     return PBSGPU_OK;
 }
 
-// non-blocking: collect windows whose SHA kernel has finished
+// non-blocking: deliver windows whose hash job has finished
 int stream_reap(pbsgpu_stream *s) {
-    std::lock_guard<std::mutex> lk(s->eng->mu);
     CHK(set_device(s->eng));
     while (!s->inflight.empty()) {
-        hipError_t q = hipStreamQuery(s->inflight.front().slot->stream);
-        if (q == hipErrorNotReady) {
-            (void)hipGetLastError();
-            break;
-        }
-        if (q != hipSuccess) {
-            g_last_hip_error.store((int)q);
-            return PBSGPU_E_HIP;
-        }
-        CHK(stream_complete_oldest(s));
+        const int st = stream_complete_oldest(s, false);
+        if (st == PBSGPU_E_BUSY) break;
+        CHK(st);
     }
     return PBSGPU_OK;
 }
 
 int stream_drain(pbsgpu_stream *s) {
-    std::lock_guard<std::mutex> lk(s->eng->mu);
     CHK(set_device(s->eng));
-    while (!s->inflight.empty()) CHK(stream_complete_oldest(s));
+    while (!s->inflight.empty()) CHK(stream_complete_oldest(s, true));
+    return PBSGPU_OK;
+}
+
+// H2D of one staged piece behind the window's current fill
+int stream_push_piece(pbsgpu_stream *s, int k, size_t n) {
+    HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->carry + s->fill, s->stage[k].p, n, hipMemcpyHostToDevice,
+                          s->copy_stream));
+    HIPCHK(hipEventRecord(s->stage_ev[k], s->copy_stream));
+    s->stage_idx = (k + 1) % kStreamStages;
+    s->fill += n;
+    s->written += n;
+    if (s->fill == s->window) CHK(stream_flush(s, false));
     return PBSGPU_OK;
 }
 
@@ -187,6 +401,7 @@ int stream_drain(pbsgpu_stream *s) {
 // -------------------------------------------------------------------------------------
 struct pbsgpu_chunker {
     pbsgpu_engine *eng = nullptr;
+    Slot ctx;                 // private scan context
     uint64_t chunk_size = 0;  // bytes consumed since the last cut
     uint8_t tail[63];         // last bytes consumed (window continuity across calls)
     uint32_t tail_len = 0;
@@ -222,22 +437,29 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     if (window_bytes < e->cfg.max) window_bytes = e->cfg.max;
     pbsgpu_stream *s = new (std::nothrow) pbsgpu_stream();
     if (!s) return PBSGPU_E_NOMEM;
+    engine_ref(e);
     s->eng = e;
     s->window = window_bytes;
-    int st;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        st = set_device(e);
-        const size_t devcap = (size_t)window_bytes + (size_t)e->cfg.max + 256;
-        const size_t nbuf = e->slots.size() + 1;  // one being filled + one per hashing window
-        s->dev.resize(nbuf);
-        s->dev_busy.assign(nbuf, 0);
-        for (size_t i = 0; i < nbuf && st == PBSGPU_OK; ++i) st = s->dev[i].ensure(devcap);
-        for (int i = 0; i < 2 && st == PBSGPU_OK; ++i) st = s->stage[i].ensure(kStreamStage);
-        if (st == PBSGPU_OK && hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
-        for (int i = 0; i < 2 && st == PBSGPU_OK; ++i)
-            if (hipEventCreateWithFlags(&s->stage_ev[i], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
+    s->devcap = (size_t)window_bytes + (size_t)e->cfg.max + 256;
+    // ring limit: enough windows in flight to cover the hash latency (~0.5 s) at this stream's ingest rate, within ~6 GiB
+    size_t nb = (size_t)((6ull << 30) / s->devcap);
+    if (const char *v = getenv("PBSGPU_STREAM_WINDOWS")) nb = (size_t)atol(v);
+    s->max_bufs = std::min<size_t>(std::max<size_t>(nb, 3), 64);
+    int st = set_device(e);
+    if (st == PBSGPU_OK) st = s->cut.init();
+    // everything a window can need is allocated here: a regrow later (hipFree / hipHostFree) would wait for the whole
+    // device, i.e. for other windows' running hash jobs
+    if (st == PBSGPU_OK) st = presize_cut(e, s->cut, s->devcap);
+    if (st == PBSGPU_OK) st = s->h_recs.ensure((s->devcap / std::min(e->effmin, e->cfg.min) + 4) * sizeof(pbsgpu_record));
+    if (st == PBSGPU_OK) {
+        s->dev.resize(2);
+        s->dev_busy.assign(2, 0);
+        st = s->dev[0].ensure(s->devcap);
     }
+    if (st == PBSGPU_OK && hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+    if (st == PBSGPU_OK && hipEventCreateWithFlags(&s->copied, hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
+    for (int i = 0; i < kStreamStages && st == PBSGPU_OK; ++i)
+        if (hipEventCreateWithFlags(&s->stage_ev[i], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
     if (st != PBSGPU_OK) {
         pbsgpu_stream_destroy(s);
         return st;
@@ -248,45 +470,47 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
 
 void pbsgpu_stream_destroy(pbsgpu_stream *s) {
     if (!s) return;
-    if (s->eng) {
+    pbsgpu_engine *e = s->eng;
+    if (e) {
+        (void)hipSetDevice(e->device);
         (void)stream_drain(s);
-        std::lock_guard<std::mutex> lk(s->eng->mu);
-        (void)hipSetDevice(s->eng->device);
+        while (!s->inflight.empty()) {  // drain failed (HIP error): drop the references so the jobs can be reused
+            s->inflight.front().job->refs.fetch_sub(1);
+            s->inflight.pop_front();
+        }
         if (s->copy_stream) {
             (void)hipStreamSynchronize(s->copy_stream);
             (void)hipStreamDestroy(s->copy_stream);
         }
+        s->cut.destroy();
+        if (s->copied) (void)hipEventDestroy(s->copied);
         for (auto &b : s->dev) b.release();
         for (auto &b : s->stage) b.release();
+        s->h_recs.release();
         for (auto &ev : s->stage_ev)
             if (ev) (void)hipEventDestroy(ev);
     }
     delete s;
+    if (e) engine_unref(e);
 }
 
 int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
     if (!s || (!data && len)) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
+    if (len) CHK(set_device(s->eng));
     const uint8_t *p = static_cast<const uint8_t *>(data);
     while (len) {
         size_t n = (size_t)std::min<uint64_t>(len, s->window - s->fill);
         n = std::min(n, kStreamStage);
-        {   // caller bytes -> library-owned pinned staging -> device window (async on the copy stream)
-            std::lock_guard<std::mutex> lk(s->eng->mu);
-            CHK(set_device(s->eng));
-            const int k = s->stage_idx;
-            HIPCHK(hipEventSynchronize(s->stage_ev[k]));
-            std::memcpy(s->stage[k].p, p, n);
-            HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->carry + s->fill, s->stage[k].p, n,
-                                  hipMemcpyHostToDevice, s->copy_stream));
-            HIPCHK(hipEventRecord(s->stage_ev[k], s->copy_stream));
-            s->stage_idx ^= 1;
-        }
-        s->fill += n;
-        s->written += n;
+        // caller bytes -> library-owned pinned staging -> device window (async on the copy stream); the memcpy runs on
+        // the caller's thread with no lock held, so several streams copy in parallel
+        const int k = s->stage_idx;
+        CHK(s->stage[k].ensure(kStreamStage));
+        HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
+        std::memcpy(s->stage[k].p, p, n);
+        CHK(stream_push_piece(s, k, n));
         p += n;
         len -= n;
-        if (s->fill == s->window) CHK(stream_flush(s, false));
     }
     return PBSGPU_OK;
 }
@@ -294,9 +518,9 @@ int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
 int pbsgpu_stream_reserve(pbsgpu_stream *s, void **buf, size_t *cap) {
     if (!s || !buf || !cap) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
-    std::lock_guard<std::mutex> lk(s->eng->mu);
     CHK(set_device(s->eng));
     const int k = s->stage_idx;
+    CHK(s->stage[k].ensure(kStreamStage));
     HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
     s->reserved = k;
     *buf = s->stage[k].p;
@@ -311,23 +535,22 @@ int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len) {
     if (len > (size_t)std::min<uint64_t>(kStreamStage, s->window - s->fill)) return PBSGPU_E_INVALID;
     s->reserved = -1;
     if (len == 0) return PBSGPU_OK;
-    {
-        std::lock_guard<std::mutex> lk(s->eng->mu);
-        CHK(set_device(s->eng));
-        HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->carry + s->fill, s->stage[k].p, len,
-                              hipMemcpyHostToDevice, s->copy_stream));
-        HIPCHK(hipEventRecord(s->stage_ev[k], s->copy_stream));
-        s->stage_idx ^= 1;
-    }
-    s->fill += len;
-    s->written += len;
-    if (s->fill == s->window) CHK(stream_flush(s, false));
+    CHK(set_device(s->eng));
+    return stream_push_piece(s, k, len);
+}
+
+int pbsgpu_stream_suggest(pbsgpu_stream *s, uint64_t offset) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->finished) return PBSGPU_E_STATE;
+    if (!s->suggested.empty() && offset < s->suggested.back()) return PBSGPU_E_INVALID;  // ascending, like the channel
+    if (offset <= s->base) return PBSGPU_OK;  // at or before the open chunk's start: in the past, ignored
+    s->suggested.push_back(offset);
     return PBSGPU_OK;
 }
 
 int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
     if (!s) return PBSGPU_E_INVALID;
-    if (s->finished) return PBSGPU_E_STATE;
+    if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
     CHK(stream_flush(s, true));
     s->base += inject_bytes;
     s->inject_total += inject_bytes;
@@ -338,6 +561,7 @@ int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
 int pbsgpu_stream_finish(pbsgpu_stream *s) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished) return PBSGPU_OK;
+    if (s->reserved >= 0) return PBSGPU_E_STATE;
     CHK(stream_flush(s, true));
     CHK(stream_drain(s));
     s->finished = true;
@@ -356,7 +580,16 @@ int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint6
     return PBSGPU_OK;
 }
 
-int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *bytes_written) {
+int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *position) {
+    if (!s || !position) return PBSGPU_E_INVALID;
+    // Encoder().PayloadPosition() semantics (commit_reuse.go:265): bytes written PLUS bytes injected — InjectChunks
+    // advances the payload position by the injected sizes (keepLast_chunk_test.go: enc.Advance(total)), and the
+    // record `end` offsets live in the same coordinates
+    *position = s->written + s->inject_total;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_bytes_written(const pbsgpu_stream *s, uint64_t *bytes_written) {
     if (!s || !bytes_written) return PBSGPU_E_INVALID;
     *bytes_written = s->written;
     return PBSGPU_OK;
@@ -368,14 +601,12 @@ int pbsgpu_chunker_create(pbsgpu_engine *e, pbsgpu_chunker **out) {
     *out = nullptr;
     pbsgpu_chunker *c = new (std::nothrow) pbsgpu_chunker();
     if (!c) return PBSGPU_E_NOMEM;
+    engine_ref(e);
     c->eng = e;
-    int st;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        st = set_device(e);
-        if (st == PBSGPU_OK) st = c->dev.ensure(kChunkerSlice + 256);
-        if (st == PBSGPU_OK) st = c->host.ensure(kChunkerSlice + 256);
-    }
+    int st = set_device(e);
+    if (st == PBSGPU_OK) st = c->ctx.init();
+    if (st == PBSGPU_OK) st = c->dev.ensure(kChunkerSlice + 256);
+    if (st == PBSGPU_OK) st = c->host.ensure(kChunkerSlice + 256);
     if (st != PBSGPU_OK) {
         pbsgpu_chunker_destroy(c);
         return st;
@@ -386,13 +617,15 @@ int pbsgpu_chunker_create(pbsgpu_engine *e, pbsgpu_chunker **out) {
 
 void pbsgpu_chunker_destroy(pbsgpu_chunker *c) {
     if (!c) return;
-    if (c->eng) {
-        std::lock_guard<std::mutex> lk(c->eng->mu);
-        (void)hipSetDevice(c->eng->device);
+    pbsgpu_engine *e = c->eng;
+    if (e) {
+        (void)hipSetDevice(e->device);
+        c->ctx.destroy();
         c->dev.release();
         c->host.release();
     }
     delete c;
+    if (e) engine_unref(e);
 }
 
 int pbsgpu_chunker_reset(pbsgpu_chunker *c) {
@@ -423,10 +656,8 @@ int pbsgpu_chunker_scan(pbsgpu_chunker *c, const void *data, size_t len, size_t 
         uint64_t ncand = 0;
         const uint32_t tl = c->tail_len;
         {
-            std::lock_guard<std::mutex> lk(e->mu);
             CHK(set_device(e));
-            Slot *slot = find_free_slot(e);
-            if (!slot) return PBSGPU_E_BUSY;
+            Slot *slot = &c->ctx;
             uint8_t *h = c->host.as<uint8_t>();
             std::memcpy(h, c->tail, tl);
             std::memcpy(h + tl, p + off, n);
@@ -491,13 +722,38 @@ int pbsgpu_payload_pack_device(pbsgpu_engine *e, const void *src, uint64_t src_b
     }
     if (fmt->with_tail) header(fmt->tail_type, 16);
     if (items.size() >= (1ull << 31)) return PBSGPU_E_INVALID;
-    std::lock_guard<std::mutex> lk(e->mu);
     CHK(set_device(e));
-    Slot *s = find_free_slot(e);
-    if (!s) return PBSGPU_E_BUSY;
+    AuxLease lease(e);
+    Slot *s = lease.s;
     const size_t bytes = items.size() * sizeof(pbsk::PackItem);
     CHK(s->tile_slots.ensure(bytes + 64));
-    CHK(staged_h2d(e, s->tile_slots.p, items.data(), bytes, s->stream));
+    CHK(staged_h2d(*s, s->tile_slots.p, items.data(), bytes, s->stream));
+    HIPCHK(pbsk::launch_pack(static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst),
+                             s->tile_slots.as<pbsk::PackItem>(), (uint32_t)items.size(), s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return PBSGPU_OK;
+}
+
+// ---- piece-table copy (synthetic corpus editing) -------------------------------------------------
+int pbsgpu_gather_device(pbsgpu_engine *e, const void *src, uint64_t src_bytes, void *dst, uint64_t dst_bytes,
+                         const pbsgpu_copy_item *its, uint32_t nitems) {
+    if (!e || (nitems && (!its || !src || !dst))) return PBSGPU_E_INVALID;
+    if (nitems == 0) return PBSGPU_OK;
+    constexpr uint64_t kPiece = 4ull << 20;
+    std::vector<pbsk::PackItem> items;
+    for (uint32_t i = 0; i < nitems; ++i) {
+        if (its[i].len > src_bytes || its[i].src_off > src_bytes - its[i].len) return PBSGPU_E_INVALID;
+        if (its[i].len > dst_bytes || its[i].dst_off > dst_bytes - its[i].len) return PBSGPU_E_INVALID;
+        for (uint64_t o = 0; o < its[i].len; o += kPiece)
+            items.push_back(pbsk::PackItem{its[i].src_off + o, its[i].dst_off + o, std::min<uint64_t>(kPiece, its[i].len - o), 0u, 0u});
+    }
+    if (items.size() >= (1ull << 31)) return PBSGPU_E_INVALID;
+    CHK(set_device(e));
+    AuxLease lease(e);
+    Slot *s = lease.s;
+    const size_t bytes = items.size() * sizeof(pbsk::PackItem);
+    CHK(s->tile_slots.ensure(bytes + 64));
+    CHK(staged_h2d(*s, s->tile_slots.p, items.data(), bytes, s->stream));
     HIPCHK(pbsk::launch_pack(static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst),
                              s->tile_slots.as<pbsk::PackItem>(), (uint32_t)items.size(), s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -511,10 +767,9 @@ int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, u
     if (n >= (1ull << 32)) return PBSGPU_E_INVALID;
     std::memset(stats, 0, sizeof(*stats));
     if (n == 0) return PBSGPU_OK;
-    std::lock_guard<std::mutex> lk(e->mu);
     CHK(set_device(e));
-    Slot *s = find_free_slot(e);
-    if (!s) return PBSGPU_E_BUSY;
+    AuxLease lease(e);
+    Slot *s = lease.s;
     const size_t tmp_bytes = pbsk::dedup_tmp_bytes(n);
     // layout inside slot buffers: recs | keys | keys_alt | idx | idx_alt | dup | stats | tmp
     CHK(s->recs.ensure((size_t)n * sizeof(pbsgpu_record)));
@@ -524,7 +779,7 @@ int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, u
     CHK(s->scalars.ensure(SC_COUNT * 4 + 64));
     CHK(s->scan_tmp.ensure(tmp_bytes));
     CHK(s->h_scalars.ensure(64));
-    CHK(staged_h2d(e, s->recs.p, recs, n * sizeof(pbsgpu_record), s->stream));
+    CHK(staged_h2d(*s, s->recs.p, recs, n * sizeof(pbsgpu_record), s->stream));
     uint64_t *keys = s->dense.as<uint64_t>();
     uint64_t *keys_alt = keys + n;
     uint32_t *idx = s->tile_slots.as<uint32_t>();

@@ -30,41 +30,98 @@ def shard_segments(lengths, world_size: int):
     return [sorted(x) for x in out]
 
 
-def allgather_records(records: np.ndarray, device=None, group=None) -> np.ndarray:
+def allgather_records(records: np.ndarray, device=None, group=None, cap_records: int | None = None) -> np.ndarray:
     """All-gather every rank's record array (variable length) -> concatenation in rank order.
 
-    One all_gather of the counts and one of the padded payload (uint8 view of the 48-byte
-    records). `device` = torch device for the communication buffers ("cuda:N" with RCCL,
-    None/"cpu" with gloo)."""
+    With `cap_records` (an upper bound every rank agrees on, e.g. bytes / min chunk size) this is ONE collective:
+    an all_gather_into_tensor of [count | padded 48-byte records]; without it the counts are exchanged first.
+    `device` = torch device of the communication buffers ("cuda:N" with RCCL, None/"cpu" with gloo)."""
     import torch
     import torch.distributed as dist
 
     ws = dist.get_world_size(group)
     recs = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
     dev = torch.device(device) if device is not None else torch.device("cpu")
-    cnt = torch.tensor([recs.size], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    payload = np.zeros(cap * RECORD_DTYPE.itemsize, dtype=np.uint8)
-    payload[: recs.size * RECORD_DTYPE.itemsize] = recs.view(np.uint8).reshape(-1)
+    isz = RECORD_DTYPE.itemsize
+    if cap_records is None:
+        cnt = torch.tensor([recs.size], dtype=torch.int64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+        dist.all_gather(counts, cnt, group=group)
+        cap_records = max(max(int(c.item()) for c in counts), 1)
+    if recs.size > cap_records:
+        raise ValueError(f"{recs.size} records exceed the agreed capacity {cap_records}")
+    row = 16 + cap_records * isz                       # 16-byte header keeps the records 16-byte aligned
+    payload = np.zeros(row, dtype=np.uint8)
+    payload[:8] = np.frombuffer(np.uint64(recs.size).tobytes(), dtype=np.uint8)
+    payload[16:16 + recs.size * isz] = recs.view(np.uint8).reshape(-1)
     mine = torch.from_numpy(payload).to(dev)
-    bufs = [torch.empty_like(mine) for _ in range(ws)]
-    dist.all_gather(bufs, mine, group=group)
+    out = torch.empty(ws * row, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    host = out.cpu().numpy().reshape(ws, row)
     parts = []
     for r in range(ws):
-        a = bufs[r].cpu().numpy()[: counts[r] * RECORD_DTYPE.itemsize]
-        parts.append(a.view(RECORD_DTYPE).copy())
+        n = int(host[r, :8].view(np.uint64)[0])
+        parts.append(host[r, 16:16 + n * isz].view(RECORD_DTYPE).copy())
     return np.concatenate(parts) if parts else np.zeros(0, dtype=RECORD_DTYPE)
 
 
-def global_dedup(engine, local_records: np.ndarray, device=None, group=None):
-    """Digest-set reduce: gather all ranks' records, then duplicate detection on this rank's
-    GPU (sort by digest prefix + compare, libpbsgpu). Returns (dup flags, stats, all records)."""
-    allrecs = allgather_records(local_records, device=device, group=group)
+def global_dedup(engine, local_records: np.ndarray, device=None, group=None, cap_records: int | None = None):
+    """Digest-set reduce: gather all ranks' records (one collective), then duplicate detection on this rank's
+    GPU (radix sort by digest prefix + compare, libpbsgpu). Returns (dup flags, stats, all records)."""
+    allrecs = allgather_records(local_records, device=device, group=group, cap_records=cap_records)
     dup, stats = engine.dedup(allrecs)
     return dup, stats, allrecs
+
+
+def ingest_corpus(engine, lengths, make_batch, device=None, group=None, max_batch_bytes: int = 64 << 30):
+    """End-to-end corpus ingest over all ranks: shard the segments (files) over the ranks, cut + hash
+    this rank's share batch by batch on its GPU, then ONE digest-set reduce (all-gather of the 48-byte records) and
+    duplicate detection. No data-path collective: segments are independent streams.
+
+    lengths      byte length of every segment of the corpus (same on every rank)
+    make_batch   callback(list of global segment indices) -> (device buffer, [(offset, length)] in that buffer);
+                 the caller owns how bytes reach HBM (generated, read from disk, received from agents)
+    Returns (records of this rank with GLOBAL segment ids, dedup stats over the whole corpus, all ranks' records)."""
+    import torch.distributed as dist
+
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lengths = np.asarray(lengths, dtype=np.uint64)
+    plan = shard_segments(lengths, ws)
+    mine = plan[rank]
+    # batches of <= max_batch_bytes, in segment order
+    batches, cur, cur_bytes = [], [], 0
+    for g in mine:
+        n = int(lengths[g])
+        if cur and cur_bytes + n > max_batch_bytes:
+            batches.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(g)
+        cur_bytes += n
+    if cur:
+        batches.append(cur)
+    parts, pending = [], []
+    for ids in batches:                      # two batches in flight: the next is generated while one hashes
+        buf, segs = make_batch(ids)
+        pending.append((ids, engine.submit(buf, segs, None if not isinstance(buf, int) else sum(n for _, n in segs))))
+        if len(pending) == 2:
+            parts.append(_collect_global(engine, *pending.pop(0)))
+    while pending:
+        parts.append(_collect_global(engine, *pending.pop(0)))
+    local = np.concatenate(parts) if parts else np.zeros(0, dtype=RECORD_DTYPE)
+    if ws > 1:
+        cap = max(int(sum(int(lengths[g]) for g in p) // max(1, engine.config.MinSize)) + 2 * len(p) + 16 for p in plan)
+        dup, stats, allrecs = global_dedup(engine, local, device=device, group=group, cap_records=cap)
+    else:
+        dup, stats = engine.dedup(local)
+        allrecs = local
+    return local, stats, allrecs
+
+
+def _collect_global(engine, ids, ticket):
+    recs = engine.collect(ticket)
+    recs["segment"] = np.asarray(ids, dtype=np.uint32)[recs["segment"]]   # batch-local -> global segment id
+    return recs
 
 
 # ---- one stream split over several GPUs -----------------------------------------------------------

@@ -112,17 +112,41 @@ class Engine:
         return None, None
 
     # ---- batch path ------------------------------------------------------------------------------
-    def submit(self, data, segments=None, nbytes: int | None = None) -> int:
-        """Enqueue cut + digest of every segment; returns a ticket."""
+    def submit(self, data, segments=None, nbytes: int | None = None, suggested=None) -> int:
+        """Enqueue cut + digest of every segment; returns a ticket. `suggested` = one ascending list of suggested
+        boundaries per segment (relative to the segment start; payload-chunker rule, see pbsgpu.h)."""
         segs, nseg = _segs(segments)
         t = C.c_uint64()
         ptr, n = self._dev(data, nbytes)
+        if suggested is not None:
+            ns = max(nseg, 1)
+            assert len(suggested) == ns, "one suggested-boundary list per segment"
+            flat = (np.concatenate([np.asarray(x, dtype=np.uint64).reshape(-1) for x in suggested])
+                    if ns else np.zeros(0, np.uint64))
+            flat = np.ascontiguousarray(flat, dtype=np.uint64)
+            idx = np.zeros(ns + 1, dtype=np.uint32)
+            idx[1:] = np.cumsum([len(x) for x in suggested])
+            fp = flat.ctypes.data if flat.size else None
+            if ptr is not None:
+                check(self._L.pbsgpu_submit_device_suggested(self._h, ptr, n, segs, nseg, fp, idx.ctypes.data,
+                                                             C.byref(t)), "submit_device_suggested")
+            else:
+                a = _host_view(data)
+                check(self._L.pbsgpu_submit_host_suggested(self._h, a.ctypes.data, a.size, segs, nseg, fp,
+                                                           idx.ctypes.data, C.byref(t)), "submit_host_suggested")
+            return t.value
         if ptr is not None:
             check(self._L.pbsgpu_submit_device(self._h, ptr, n, segs, nseg, C.byref(t)), "submit_device")
         else:
             a = _host_view(data)
             check(self._L.pbsgpu_submit_host(self._h, a.ctypes.data, a.size, segs, nseg, C.byref(t)), "submit_host")
         return t.value
+
+    def h2d_bandwidth(self, nbytes: int = 1 << 30) -> float:
+        """Measured pinned host -> device copy rate of this box in GB/s."""
+        v = C.c_double()
+        check(self._L.pbsgpu_measure_h2d(self._h, int(nbytes), C.byref(v)), "measure_h2d")
+        return float(v.value)
 
     def wait(self, ticket: int) -> int:
         n = C.c_uint64()
@@ -147,8 +171,8 @@ class Engine:
         check(self._L.pbsgpu_collect(self._h, ticket, out.ctypes.data, n, C.byref(got)), "collect")
         return out[: got.value]
 
-    def chunk_and_digest(self, data, segments=None, nbytes: int | None = None) -> np.ndarray:
-        return self.collect(self.submit(data, segments, nbytes))
+    def chunk_and_digest(self, data, segments=None, nbytes: int | None = None, suggested=None) -> np.ndarray:
+        return self.collect(self.submit(data, segments, nbytes, suggested))
 
     def candidates(self, data, nbytes: int | None = None) -> np.ndarray:
         """Raw Buzhash candidates (ascending END offsets) of a device byte range."""
@@ -219,6 +243,14 @@ class Engine:
         check(self._L.pbsgpu_payload_pack_device(self._h, sp, sn, segs, n, C.byref(fmt), dp, dn, C.byref(out_len),
                                                  offs.ctypes.data), "payload_pack_device")
         return out_len.value, offs[:n]
+
+    def gather(self, src, dst, items) -> None:
+        """Piece-table copy on the device: items = (n, 3) uint64 rows (src_off, dst_off, len)."""
+        a = np.ascontiguousarray(items, dtype=np.uint64).reshape(-1, 3)
+        sp, sn = self._dev(src)
+        dp, dn = self._dev(dst)
+        check(self._L.pbsgpu_gather_device(self._h, sp, sn, dp, dn, a.ctypes.data if a.size else None, a.shape[0]),
+              "gather_device")
 
     # ---- digest set ------------------------------------------------------------------------------------
     def dedup(self, records: np.ndarray):
@@ -301,9 +333,20 @@ class PayloadStream:
         return np.concatenate(outs) if outs else np.zeros(0, dtype=RECORD_DTYPE)
 
     def position(self) -> int:
+        """Encoder().PayloadPosition(): bytes written + bytes injected (the records' coordinate system)."""
         n = C.c_uint64()
         check(self._L.pbsgpu_stream_position(self._h, C.byref(n)), "stream_position")
         return n.value
+
+    def bytes_written(self) -> int:
+        n = C.c_uint64()
+        check(self._L.pbsgpu_stream_bytes_written(self._h, C.byref(n)), "stream_bytes_written")
+        return n.value
+
+    def suggest(self, offset: int | None = None) -> None:
+        """Suggest a chunk boundary at absolute payload position `offset` (default: here)."""
+        check(self._L.pbsgpu_stream_suggest(self._h, self.position() if offset is None else int(offset)),
+              "stream_suggest")
 
     def close(self):
         if getattr(self, "_h", None):

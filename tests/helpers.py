@@ -25,6 +25,29 @@ def resolve_model(cands, seg_len, cmin, cmax):
     return np.asarray(ends, dtype=np.uint64)
 
 
+def resolve_model_suggested(cands, sugg, seg_len, cmin, cmax):
+    """k_resolve with suggested boundaries: after a cut at s the next cut is the EARLIER of the hash/max cut and the
+    first suggested boundary b with b - s >= min (those closer than min are dropped for good); b wins only when
+    b < hash cut <= s + max. Must equal the payload chunker fed byte by byte."""
+    effmin = max(cmin, 65)
+    cands = np.asarray(cands, dtype=np.uint64)
+    sugg = np.asarray(sorted(sugg), dtype=np.uint64)
+    ends = []
+    s = 0
+    while s < seg_len:
+        tlo, thi = s + effmin, s + cmax
+        j = int(np.searchsorted(cands, tlo, side="left"))
+        c = int(cands[j]) if j < cands.size else None
+        e = c if (c is not None and c < thi) else thi
+        e = min(e, seg_len)
+        k = int(np.searchsorted(sugg, s + cmin, side="left"))
+        if k < sugg.size and int(sugg[k]) < e:
+            e = int(sugg[k])
+        ends.append(e)
+        s = e
+    return np.asarray(ends, dtype=np.uint64)
+
+
 def records_equal(a, b):
     if a.shape != b.shape:
         return False

@@ -1,0 +1,376 @@
+"""Round-2 GPU parity tests (through the C ABI, against the CPU oracle, bit-exact): suggested boundaries
+(payload chunker), PayloadPosition with injected bytes, many streams / threads sharing one engine without
+E_BUSY, >4096 segments per submit, 16 tickets in flight, dense-tile compaction, the piece-table gather, the
+shared hash jobs of the streaming writer at production chunk size, and handle lifetime."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import describe_mismatch, records_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines(gpu_lib):
+    from pbs_plus_amd import Engine, buzhash
+
+    cache = {}
+
+    def get(avg, inflight=2):
+        if (avg, inflight) not in cache:
+            cache[(avg, inflight)] = Engine(buzhash.NewConfig(avg), device=0, inflight=inflight)
+        return cache[(avg, inflight)]
+
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def random_suggestions(rng, seg_len, cfg, n):
+    """ascending suggested boundaries that hit every branch: closer than min, exactly min / max apart, duplicates,
+    beyond max, at and past the segment end"""
+    pts = set(int(x) for x in rng.integers(1, max(2, seg_len), n))
+    base = int(rng.integers(0, max(1, seg_len // 2)))
+    pts |= {base + cfg.min, base + cfg.min - 1, base + cfg.max, base + cfg.max + 1, seg_len, seg_len + 5, 64, 65}
+    out = sorted(p for p in pts if p > 0)
+    return out + out[:3]  # a few duplicates; re-sorted below
+
+
+@pytest.mark.parametrize("avg", [256, 4096, 65536])
+def test_suggested_boundaries_match_the_payload_chunker(engines, O, avg):
+    """pbsgpu_submit_*_suggested == oracle_payload_chunker_scan fed byte by byte (SURVEY.md Appendix A note 3)."""
+    eng = engines(avg)
+    cfg = O.new_config(avg)
+    rng = np.random.default_rng(avg)
+    lens = [avg * 37 + 13, 0, avg * 5, 63, avg * 61 + 1, avg // 2]
+    kinds = [0, 0, 1, 0, 3, 0]          # a zero run: only max-size cuts unless a suggestion intervenes
+    segs, off = [], 0
+    for n in lens:
+        segs.append((off, n))
+        off += (n + 7) & ~7
+    data = np.zeros(max(off, 8), dtype=np.uint8)
+    for (o, n), k, i in zip(segs, kinds, range(len(segs))):
+        if n:
+            data[o:o + n] = O.fill(n, 900 + i, k)
+    sugg = [sorted(random_suggestions(rng, n, cfg, 40)) for _, n in segs]
+    want = O.chunk_and_digest_suggested(cfg, data, segs, sugg)
+    plain = O.chunk_and_digest(cfg, data, segs)
+    assert want.size != plain.size or not np.array_equal(want["end"], plain["end"])  # the suggestions do change cuts
+    got = eng.chunk_and_digest(data, segs, suggested=sugg)          # host submit
+    assert records_equal(got, want), describe_mismatch(got, want)
+    buf = eng.alloc(data.size)
+    buf.upload(data)
+    got = eng.chunk_and_digest(buf, segs, suggested=sugg)           # device submit
+    assert records_equal(got, want), describe_mismatch(got, want)
+    # no suggestions given == the plain entry point
+    got = eng.chunk_and_digest(buf, segs, suggested=[[] for _ in segs])
+    assert records_equal(got, plain)
+    buf.free()
+
+
+def test_upstream_suggested_boundary_vector_on_gpu(engines, O):
+    """The chunk sizes recalled from upstream Proxmox's test_suggested_boundary (LE u32 counter buffer, avg 64 KiB):
+    [32768, 110609, 229376, 32768, 262144, 262144, 118767] — see tests/test_oracle_buzhash.py for the provenance."""
+    eng = engines(65536)
+    data = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
+    got = eng.chunk_and_digest(data, None, suggested=[[32 * 1024, 32 * 1024, 372753, 405521]])
+    assert np.diff(np.concatenate([[0], got["end"]])).astype(int).tolist() == \
+        [32768, 110609, 229376, 32768, 262144, 262144, 118767]
+
+
+def test_stream_position_counts_injected_bytes(engines, O):
+    """Encoder().PayloadPosition() after InjectChunks (commit_reuse.go:265, keepLast_chunk_test.go enc.Advance):
+    position = written + injected = the coordinate system of the record ends."""
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4096)
+    a, b = O.fill(150_000, 5), O.fill(70_001, 6)
+    ps = PayloadStream(eng, window_bytes=1 << 17)
+    ps.write(a)
+    assert ps.position() == a.size and ps.bytes_written() == a.size
+    ps.inject(1_000_000)
+    assert ps.position() == a.size + 1_000_000 and ps.bytes_written() == a.size
+    ps.write(b)
+    ps.finish()
+    recs = ps.poll()
+    assert ps.position() == a.size + 1_000_000 + b.size
+    assert int(recs["end"][-1]) == ps.position()
+    ps.close()
+
+
+def test_stream_suggest_matches_the_payload_chunker(engines, O):
+    """pbsgpu_stream_suggest at absolute payload positions, windows + carry-over, an inject in the middle."""
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(77)
+    a, b = O.fill(700_003, 11, 3), O.fill(400_000, 12, 0)
+    sa = sorted(int(x) for x in rng.integers(1, a.size, 60))
+    sb = sorted(int(x) for x in rng.integers(1, b.size, 30))
+    inj = 123_456
+    ps = PayloadStream(eng, window_bytes=1 << 16)
+    pos, si = 0, 0
+    while pos < a.size:                       # suggestions are sent when the writer reaches them ("a file starts here")
+        nxt = sa[si] if si < len(sa) else a.size
+        n = min(int(rng.integers(1, 50_000)), max(nxt - pos, 1), a.size - pos)
+        ps.write(a[pos:pos + n])
+        pos += n
+        while si < len(sa) and sa[si] <= pos:
+            ps.suggest()                      # == ps.suggest(pos): "a file starts here"
+            si += 1
+    ps.inject(inj)
+    for x in sb:                              # all boundaries of the second section announced ahead of the bytes
+        ps.suggest(a.size + inj + x)
+    ps.write(b)
+    ps.finish()
+    got = ps.poll()
+    wa = O.chunk_and_digest_suggested(cfg, a, [(0, a.size)], [sa])
+    wb = O.chunk_and_digest_suggested(cfg, b, [(0, b.size)], [sb])
+    want_end = np.concatenate([wa["end"], wb["end"] + np.uint64(a.size + inj)])
+    assert np.array_equal(got["end"], want_end), (got["end"][:8], want_end[:8])
+    assert np.array_equal(got["digest"], np.concatenate([wa["digest"], wb["digest"]]))
+    ps.close()
+
+
+def test_many_streams_and_batches_share_one_engine(engines, O):
+    """8 writer threads (one PayloadStream each) + 2 batch threads + helper calls on ONE engine with 2 ticket
+    slots: nothing ever answers E_BUSY except a batch submit with both tickets out, and every result is exact."""
+    from pbs_plus_amd import PayloadStream, PbsGpuError, _lib
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    datas = [O.fill(900_000 + 7777 * i, 500 + i, i % 4) for i in range(8)]
+    wants = [O.chunk_and_digest(cfg, d) for d in datas]
+    errors = []
+
+    def writer(i):
+        try:
+            for rep in range(3):
+                ps = PayloadStream(eng, window_bytes=(1 << 16) << (i % 3))
+                rng = np.random.default_rng(i * 10 + rep)
+                pos = 0
+                while pos < datas[i].size:
+                    n = int(rng.integers(1, 120_000))
+                    ps.write(datas[i][pos:pos + n])
+                    pos += n
+                ps.finish()
+                got = ps.poll()
+                if not (np.array_equal(got["end"], wants[i]["end"]) and np.array_equal(got["digest"], wants[i]["digest"])):
+                    errors.append((i, "stream mismatch"))
+                ps.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    def batcher(i):
+        try:
+            for _ in range(6):
+                while True:
+                    try:
+                        got = eng.chunk_and_digest(datas[i])
+                        break
+                    except PbsGpuError as exc:      # both tickets held by the other batch thread: legal for submit only
+                        if exc.status != _lib.E_BUSY:
+                            raise
+                if not records_equal(got, wants[i]):
+                    errors.append((i, "batch mismatch"))
+                d = eng.sha256_many(datas[i], [(0, 1000), (5, datas[i].size - 5)])
+                import hashlib
+                if bytes(d[1]) != hashlib.sha256(datas[i][5:].tobytes()).digest():
+                    errors.append((i, "sha256_many mismatch"))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    ts = [threading.Thread(target=writer, args=(i,)) for i in range(8)] + \
+         [threading.Thread(target=batcher, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a thread hung"
+    assert not errors, errors
+
+
+def test_helper_calls_wait_for_a_context_instead_of_failing(engines, O):
+    """with every ticket slot held by uncollected batches, streams, chunkers and the synchronous helpers
+    still work (they own / lease their contexts); 8 threads of helper calls queue for the 4 aux contexts."""
+    import hashlib
+
+    import xxhash
+
+    from pbs_plus_amd import Chunker, PayloadStream
+
+    eng = engines(4096, 1)
+    cfg = O.new_config(4096)
+    data = O.fill(600_000, 31, 0)
+    held = eng.submit(data)                 # the only ticket slot stays occupied during everything below
+    ps = PayloadStream(eng, window_bytes=1 << 17)
+    ps.write(data)
+    ps.finish()
+    want = O.chunk_and_digest(cfg, data)
+    got = ps.poll()
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    ps.close()
+    ck = Chunker(eng)
+    assert ck.scan(data) == int(want["end"][0])
+    ck.close()
+    errors = []
+
+    def helper(i):
+        try:
+            for _ in range(5):
+                seg = [(i * 100, 50_000 + i)]
+                if bytes(eng.sha256_many(data, seg)[0]) != hashlib.sha256(data[i * 100:i * 100 + 50_000 + i].tobytes()).digest():
+                    errors.append("sha")
+                if int(eng.xxh3_many(data, seg)[0]) != xxhash.xxh3_64_intdigest(data[i * 100:i * 100 + 50_000 + i].tobytes()):
+                    errors.append("xxh3")
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    ts = [threading.Thread(target=helper, args=(i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert records_equal(eng.collect(held), want)
+
+
+def test_more_than_4096_segments_in_one_submit(engines, O):
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(4096)
+    lens = rng.integers(0, 40_000, 6000)
+    lens[::97] = 0
+    segs, off = [], 0
+    for n in lens:
+        segs.append((off, int(n)))
+        off += (int(n) + 7) & ~7
+    data = O.fill(off, 8, 3)
+    want = O.chunk_and_digest(cfg, data, segs)
+    got = eng.chunk_and_digest(data, segs)
+    assert records_equal(got, want), describe_mismatch(got, want)
+
+
+def test_sixteen_tickets_in_flight_collected_out_of_order(engines, O):
+    eng = engines(65536, 16)
+    cfg = O.new_config(65536)
+    n = 3 << 20
+    bufs, wants = [], []
+    for i in range(16):
+        b = eng.alloc(n)
+        eng.fill(b.ptr, n, 700 + i, i % 4)
+        bufs.append(b)
+        wants.append(O.chunk_and_digest(cfg, O.fill(n, 700 + i, i % 4)))
+    for rep in range(2):
+        tickets = [eng.submit(b, None, n) for b in bufs]
+        from pbs_plus_amd import PbsGpuError, _lib
+        with pytest.raises(PbsGpuError) as ei:
+            eng.submit(bufs[0], None, n)            # a 17th: the documented E_BUSY
+        assert ei.value.status == _lib.E_BUSY
+        order = list(np.random.default_rng(rep).permutation(16))
+        for i in order:
+            got = eng.collect(tickets[i])
+            assert records_equal(got, wants[i]), (i, describe_mismatch(got, wants[i]))
+    for b in bufs:
+        b.free()
+
+
+def test_dense_tiles_compact_in_order_at_the_large_tile_size(engines, O):
+    """k_compact's per-tile sort must stay linear on crafted input. 64 MiB of a 64-byte-periodic block
+    that hits the break test: ~one candidate per period, thousands per 272 KiB scan tile (counting-sort path)."""
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(123)
+    for _ in range(4000):
+        block = rng.integers(0, 256, 64, dtype=np.uint8)
+        if O.candidates(cfg, np.tile(block, 4)).size:
+            break
+    else:
+        pytest.skip("no dense pattern found")
+    data = np.tile(block, (64 << 20) // 64)
+    buf = eng.alloc(data.size)
+    buf.upload(data)
+    got = eng.candidates(buf, data.size)
+    want = O.candidates(cfg, data)
+    assert want.size >= (1 << 20) - 4
+    assert np.array_equal(got, want)
+    buf.free()
+
+
+def test_gather_applies_a_piece_table(engines):
+    eng = engines(4096)
+    rng = np.random.default_rng(9)
+    src = rng.integers(0, 256, 3_000_017, dtype=np.uint8)
+    sb = eng.alloc(src.size)
+    sb.upload(src)
+    items, pos = [], 0
+    for _ in range(300):
+        ln = int(rng.integers(1, 40_000))
+        so = int(rng.integers(0, src.size - ln))
+        items.append((so, pos, ln))
+        pos += ln
+    items.append((5, pos, 2_900_000))      # a piece that is split internally (4 MiB work items) and misaligned
+    pos += 2_900_000
+    db = eng.alloc(pos + 64)
+    rng.shuffle(items)
+    eng.gather(sb, db, np.array(items, dtype=np.uint64))
+    got = db.download(0, pos)
+    want = np.zeros(pos, dtype=np.uint8)
+    for so, do, ln in items:
+        want[do:do + ln] = src[so:so + ln]
+    assert np.array_equal(got, want)
+    sb.free()
+    db.free()
+
+
+def test_host_fed_stream_at_production_chunk_size(engines, O):
+    """The WriteEntryReader seam at avg 4 MiB: 1.5 GiB of host bytes through 128 MiB windows (carry-over of open
+    chunks up to 16 MiB, a dozen windows whose chunks share hash jobs) == the batch path on the same bytes, and a
+    sampled prefix == the oracle."""
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4 << 20)
+    n = 1536 << 20
+    data = np.empty(n, dtype=np.uint8)
+    for i in range(0, n, 256 << 20):                       # zero extents make max-size (16 MiB) chunks
+        O.fill(256 << 20, 40 + i, 3 if (i >> 28) % 2 else 0, out=data[i:i + (256 << 20)])
+    data[700 << 20:760 << 20] = 0
+    ps = PayloadStream(eng, window_bytes=128 << 20)
+    for pos in range(0, n, 24 << 20):
+        ps.write(data[pos:pos + (24 << 20)])
+    ps.finish()
+    got = ps.poll()
+    ps.close()
+    buf = eng.alloc(n)
+    buf.upload(data)
+    want = eng.chunk_and_digest(buf, None, n)
+    buf.free()
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    assert int(got["size"].max()) == 16 << 20
+    k = 192 << 20
+    pre = O.chunk_and_digest(O.new_config(4 << 20), data[:k])
+    m = pre.size - 1
+    assert m > 10 and np.array_equal(pre["end"][:m], got["end"][:m]) and np.array_equal(pre["digest"][:m], got["digest"][:m])
+
+
+def test_engine_may_be_closed_before_its_streams(gpu_lib, O):
+    """a Go finalizer / Python __del__ may destroy the engine first; children keep it alive."""
+    from pbs_plus_amd import Chunker, Engine, PayloadStream, buzhash
+
+    eng = Engine(buzhash.NewConfig(4096), device=0, inflight=1)
+    ps = PayloadStream(eng, window_bytes=1 << 16)
+    ck = Chunker(eng)
+    data = O.fill(300_000, 3, 0)
+    ps.write(data[:100_000])
+    eng.close()                      # the handle is gone, the engine lives on in its children
+    ps.write(data[100_000:])
+    ps.finish()
+    got = ps.poll()
+    want = O.chunk_and_digest(O.new_config(4096), data)
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    assert ck.scan(data) == int(want["end"][0])
+    ps.close()
+    ck.close()

@@ -97,3 +97,110 @@ def test_split_plan_covers_stream_with_halo_and_overlap():
             assert lo == max(0, a - 63) and hi == min(T, b + mx) and a <= b
             if nxt is not None:
                 assert nxt[0] == b
+
+
+class _OracleEngine:
+    """Engine stand-in for the CPU tests of the multi-rank driver: same submit/collect/dedup surface, answers with
+    the oracle (test infrastructure; the product path never does this)."""
+
+    def __init__(self, avg):
+        from oracle import oracle as O
+        from pbs_plus_amd import buzhash
+
+        self.O, self.cfg, self.config = O, O.new_config(avg), buzhash.NewConfig(avg)
+        self.t, self.tickets = 0, {}
+
+    def submit(self, buf, segments=None, nbytes=None):
+        self.t += 1
+        self.tickets[self.t] = self.O.chunk_and_digest(self.cfg, buf, [(int(o), int(n)) for o, n in segments])
+        return self.t
+
+    def collect(self, t):
+        return self.tickets.pop(t)
+
+    def dedup(self, records):
+        seen, dup, ub = set(), np.zeros(records.size, dtype=np.uint8), 0
+        for i, d in enumerate(records["digest"]):
+            k = d.tobytes()
+            dup[i] = k in seen
+            if k not in seen:
+                ub += int(records["size"][i])
+            seen.add(k)
+        return dup, {"nrecords": int(records.size), "nunique": len(seen), "total_bytes": int(records["size"].sum()),
+                     "unique_bytes": ub}
+
+
+def _corpus(nseg=24, seg=1 << 20, dup_pct=40, seed=11):
+    """content id per segment: dup_pct % copy an earlier segment (deterministic)"""
+    rng = np.random.default_rng(seed)
+    root = np.arange(nseg)
+    for i in range(1, nseg):
+        if rng.integers(0, 100) < dup_pct:
+            root[i] = root[int(rng.integers(0, i))]
+    return root, [seg + 4096 * (i % 3) for i in range(nseg)]
+
+
+def _ingest_worker(rank, ws, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from pbs_plus_amd.dist import ingest_corpus
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        eng = _OracleEngine(65536)
+        root, lens = _corpus()
+
+        def make_batch(ids):     # "bytes reach HBM": here a host array, segments back to back
+            parts, segs, off = [], [], 0
+            for g in ids:
+                parts.append(eng.O.fill(lens[g], 1000 + int(root[g]), 0)[: lens[g]])
+                segs.append((off, lens[g]))
+                off += lens[g]
+            return np.concatenate(parts), segs
+
+        local, stats, allrecs = ingest_corpus(eng, lens, make_batch, max_batch_bytes=5 << 20)
+        q.put((rank, local.tobytes(), {k: int(v) for k, v in stats.items()}, allrecs.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ingest_corpus_two_ranks_finds_the_planted_duplicates():
+    """dist.ingest_corpus end to end over gloo, world size 2: shard -> per-rank batches (several per rank) -> ONE
+    all-gather of the records -> dedup. The duplicate bytes found equal the bytes of the planted duplicate segments
+    (whole segments are copied and cuts are content-defined, so the match is exact, not statistical)."""
+    import torch.multiprocessing as mp
+
+    from pbs_plus_amd import RECORD_DTYPE
+
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ingest_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(ws))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    root, lens = _corpus()
+    assert got[0][2] == got[1][2] and got[0][3] == got[1][3]          # every rank: same stats, same global record set
+    stats = got[0][2]
+    locals_ = [np.frombuffer(g[1], dtype=RECORD_DTYPE) for g in got]
+    allr = np.frombuffer(got[0][3], dtype=RECORD_DTYPE)
+    assert allr.size == sum(x.size for x in locals_)
+    assert sorted(set(int(s) for s in allr["segment"])) == list(range(len(lens)))   # GLOBAL segment ids, all present
+    assert set(int(s) for s in locals_[0]["segment"]).isdisjoint(int(s) for s in locals_[1]["segment"])
+    first = {}
+    dup_bytes = 0
+    for g in range(len(lens)):
+        if int(root[g]) in first and lens[first[int(root[g])]] == lens[g]:
+            dup_bytes += lens[g]
+        else:
+            first.setdefault(int(root[g]), g)
+    assert stats["total_bytes"] == sum(lens)
+    # segments with equal content id but different length share a prefix: their common leading chunks dedup as well
+    assert stats["total_bytes"] - stats["unique_bytes"] >= dup_bytes > 0
+    frac = 1 - stats["unique_bytes"] / stats["total_bytes"]
+    assert 0.2 < frac < 0.6

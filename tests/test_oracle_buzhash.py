@@ -77,6 +77,63 @@ def test_upstream_counter_buffer_chunk_sizes(O):
     assert after[0] == 110609
 
 
+def test_upstream_suggested_boundary_vector(O):
+    """Payload chunker (ChunkerImpl + suggested boundaries) on the same counter buffer. The recalled upstream
+    expectation [32768, 110609, 229376, 32768, 262144, 262144, 118767] is reproduced — for 1-byte feeds, whole-buffer
+    feeds and 4 KiB feeds alike, which is the invariant upstream's test asserts — with the boundary list
+    {32768 (twice: the second yields an empty chunk and is dropped), 0 (in the past), 372753, 405521 (aligned with
+    the regular max-size cut at 143377 + 262144)}. 372753 is implied by the expected sizes themselves (a 32768-byte
+    chunk ending on the regular boundary 405521 needs a cut there that no hash/max rule produces); without it the
+    same code gives [32768, 110609, 262144, 262144, 262144, 118767]. EXTERNAL / recalled: corroboration, not a pin."""
+    buf = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
+    cfg = O.new_config(64 * 1024)
+    for feed in (1, 0, 4096, 77777):
+        e = O.chunk_stream_suggested(cfg, buf, [32 * 1024, 32 * 1024, 0, 372753, 405521], feed)
+        assert np.diff(np.concatenate([[0], e])).astype(int).tolist() == \
+            [32768, 110609, 229376, 32768, 262144, 262144, 118767], feed
+        e = O.chunk_stream_suggested(cfg, buf, [32 * 1024, 32 * 1024, 0, 405521], feed)
+        assert np.diff(np.concatenate([[0], e])).astype(int).tolist() == \
+            [32768, 110609, 262144, 262144, 262144, 118767], feed
+    # no suggestions == the plain chunker
+    assert np.array_equal(O.chunk_stream_suggested(cfg, buf, [], 1), O.chunk_stream(cfg, buf))
+
+
+@pytest.mark.parametrize("avg,n,kind", [(256, 60_000, 0), (4096, 900_000, 0), (4096, 500_000, 1), (4096, 700_000, 3),
+                                        (65536, 5_000_000, 0)])
+def test_suggested_boundaries_as_a_second_candidate_list(O, avg, n, kind):
+    """The engine's formulation (tests/helpers.py::resolve_model_suggested = kernels.hip k_resolve) equals the serial
+    payload chunker fed byte by byte, including boundaries closer than min (dropped), farther than max (left to the
+    hash scan and re-examined from the next chunk), duplicates, and boundaries at / past the end."""
+    from helpers import resolve_model_suggested
+
+    cfg = O.new_config(avg)
+    data = O.fill(n, 2000 + avg + n, kind)
+    rng = np.random.default_rng(avg + n)
+    cands = O.candidates(cfg, data)
+    for dens in (3, 40, 400):
+        sg = sorted(set(int(x) for x in rng.integers(1, n + 10, dens)) | {cfg.min, cfg.min - 1, cfg.max, cfg.max + 1, n, 64, 65})
+        sg = sg + sg[:2]
+        want = O.chunk_stream_suggested(cfg, data, sorted(sg), 1)
+        got = resolve_model_suggested(cands, sg, data.size, cfg.min, cfg.max)
+        assert np.array_equal(got, want), (dens, got[:6], want[:6])
+
+
+def test_suggested_boundary_feed_dependence_is_documented(O):
+    """Upstream's scan lets a suggested boundary inside the CURRENT buffer win over an earlier hash cut in the same
+    buffer, so its result depends on how much data one scan call sees; the engine implements the byte-serial limit
+    (earlier hash cut wins). Find an input where the two differ and pin both behaviours."""
+    cfg = O.new_config(4096)
+    data = O.fill(200_000, 99, 0)
+    plain = O.chunk_stream(cfg, data)
+    first = int(plain[0])
+    b = first + 700                      # a boundary shortly after the first hash cut, within [min, max] of offset 0
+    assert cfg.min <= b <= cfg.max
+    serial = O.chunk_stream_suggested(cfg, data, [b], 1)
+    whole = O.chunk_stream_suggested(cfg, data, [b], 0)
+    assert int(serial[0]) == first       # byte-serial: the hash cut comes first, the boundary is then too close (< min)
+    assert int(whole[0]) == b            # whole-buffer feed: the boundary pre-empts the scan
+
+
 def test_chunk_size_bounds_and_zero_runs(O):
     cfg = O.new_config(4096)
     data = O.fill(2_000_000, 8)
