@@ -15,7 +15,11 @@ type (
 	Engine  struct{}
 	Stream  struct{}
 	Chunker struct{}
+	Ticket  uint64
 )
 
 func NewConfig(int) (Config, error)               { return Config{}, ErrNotBuilt }
 func NewEngine(int, Config, int) (*Engine, error) { return nil, ErrNotBuilt }
+func (e *Engine) NewStream(uint64) (*Stream, error) { return nil, ErrNotBuilt }
+func (e *Engine) NewChunker() (*Chunker, error)     { return nil, ErrNotBuilt }
+func (e *Engine) Close()                            {}

@@ -75,8 +75,10 @@ type ChunkInfo struct {
 	Size    uint32
 }
 
-// Engine owns the device state for one GPU. One goroutine at a time per Engine, like the
-// single writer goroutine of the reference (internal/tapeio/converter.go:672-680).
+// Engine owns the device state for one GPU. It may be shared by any number of goroutines: batch submits,
+// helper calls and any number of Streams / Chunkers created from it run concurrently (the library holds no lock
+// across device waits); one Stream or Chunker is for one goroutine at a time, like the reference's writers
+// (internal/tapeio/converter.go:672-680).
 type Engine struct{ h *C.pbsgpu_engine }
 
 func NewEngine(device int, cfg Config, inflight int) (*Engine, error) {
@@ -88,6 +90,8 @@ func NewEngine(device int, cfg Config, inflight int) (*Engine, error) {
 	return e, nil
 }
 
+// Close releases the handle. Streams and Chunkers created from the engine keep the device state alive until
+// they are closed too (the C library reference-counts), so finalizer order does not matter.
 func (e *Engine) Close() {
 	if e.h != nil {
 		C.pbsgpu_engine_destroy(e.h)
@@ -95,16 +99,239 @@ func (e *Engine) Close() {
 	}
 }
 
+func toSegments(offsets, lengths []uint64) ([]C.pbsgpu_segment, error) {
+	if len(offsets) != len(lengths) {
+		return nil, errors.New("pbsgpu: offsets/lengths differ in length")
+	}
+	segs := make([]C.pbsgpu_segment, len(offsets))
+	for i := range segs {
+		segs[i].offset, segs[i].length = C.uint64_t(offsets[i]), C.uint64_t(lengths[i])
+	}
+	return segs, nil
+}
+
+func fromRecords(buf []C.pbsgpu_record, n int) []ChunkInfo {
+	out := make([]ChunkInfo, n)
+	for i := range out {
+		out[i].End, out[i].Segment, out[i].Size = uint64(buf[i].end), uint32(buf[i].segment), uint32(buf[i].size)
+		copy(out[i].Digest[:], C.GoBytes(unsafe.Pointer(&buf[i].digest[0]), 32))
+	}
+	return out
+}
+
+func toRecords(in []ChunkInfo) []C.pbsgpu_record {
+	out := make([]C.pbsgpu_record, len(in))
+	for i, ci := range in {
+		out[i].end, out[i].segment, out[i].size = C.uint64_t(ci.End), C.uint32_t(ci.Segment), C.uint32_t(ci.Size)
+		for b := 0; b < 32; b++ {
+			out[i].digest[b] = C.uint8_t(ci.Digest[b])
+		}
+	}
+	return out
+}
+
+// ---- batch path: many files / segments of one buffer at once (BASELINE configs[2]) -------------------------------
+
+// Ticket identifies an asynchronous batch.
+type Ticket uint64
+
+// ErrBusy: every in-flight ticket slot is taken; Collect one first.
+var ErrBusy = errors.New("pbsgpu: all in-flight tickets used")
+
+// Submit cuts and hashes every segment buf[offsets[i] : offsets[i]+lengths[i]] as an independent stream (fresh
+// chunker state, forced cut at its end). The Go slice is copied to pinned staging before the call returns.
+// suggested (optional): one ascending list of suggested boundaries per segment, relative to the segment start.
+func (e *Engine) Submit(buf []byte, offsets, lengths []uint64, suggested [][]uint64) (Ticket, error) {
+	segs, err := toSegments(offsets, lengths)
+	if err != nil {
+		return 0, err
+	}
+	var base unsafe.Pointer
+	if len(buf) > 0 {
+		base = unsafe.Pointer(&buf[0])
+	}
+	var sp *C.pbsgpu_segment
+	if len(segs) > 0 {
+		sp = &segs[0]
+	}
+	var t C.uint64_t
+	var st C.int
+	if suggested == nil {
+		st = C.pbsgpu_submit_host(e.h, base, C.uint64_t(len(buf)), sp, C.uint32_t(len(segs)), &t)
+	} else {
+		nseg := len(segs)
+		if nseg == 0 {
+			nseg = 1
+		}
+		if len(suggested) != nseg {
+			return 0, errors.New("pbsgpu: one suggested-boundary list per segment")
+		}
+		idx := make([]C.uint32_t, nseg+1)
+		var flat []C.uint64_t
+		for i, l := range suggested {
+			for _, v := range l {
+				flat = append(flat, C.uint64_t(v))
+			}
+			idx[i+1] = C.uint32_t(len(flat))
+		}
+		var fp *C.uint64_t
+		if len(flat) > 0 {
+			fp = &flat[0]
+		}
+		st = C.pbsgpu_submit_host_suggested(e.h, base, C.uint64_t(len(buf)), sp, C.uint32_t(len(segs)), fp, &idx[0], &t)
+	}
+	runtime.KeepAlive(buf)
+	if st == C.PBSGPU_E_BUSY {
+		return 0, ErrBusy
+	}
+	return Ticket(t), check(st, "submit_host")
+}
+
+// Done reports, without blocking, whether Collect would return at once.
+func (e *Engine) Done(t Ticket) (bool, error) {
+	var d C.int
+	err := check(C.pbsgpu_ticket_done(e.h, C.uint64_t(t), &d), "ticket_done")
+	return d != 0, err
+}
+
+// Collect waits for the batch and returns its records ordered by (segment, end); the ticket is released.
+func (e *Engine) Collect(t Ticket) ([]ChunkInfo, error) {
+	var n C.uint64_t
+	if err := check(C.pbsgpu_wait(e.h, C.uint64_t(t), &n), "wait"); err != nil {
+		return nil, err
+	}
+	buf := make([]C.pbsgpu_record, int(n)+1)
+	if err := check(C.pbsgpu_collect(e.h, C.uint64_t(t), &buf[0], n, &n), "collect"); err != nil {
+		return nil, err
+	}
+	return fromRecords(buf, int(n)), nil
+}
+
+// ---- digest set, dynamic index, reuse planner ---------------------------------------------------------------------
+
+// DedupStats mirrors pbsgpu_dedup_stats.
+type DedupStats struct{ Records, Unique, TotalBytes, UniqueBytes uint64 }
+
+// Dedup flags every record whose digest already occurred at a lower index (device sort + compare): the digest-set
+// reduce of cross-file duplicate detection, run on the all-gathered records of all GPUs.
+func (e *Engine) Dedup(recs []ChunkInfo) ([]bool, DedupStats, error) {
+	if len(recs) == 0 {
+		return nil, DedupStats{}, nil
+	}
+	cr := toRecords(recs)
+	dup := make([]C.uint8_t, len(recs))
+	var st C.pbsgpu_dedup_stats
+	if err := check(C.pbsgpu_dedup_host(e.h, &cr[0], C.uint64_t(len(cr)), &dup[0], &st), "dedup_host"); err != nil {
+		return nil, DedupStats{}, err
+	}
+	out := make([]bool, len(recs))
+	for i := range out {
+		out[i] = dup[i] != 0
+	}
+	return out, DedupStats{uint64(st.nrecords), uint64(st.nunique), uint64(st.total_bytes), uint64(st.unique_bytes)}, nil
+}
+
+// EncodeDynamicIndex is datastore.NewDynamicIndexWriter(ctime).Add(end, digest)...Finish()
+// (internal/pxarmount/commit_bottleneck_test.go:773-793): the .didx image of one stream's records.
+func (e *Engine) EncodeDynamicIndex(recs []ChunkInfo, uuid [16]byte, ctime int64) ([]byte, error) {
+	var nb C.uint64_t
+	C.pbsgpu_didx_size(C.uint64_t(len(recs)), &nb)
+	out := make([]byte, int(nb))
+	cr := toRecords(recs)
+	var rp *C.pbsgpu_record
+	if len(cr) > 0 {
+		rp = &cr[0]
+	}
+	err := check(C.pbsgpu_didx_encode(e.h, rp, C.uint64_t(len(cr)), (*C.uint8_t)(unsafe.Pointer(&uuid[0])), C.int64_t(ctime),
+		(*C.uint8_t)(unsafe.Pointer(&out[0])), nb), "didx_encode")
+	return out, err
+}
+
+// ParseDynamicIndex is datastore.ParseDynamicIndex (internal/pxarmount/commit_orchestrate.go:219).
+func ParseDynamicIndex(blob []byte) (recs []ChunkInfo, ctime int64, csum [32]byte, err error) {
+	if len(blob) == 0 {
+		return nil, 0, csum, errors.New("pbsgpu: empty index")
+	}
+	var n C.uint64_t
+	var ct C.int64_t
+	st := C.pbsgpu_didx_decode((*C.uint8_t)(unsafe.Pointer(&blob[0])), C.uint64_t(len(blob)), nil, 0, &n, &ct,
+		(*C.uint8_t)(unsafe.Pointer(&csum[0])))
+	if st != C.PBSGPU_OK && st != C.PBSGPU_E_CAPACITY {
+		return nil, 0, csum, check(st, "didx_decode")
+	}
+	buf := make([]C.pbsgpu_record, int(n)+1)
+	if err = check(C.pbsgpu_didx_decode((*C.uint8_t)(unsafe.Pointer(&blob[0])), C.uint64_t(len(blob)), &buf[0], n, &n, &ct,
+		(*C.uint8_t)(unsafe.Pointer(&csum[0]))), "didx_decode"); err != nil {
+		return nil, 0, csum, err
+	}
+	return fromRecords(buf, int(n)), int64(ct), csum, nil
+}
+
+// ReuseChunk mirrors the chunks lookupDynamicEntries returns (internal/pxarmount/commit_reuse.go:84-135).
+type ReuseChunk struct {
+	Size, Padding, EndOffset uint64
+	Digest                   [32]byte
+}
+
+// LookupDynamicEntries is lookupDynamicEntries(idx, rangeStart, rangeEnd).
+func LookupDynamicEntries(idx []ChunkInfo, rangeStart, rangeEnd uint64) (chunks []ReuseChunk, startPadding, endPadding uint64, err error) {
+	cr := toRecords(idx)
+	var rp *C.pbsgpu_record
+	if len(cr) > 0 {
+		rp = &cr[0]
+	}
+	buf := make([]C.pbsgpu_reuse_chunk, len(idx)+1)
+	var n, sp, ep C.uint64_t
+	if err = check(C.pbsgpu_reuse_lookup(rp, C.uint64_t(len(cr)), C.uint64_t(rangeStart), C.uint64_t(rangeEnd), &buf[0],
+		C.uint64_t(len(buf)), &n, &sp, &ep), "reuse_lookup"); err != nil {
+		return nil, 0, 0, err
+	}
+	chunks = make([]ReuseChunk, int(n))
+	for i := range chunks {
+		chunks[i].Size, chunks[i].Padding, chunks[i].EndOffset = uint64(buf[i].size), uint64(buf[i].padding), uint64(buf[i].end_offset)
+		copy(chunks[i].Digest[:], C.GoBytes(unsafe.Pointer(&buf[i].digest[0]), 32))
+	}
+	return chunks, uint64(sp), uint64(ep), nil
+}
+
+// ShouldReuse is shouldReuse with chunkPaddingThreshold (commit_reuse.go:152-183, commit_types.go:14).
+func ShouldReuse(idx []ChunkInfo, rangeStart, rangeEnd uint64, saved *ReuseChunk, threshold float64) (bool, error) {
+	cr := toRecords(idx)
+	var rp *C.pbsgpu_record
+	if len(cr) > 0 {
+		rp = &cr[0]
+	}
+	var sv *C.pbsgpu_reuse_chunk
+	var tmp C.pbsgpu_reuse_chunk
+	if saved != nil {
+		tmp.size, tmp.padding, tmp.end_offset = C.uint64_t(saved.Size), C.uint64_t(saved.Padding), C.uint64_t(saved.EndOffset)
+		for b := 0; b < 32; b++ {
+			tmp.digest[b] = C.uint8_t(saved.Digest[b])
+		}
+		sv = &tmp
+	}
+	var r C.int
+	err := check(C.pbsgpu_reuse_should(rp, C.uint64_t(len(cr)), C.uint64_t(rangeStart), C.uint64_t(rangeEnd), sv,
+		C.double(threshold), &r), "reuse_should")
+	return r != 0, err
+}
+
+// ---- payload-stream writer -----------------------------------------------------------------------------------------
+
 // Stream is the payload-stream seam WriteEntryReader feeds: Write appends bytes, Poll returns
 // finished (end, digest) entries in stream order, Inject mirrors ArchiveWriter.InjectChunks
 // (commit_reuse.go:315-341: the open chunk is flushed, offsets skip the injected payload).
-type Stream struct{ h *C.pbsgpu_stream }
+type Stream struct {
+	h   *C.pbsgpu_stream
+	eng *Engine // keeps the Go handle reachable while the stream lives
+}
 
 func (e *Engine) NewStream(windowBytes uint64) (*Stream, error) {
-	s := &Stream{}
+	s := &Stream{eng: e}
 	if err := check(C.pbsgpu_stream_create(e.h, C.uint64_t(windowBytes), &s.h), "stream_create"); err != nil {
 		return nil, err
 	}
+	runtime.SetFinalizer(s, func(s *Stream) { s.Close() })
 	return s, nil
 }
 
@@ -114,7 +341,9 @@ func (s *Stream) Write(p []byte) (int, error) {
 	if len(p) == 0 {
 		return 0, nil
 	}
-	if err := check(C.pbsgpu_stream_write(s.h, unsafe.Pointer(&p[0]), C.size_t(len(p))), "stream_write"); err != nil {
+	err := check(C.pbsgpu_stream_write(s.h, unsafe.Pointer(&p[0]), C.size_t(len(p))), "stream_write")
+	runtime.KeepAlive(p)
+	if err != nil {
 		return 0, err
 	}
 	return len(p), nil
@@ -130,6 +359,10 @@ func (s *Stream) ReadFrom(r io.Reader) (int64, error) {
 		if err := check(C.pbsgpu_stream_reserve(s.h, &buf, &capacity), "stream_reserve"); err != nil {
 			return total, err
 		}
+		if capacity == 0 { // inside an entry whose announced size has been reached
+			_ = C.pbsgpu_stream_commit(s.h, 0)
+			return total, nil
+		}
 		n, rerr := io.ReadFull(r, unsafe.Slice((*byte)(buf), int(capacity)))
 		if err := check(C.pbsgpu_stream_commit(s.h, C.size_t(n)), "stream_commit"); err != nil {
 			return total, err
@@ -144,8 +377,77 @@ func (s *Stream) ReadFrom(r io.Reader) (int64, error) {
 	}
 }
 
+// WriteEntryReader is the payload half of ArchiveWriter.WriteEntryReader(entry, r, size): 16-byte payload header,
+// exactly size bytes from r (zero-copy), per-file XXH3-64 tee. Returns the entry's payload offset (the PAYLOAD_REF /
+// WriteEntryRef value, commit_walk.go:455) and the file index under which PollFiles reports the hash — what
+// writeBackedFile keeps in backedHashes[path] (commit_reuse.go:450-461).
+func (s *Stream) WriteEntryReader(r io.Reader, size uint64) (payloadOffset, fileIndex uint64, err error) {
+	var off, idx C.uint64_t
+	if err = check(C.pbsgpu_stream_begin_entry(s.h, nil, C.uint64_t(size), &off), "stream_begin_entry"); err != nil {
+		return 0, 0, err
+	}
+	n, err := s.ReadFrom(io.LimitReader(r, int64(size)))
+	if err != nil {
+		return uint64(off), 0, err
+	}
+	if uint64(n) != size {
+		return uint64(off), 0, io.ErrUnexpectedEOF
+	}
+	err = check(C.pbsgpu_stream_end_entry(s.h, &idx), "stream_end_entry")
+	return uint64(off), uint64(idx), err
+}
+
+// BeginFile / EndFile bracket a file body for the XXH3 tee when the caller writes the bytes itself.
+func (s *Stream) BeginFile() error { return check(C.pbsgpu_stream_begin_file(s.h), "stream_begin_file") }
+func (s *Stream) EndFile() (uint64, error) {
+	var idx C.uint64_t
+	err := check(C.pbsgpu_stream_end_file(s.h, &idx), "stream_end_file")
+	return uint64(idx), err
+}
+
+// FileHash is one finished file of the tee.
+type FileHash struct{ Index, Size, XXH3 uint64 }
+
+func (s *Stream) PollFiles(max int) ([]FileHash, error) {
+	if max <= 0 {
+		return nil, errors.New("pbsgpu: PollFiles(max <= 0)")
+	}
+	buf := make([]C.pbsgpu_file_hash, max)
+	var n C.uint64_t
+	if err := check(C.pbsgpu_stream_poll_files(s.h, &buf[0], C.uint64_t(max), &n), "stream_poll_files"); err != nil {
+		return nil, err
+	}
+	out := make([]FileHash, int(n))
+	for i := range out {
+		out[i] = FileHash{uint64(buf[i].index), uint64(buf[i].size), uint64(buf[i].xxh3)}
+	}
+	return out, nil
+}
+
+// WriteMarker appends the payload start (tail = false) or tail marker.
+func (s *Stream) WriteMarker(tail bool) error {
+	t := C.int(0)
+	if tail {
+		t = 1
+	}
+	return check(C.pbsgpu_stream_write_marker(s.h, nil, t), "stream_write_marker")
+}
+
+// Inject mirrors InjectChunks: forced cut, the payload position advances by the injected sizes.
 func (s *Stream) Inject(injectedBytes uint64) error {
 	return check(C.pbsgpu_stream_cut(s.h, C.uint64_t(injectedBytes)), "stream_cut")
+}
+
+// PayloadPosition is Encoder().PayloadPosition() (commit_reuse.go:265): written + injected bytes.
+func (s *Stream) PayloadPosition() uint64 {
+	var n C.uint64_t
+	C.pbsgpu_stream_position(s.h, &n)
+	return uint64(n)
+}
+
+// SuggestBoundary suggests a chunk boundary at the current position (payload chunker; a file starts here).
+func (s *Stream) SuggestBoundary() error {
+	return check(C.pbsgpu_stream_suggest(s.h, C.uint64_t(s.PayloadPosition())), "stream_suggest")
 }
 
 func (s *Stream) Finish() error { return check(C.pbsgpu_stream_finish(s.h), "stream_finish") }
@@ -159,12 +461,7 @@ func (s *Stream) Poll(max int) ([]ChunkInfo, error) {
 	if err := check(C.pbsgpu_stream_poll(s.h, &buf[0], C.uint64_t(max), &n), "stream_poll"); err != nil {
 		return nil, err
 	}
-	out := make([]ChunkInfo, int(n))
-	for i := range out {
-		out[i].End, out[i].Segment, out[i].Size = uint64(buf[i].end), uint32(buf[i].segment), uint32(buf[i].size)
-		copy(out[i].Digest[:], C.GoBytes(unsafe.Pointer(&buf[i].digest[0]), 32))
-	}
-	return out, nil
+	return fromRecords(buf, int(n)), nil
 }
 
 func (s *Stream) Close() {
@@ -172,17 +469,22 @@ func (s *Stream) Close() {
 		C.pbsgpu_stream_destroy(s.h)
 		s.h = nil
 	}
+	s.eng = nil
 }
 
 // Chunker mirrors the module's streaming chunker: Scan returns 0 when no boundary was found
 // in data (all of it consumed) or the boundary position (bytes consumed, state reset).
-type Chunker struct{ h *C.pbsgpu_chunker }
+type Chunker struct {
+	h   *C.pbsgpu_chunker
+	eng *Engine
+}
 
 func (e *Engine) NewChunker() (*Chunker, error) {
-	c := &Chunker{}
+	c := &Chunker{eng: e}
 	if err := check(C.pbsgpu_chunker_create(e.h, &c.h), "chunker_create"); err != nil {
 		return nil, err
 	}
+	runtime.SetFinalizer(c, func(c *Chunker) { c.Close() })
 	return c, nil
 }
 
@@ -192,33 +494,54 @@ func (c *Chunker) Scan(data []byte) (int, error) {
 	}
 	var pos C.size_t
 	err := check(C.pbsgpu_chunker_scan(c.h, unsafe.Pointer(&data[0]), C.size_t(len(data)), &pos), "chunker_scan")
+	runtime.KeepAlive(data)
 	return int(pos), err
 }
+
+func (c *Chunker) Reset() error { return check(C.pbsgpu_chunker_reset(c.h), "chunker_reset") }
 
 func (c *Chunker) Close() {
 	if c.h != nil {
 		C.pbsgpu_chunker_destroy(c.h)
 		c.h = nil
 	}
+	c.eng = nil
 }
 
+// ---- whole-file hashes (verification) -------------------------------------------------------------------------------
+
 // HashFiles is verification.HashFile (internal/agent/verification/handler.go:36-68) for many
-// files of one buffer: digests[i] = SHA-256(buf[offsets[i] : offsets[i]+lengths[i]]).
+// files of one buffer: digests[i] = SHA-256(buf[offsets[i] : offsets[i]+lengths[i]]). One GPU lane per file:
+// worth it for MANY files per call (see DESIGN.md, crossover), not for a handful of huge ones.
 func (e *Engine) HashFiles(buf []byte, offsets, lengths []uint64) ([][32]byte, error) {
-	n := len(offsets)
-	if n == 0 || n != len(lengths) {
-		return nil, errors.New("pbsgpu: HashFiles needs matching offsets/lengths")
+	segs, err := toSegments(offsets, lengths)
+	if err != nil || len(segs) == 0 {
+		return nil, errors.New("pbsgpu: HashFiles needs matching, non-empty offsets/lengths")
 	}
-	segs := make([]C.pbsgpu_segment, n)
-	for i := range segs {
-		segs[i].offset, segs[i].length = C.uint64_t(offsets[i]), C.uint64_t(lengths[i])
-	}
-	out := make([][32]byte, n)
+	out := make([][32]byte, len(segs))
 	var base unsafe.Pointer
 	if len(buf) > 0 {
 		base = unsafe.Pointer(&buf[0])
 	}
-	err := check(C.pbsgpu_sha256_many_host(e.h, base, C.uint64_t(len(buf)), &segs[0], C.uint32_t(n),
+	err = check(C.pbsgpu_sha256_many_host(e.h, base, C.uint64_t(len(buf)), &segs[0], C.uint32_t(len(segs)),
 		(*C.uint8_t)(unsafe.Pointer(&out[0][0]))), "sha256_many_host")
+	runtime.KeepAlive(buf)
+	return out, err
+}
+
+// XXH3Files is the per-file XXH3-64 of verifyBackedFileHashes (internal/pxarmount/commit_orchestrate.go:485-562).
+func (e *Engine) XXH3Files(buf []byte, offsets, lengths []uint64) ([]uint64, error) {
+	segs, err := toSegments(offsets, lengths)
+	if err != nil || len(segs) == 0 {
+		return nil, errors.New("pbsgpu: XXH3Files needs matching, non-empty offsets/lengths")
+	}
+	out := make([]uint64, len(segs))
+	var base unsafe.Pointer
+	if len(buf) > 0 {
+		base = unsafe.Pointer(&buf[0])
+	}
+	err = check(C.pbsgpu_xxh3_many_host(e.h, base, C.uint64_t(len(buf)), &segs[0], C.uint32_t(len(segs)),
+		(*C.uint64_t)(unsafe.Pointer(&out[0]))), "xxh3_many_host")
+	runtime.KeepAlive(buf)
 	return out, err
 }

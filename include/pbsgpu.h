@@ -223,6 +223,31 @@ int pbsgpu_stream_bytes_written(const pbsgpu_stream *s, uint64_t *bytes_written)
  * typically the current position = "a file starts here"). Ascending; see pbsgpu_submit_device_suggested. */
 int pbsgpu_stream_suggest(pbsgpu_stream *s, uint64_t offset);
 
+/* Per-file XXH3-64 tee of the stream (writeBackedFile: hash := xxh3.New(); tee := io.TeeReader(f, hash);
+ * writer.WriteEntryReader(entry, tee, size); backedHashes[path] = hash.Sum64() — internal/pxarmount/
+ * commit_reuse.go:450-461): the bytes written between begin_file and end_file are hashed ON THE DEVICE from the
+ * same window the chunker reads (one H2D copy, two consumers; a file may span any number of windows). The hash is
+ * reported asynchronously — with the window that holds the file's last byte — through poll_files, in file order
+ * (the reference only reads backedHashes after the commit: verifyBackedFileHashes, commit_orchestrate.go:485-562). */
+typedef struct pbsgpu_file_hash {
+    uint64_t index; /* as returned by end_file / end_entry (0, 1, 2, ... per stream) */
+    uint64_t size;
+    uint64_t xxh3;  /* XXH3-64, seed 0 */
+} pbsgpu_file_hash;
+int pbsgpu_stream_begin_file(pbsgpu_stream *s);
+int pbsgpu_stream_end_file(pbsgpu_stream *s, uint64_t *file_index);
+int pbsgpu_stream_poll_files(pbsgpu_stream *s, pbsgpu_file_hash *out, uint64_t cap, uint64_t *n);
+/* pxar payload entries written straight into the stream (the layout pbsgpu_payload_pack_device produces for resident
+ * files): begin_entry appends the 16-byte {payload_type, 16 + content_len} header, reports the header's payload
+ * position (what WriteEntryRef / PAYLOAD_REF records, commit_walk.go:455) and opens the file tee; exactly
+ * content_len bytes must follow (write / reserve+commit) before end_entry (else PBSGPU_E_STATE = the Go writer's
+ * unexpected EOF). write_marker appends the start (tail = 0) or tail (tail = 1) marker. fmt NULL = defaults. */
+struct pbsgpu_payload_format;
+int pbsgpu_stream_begin_entry(pbsgpu_stream *s, const struct pbsgpu_payload_format *fmt, uint64_t content_len,
+                              uint64_t *payload_offset);
+int pbsgpu_stream_end_entry(pbsgpu_stream *s, uint64_t *file_index);
+int pbsgpu_stream_write_marker(pbsgpu_stream *s, const struct pbsgpu_payload_format *fmt, int tail);
+
 /* ---- whole-stream SHA-256 batch ---------------------------------------------
  * verification.HashFile (internal/agent/verification/handler.go:36-68) and
  * extractFileHash (internal/server/verification/job.go:1273-1303) for many

@@ -74,6 +74,10 @@ class ReuseChunk(C.Structure):
     _fields_ = [("size", C.c_uint64), ("padding", C.c_uint64), ("end_offset", C.c_uint64), ("digest", C.c_uint8 * 32)]
 
 
+class FileHash(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("size", C.c_uint64), ("xxh3", C.c_uint64)]
+
+
 class DedupStats(C.Structure):
     _fields_ = [
         ("nrecords", C.c_uint64),
@@ -125,6 +129,12 @@ SYMBOLS = {
     "pbsgpu_stream_position": (C.c_int, [_P, _U64P]),
     "pbsgpu_stream_bytes_written": (C.c_int, [_P, _U64P]),
     "pbsgpu_stream_suggest": (C.c_int, [_P, C.c_uint64]),
+    "pbsgpu_stream_begin_file": (C.c_int, [_P]),
+    "pbsgpu_stream_end_file": (C.c_int, [_P, _U64P]),
+    "pbsgpu_stream_poll_files": (C.c_int, [_P, _P, C.c_uint64, _U64P]),
+    "pbsgpu_stream_begin_entry": (C.c_int, [_P, _P, C.c_uint64, _U64P]),
+    "pbsgpu_stream_end_entry": (C.c_int, [_P, _U64P]),
+    "pbsgpu_stream_write_marker": (C.c_int, [_P, _P, C.c_int]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),

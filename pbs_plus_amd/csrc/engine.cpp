@@ -23,8 +23,13 @@ using namespace pbse;
 
 namespace pbse {
 
-int Slot::init() {
-    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+int Slot::init(hipStream_t borrowed) {
+    if (borrowed) {
+        stream = borrowed;
+        own_stream = false;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (auto &e : stage_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return PBSGPU_OK;
@@ -44,7 +49,7 @@ void Slot::destroy() {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : stage_ev)
         if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && own_stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
 }
 
@@ -91,6 +96,10 @@ AuxLease::~AuxLease() {
 static void free_engine(pbsgpu_engine *e) {
     (void)hipSetDevice(e->device);
     hd_destroy(e);
+    for (auto cs : e->copy_streams) {
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamDestroy(cs);
+    }
     for (auto &s : e->slots) s->destroy();
     for (auto &s : e->aux) s->destroy();
     if (e->d_table_rot) (void)hipFree(e->d_table_rot);
@@ -178,11 +187,16 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     CHK(s.order.ensure((size_t)s.rec_cap * 4 + 64));
     CHK(enqueue_candidates(e, s, s.dptr, s.nbytes, cap, s.nseg));
     uint32_t *sc = s.scalars.as<uint32_t>();
-    const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
+    const pbsgpu_segment *dsegs = s.segs_dev();
     pbsk::Suggested sg{};
     if (s.nsugg) {
-        sg.offsets = s.sugg.as<uint64_t>();
-        sg.index = s.sugg_idx.as<uint32_t>();
+        if (s.mapped_ctrl) {
+            sg.offsets = s.h_sugg.as<uint64_t>();
+            sg.index = reinterpret_cast<const uint32_t *>(s.h_sugg.as<uint8_t>() + (size_t)s.nsugg * 8);
+        } else {
+            sg.offsets = s.sugg.as<uint64_t>();
+            sg.index = s.sugg_idx.as<uint32_t>();
+        }
         sg.cmin = e->cfg.min;
     }
     if (s.nseg == 1) {  // one stream: records start at 0, a single walk writes them and their count
@@ -205,7 +219,7 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
 // phase 2: longest-first queue + SHA-256 of the first *SC_NREC records
 static int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     uint32_t *sc = s.scalars.as<uint32_t>();
-    const pbsgpu_segment *dsegs = s.segs.as<pbsgpu_segment>();
+    const pbsgpu_segment *dsegs = s.segs_dev();
     HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
                               sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, e->sha_slack_pct, s.stream));
     HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
@@ -278,9 +292,11 @@ int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32
     }
     CHK(s.h_segs.ensure((size_t)nseg * sizeof(pbsgpu_segment)));
     std::memcpy(s.h_segs.p, segs, (size_t)nseg * sizeof(pbsgpu_segment));
-    CHK(s.segs.ensure((size_t)nseg * sizeof(pbsgpu_segment)));
-    HIPCHK(hipMemcpyAsync(s.segs.p, s.h_segs.p, (size_t)nseg * sizeof(pbsgpu_segment), hipMemcpyHostToDevice,
-                          s.stream));
+    if (!s.mapped_ctrl) {
+        CHK(s.segs.ensure((size_t)nseg * sizeof(pbsgpu_segment)));
+        HIPCHK(hipMemcpyAsync(s.segs.p, s.h_segs.p, (size_t)nseg * sizeof(pbsgpu_segment), hipMemcpyHostToDevice,
+                              s.stream));
+    }
     s.nseg = nseg;
     s.nsugg = 0;
     if (sg && sg->offsets && sg->index) {
@@ -296,10 +312,12 @@ int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32
             CHK(s.h_sugg.ensure(ob + ib));
             std::memcpy(s.h_sugg.p, sg->offsets, ob);
             std::memcpy(s.h_sugg.as<uint8_t>() + ob, sg->index, ib);
-            CHK(s.sugg.ensure(ob + 16));
-            CHK(s.sugg_idx.ensure(ib + 16));
-            HIPCHK(hipMemcpyAsync(s.sugg.p, s.h_sugg.p, ob, hipMemcpyHostToDevice, s.stream));
-            HIPCHK(hipMemcpyAsync(s.sugg_idx.p, s.h_sugg.as<uint8_t>() + ob, ib, hipMemcpyHostToDevice, s.stream));
+            if (!s.mapped_ctrl) {
+                CHK(s.sugg.ensure(ob + 16));
+                CHK(s.sugg_idx.ensure(ib + 16));
+                HIPCHK(hipMemcpyAsync(s.sugg.p, s.h_sugg.p, ob, hipMemcpyHostToDevice, s.stream));
+                HIPCHK(hipMemcpyAsync(s.sugg_idx.p, s.h_sugg.as<uint8_t>() + ob, ib, hipMemcpyHostToDevice, s.stream));
+            }
             s.nsugg = n;
         }
     }
@@ -437,6 +455,49 @@ int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes) {
     CHK(s.order.ensure((size_t)rec_cap * 4 + 64));
     CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
     CHK(s.h_segs.ensure(4 * sizeof(pbsgpu_segment)));
+    CHK(s.h_sugg.ensure(64 << 10));
+    CHK(s.h_recs.ensure((size_t)rec_cap * sizeof(pbsgpu_record) + 64));
+    return PBSGPU_OK;
+}
+
+int cut_enqueue(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
+                uint32_t nseg, const SuggestedHost *sg) {
+    CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
+    CHK(stage_segments(e, s, segs, nseg, nbytes, sg));
+    CHK(s.h_recs.ensure((size_t)s.rec_cap * sizeof(pbsgpu_record) + 64));
+    s.dptr = dptr;
+    s.nbytes = nbytes;
+    s.host_submit = false;
+    s.retries = 0;
+    s.synced = false;
+    CHK(enqueue_cut(e, s, default_cap(e, nbytes)));
+    HIPCHK(pbsk::launch_publish(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, s.stream));
+    HIPCHK(pbsk::launch_publish_records(s.h_recs.as<pbsgpu_record>(), s.recs.as<pbsgpu_record>(),
+                                        s.scalars.as<uint32_t>() + SC_NREC, s.rec_cap, s.stream));
+    HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
+    return PBSGPU_OK;
+}
+
+int cut_finish(pbsgpu_engine *e, Slot &s, uint64_t *nrec) {
+    HIPCHK(hipEventSynchronize(s.ev[EV_SHA1]));
+    uint32_t cap = s.cap;
+    for (;;) {
+        const uint32_t *hs = s.h_scalars.as<uint32_t>();
+        if (hs[SC_MAXCNT] <= cap) break;
+        while (cap < hs[SC_MAXCNT]) cap <<= 1;
+        if (cap > pbsk::scan_tile_bytes(s.nbytes)) cap = pbsk::scan_tile_bytes(s.nbytes);
+        s.retries++;
+        CHK(enqueue_cut(e, s, cap));
+        HIPCHK(pbsk::launch_publish(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, s.stream));
+        HIPCHK(pbsk::launch_publish_records(s.h_recs.as<pbsgpu_record>(), s.recs.as<pbsgpu_record>(),
+                                            s.scalars.as<uint32_t>() + SC_NREC, s.rec_cap, s.stream));
+        HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
+        HIPCHK(hipEventSynchronize(s.ev[EV_SHA1]));
+    }
+    s.nrec = s.h_scalars.as<uint32_t>()[SC_NREC];
+    s.ncand = s.h_scalars.as<uint32_t>()[SC_NCAND];
+    if (s.nrec > s.rec_cap) return PBSGPU_E_STATE;
+    *nrec = s.nrec;
     return PBSGPU_OK;
 }
 
@@ -549,6 +610,11 @@ int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight
             st = e->aux.back() ? e->aux.back()->init() : PBSGPU_E_NOMEM;
         }
         e->aux_busy.assign(e->aux.size(), 0);
+        for (int i = 0; i < 2 && st == PBSGPU_OK; ++i) {
+            hipStream_t cs = nullptr;
+            if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+            else e->copy_streams.push_back(cs);
+        }
         if (st == PBSGPU_OK) st = hd_init(e);
     } while (0);
     if (st != PBSGPU_OK) {

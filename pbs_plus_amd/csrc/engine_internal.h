@@ -134,6 +134,7 @@ constexpr size_t kStageBytes = 32u << 20;
 
 struct Slot {
     hipStream_t stream = nullptr;
+    bool own_stream = true;  // false: the stream belongs to a sibling context (a payload stream's second cut context)
     hipEvent_t ev[EV_COUNT] = {};
     DevBuf data;  // staged copy of host submits
     DevBuf tile_cnt, tile_off, tile_slots, dense, scan_tmp, scalars, segs, seg_cnt, seg_off, recs, order;
@@ -145,6 +146,13 @@ struct Slot {
     bool recs_published = false;
     PinnedBuf stage[2];     // host -> device staging of this slot (lazily allocated)
     hipEvent_t stage_ev[2] = {};
+    // Control tables (segment table, suggested boundaries) are either copied to the device (batch tickets: thousands
+    // of segments read by many waves) or, for the streaming writers, READ BY THE KERNELS STRAIGHT FROM the mapped pinned
+    // copies: a small H2D copy would queue behind the megabytes of payload pieces in the shared SDMA queues.
+    bool mapped_ctrl = false;
+    const pbsgpu_segment *segs_dev() const {
+        return mapped_ctrl ? h_segs.as<pbsgpu_segment>() : segs.as<pbsgpu_segment>();
+    }
     std::mutex op;          // serialises operations on the ticket that owns this slot
     // in-flight state (owner only)
     bool busy = false;      // under engine mu
@@ -161,7 +169,7 @@ struct Slot {
     uint32_t retries = 0;
     uint64_t nrec = 0, ncand = 0;
 
-    int init();      // stream + events
+    int init(hipStream_t borrowed = nullptr);  // stream (unless borrowed) + events
     void destroy();  // frees everything (device must be current)
 };
 
@@ -173,7 +181,7 @@ struct HashJob {
     // host side (pinned: uploaded / downloaded asynchronously)
     std::vector<pbsk::HashDesc> descs;  // accumulated while the job is open
     PinnedBuf h_desc, h_order, h_dig;
-    DevBuf d_desc, d_order, d_queue;
+    DevBuf d_queue;
     hipEvent_t done = nullptr;
     uint32_t n = 0;          // descriptors launched
     int lane = -1;
@@ -212,6 +220,12 @@ struct pbsgpu_engine {
     std::atomic<uint32_t> cap_hint_tile{0};  // ... for this tile size
     std::mutex mu;
     std::condition_variable cv;  // an aux lease was returned
+    // Host -> device payload copies of ALL streams go through these few engine-wide HIP streams (pieces alternate
+    // between them). Measured: one HIP copy stream per payload stream maps 8 streams unevenly onto the SDMA engines
+    // (17 GiB/s aggregate, some streams 4x slower than others); two always-busy copy queues carry ~50 GiB/s whatever
+    // the number of producers. Only ready copies are ever enqueued here (nothing that waits for a kernel).
+    std::vector<hipStream_t> copy_streams;
+    std::atomic<uint32_t> copy_rr{0};
     pbse::HashDispatcher hd;
     int refs = 1;                // owner + live streams / chunkers (under mu); freed when it drops to 0
     bool destroyed = false;      // pbsgpu_engine_destroy was called (children may still be alive)
@@ -251,6 +265,13 @@ int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32
 int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint64_t *count);
 int cut_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
              uint32_t nseg, const SuggestedHost *sg, uint64_t *nrec);
+// asynchronous pair for the streaming writer: cut_enqueue queues the cut plus the publication of its scalars and
+// records into the slot's mapped pinned buffers (h_scalars, h_recs) and returns; cut_finish waits for exactly that
+// work (an event, not the stream: the stream already carries the next window's copies) and re-runs the cut
+// synchronously in the rare case that a scan tile overflowed its candidate capacity
+int cut_enqueue(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
+                uint32_t nseg, const SuggestedHost *sg);
+int cut_finish(pbsgpu_engine *e, Slot &s, uint64_t *nrec);
 // size every buffer a single-segment cut of up to max_bytes can touch, so that steady-state windows never reallocate
 int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes);
 

@@ -90,6 +90,20 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
 // XXH3-64 (seed 0) of whole segments: out[i] for segs[i]; `queue` zero at launch
 hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
                        int num_cus, hipStream_t st);
+// explicit work items (the stream writer's per-file tee): flags bit0 = first piece of its input, bit1 = last piece
+// (both = a whole input); pieces of one input carry state in states[state] and must be launched in order on one
+// stream; the hash of a finished input lands in out[out]
+struct XxhItem {
+    const uint8_t *ptr;
+    uint64_t len;
+    uint32_t flags;
+    uint32_t state;
+    uint32_t out;
+    uint32_t pad;
+};
+size_t xxh3_state_bytes();
+hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, void *states, uint64_t *out, uint32_t *queue,
+                             int num_cus, hipStream_t st);
 
 // device -> mapped pinned host memory by kernel (never through the shared SDMA copy queues; see kernels.hip)
 hipError_t launch_publish(void *dst_host_mapped, const void *src, uint64_t nbytes, hipStream_t st);

@@ -1735,9 +1735,7 @@ hipError_t launch_pack(const uint8_t *src_base, uint8_t *dst, const PackItem *it
 // new file bodies through (xxh3.New(), internal/pxarmount/commit_reuse.go:450-461) and re-checks
 // after the commit (commit_orchestrate.go:485-562).
 // =====================================================================================
-// 8 lanes per range, one per accumulator (XXH3's 512-bit state is 8 independent u64 lanes whose only
-// coupling is acc[i^1] += data[i]: a neighbour shuffle). A wave carries 8 ranges; octets pull ranges
-// from a queue. Inputs <= 240 bytes take the scalar formulas on the octet's first lane.
+// One wave per byte range (see xxh::blocks below); inputs <= 240 bytes take the scalar formulas.
 __device__ constexpr uint8_t kXxhSecret[192] = {
     0xb8, 0xfe, 0x6c, 0x39, 0x23, 0xa4, 0x4b, 0xbe, 0x7c, 0x01, 0x81, 0x2c, 0xf7, 0x21, 0xad, 0x1c, 0xde, 0xd4, 0x6d, 0xe9,
     0x83, 0x90, 0x97, 0xdb, 0x72, 0x40, 0xa4, 0xa4, 0xb7, 0xb3, 0x67, 0x1f, 0xcb, 0x79, 0xe6, 0x4e, 0xcc, 0xc0, 0xe5, 0x78,
@@ -1836,84 +1834,247 @@ __device__ uint64_t short_hash(const uint8_t *d, uint64_t n) {
 }
 }  // namespace xxh
 
-__global__ __launch_bounds__(256) void k_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
-                                              uint64_t *out, uint32_t *queue) {
+// ---- long inputs (> 240 bytes): one WAVE per byte range ---------------------------------------------------
+// XXH3's 512-bit state is 8 u64 accumulators; inside a 1 KiB block (16 stripes of 64 bytes) the update is a SUM
+//   acc[i] += data64[i ^ 1] + lo32(data64[i] ^ key[s][i]) * hi32(data64[i] ^ key[s][i])
+// and only the per-block scramble is non-linear. So all 64 lanes take part: lane = (stripe-in-half-block s8 =
+// lane >> 3, accumulator i = lane & 7) adds its two stripes of the block (two fully coalesced 512-byte wave loads),
+// the 8 partial sums per accumulator are reduced with three butterfly steps, and every lane applies the scramble to
+// its (replicated) accumulator. Loads are byte-aligned 8-byte loads (gfx950 global loads are alignment-free).
+namespace xxh {
+
+// streaming state of ONE open byte range (the stream writer's per-file tee); hist sits directly in front of pend so
+// that the final stripe (the last 64 bytes of the whole input) can be read at pend + pend_len - 64 even when fewer
+// than 64 bytes are pending
+struct State {
+    uint64_t acc[8];
+    uint64_t total;      // bytes seen so far
+    uint32_t pend_len;   // bytes waiting in pend (1..1024 once anything was seen)
+    uint32_t started;
+    uint8_t hist[64];
+    uint8_t pend[1024];
+};
+
+struct Keys {
+    uint64_t k0, k1;     // stripe keys of this lane for the two half-blocks: secret[8 * (s8 + 8h) + 8 i ..]
+    uint64_t scr, last, merge;
+};
+
+__device__ __forceinline__ Keys make_keys(int lane) {
+    const int i = lane & 7, s8 = lane >> 3;
+    Keys k;
+    k.k0 = sec64_dyn(8 * s8 + 8 * i);
+    k.k1 = sec64_dyn(8 * (s8 + 8) + 8 * i);
+    k.scr = sec64_dyn(128 + 8 * i);
+    k.last = sec64_dyn(121 + 8 * i);
+    k.merge = sec64_dyn(11 + 8 * i);
+    return k;
+}
+
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t stripe_term(uint64_t v, uint64_t key) {
+    const uint64_t nb = __shfl_xor(v, 1, 64);  // the neighbour accumulator's data word
+    const uint64_t k = v ^ key;
+    return nb + (uint64_t)(uint32_t)k * (uint64_t)(uint32_t)(k >> 32);
+}
+
+__device__ __forceinline__ uint64_t reduce_stripes(uint64_t part) {  // sum over the 8 lanes that share `i`
+    part += __shfl_xor(part, 8, 64);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    return part;
+}
+
+// consume nblk full 1 KiB blocks at p (all lanes; acc replicated over the 8 lanes with equal i)
+__device__ __forceinline__ void blocks(uint64_t &acc, const uint8_t *p, uint64_t nblk, const Keys &k, int lane) {
+    const uint8_t *q = p + 8 * lane;  // 64 * s8 + 8 * i == 8 * lane
+    uint64_t a0 = 0, a1 = 0;
+    if (nblk) {
+        a0 = ld64(q);
+        a1 = ld64(q + 512);
+    }
+    for (uint64_t b = 0; b < nblk; ++b) {
+        uint64_t n0 = 0, n1 = 0;
+        if (b + 1 < nblk) {  // next block's words in flight while this one is reduced
+            n0 = ld64(q + (b + 1) * 1024);
+            n1 = ld64(q + (b + 1) * 1024 + 512);
+        }
+        uint64_t part = stripe_term(a0, k.k0) + stripe_term(a1, k.k1);
+        acc += reduce_stripes(part);
+        acc ^= acc >> 47;
+        acc ^= k.scr;
+        acc *= P32_1;
+        a0 = n0;
+        a1 = n1;
+    }
+}
+
+// the tail of a long input: `rem` = the R (1..1024) bytes behind the last full block, n = total length (> 240);
+// the 64 bytes in front of rem must be readable when R < 64 (the input itself, or State::hist)
+__device__ __forceinline__ uint64_t finish_long(uint64_t acc, const uint8_t *rem, uint32_t R, uint64_t n, const Keys &k,
+                                                int lane) {
+    const int i = lane & 7, s8 = lane >> 3;
+    const uint32_t nstripes = (R - 1) / 64;  // full stripes that are NOT the last one
+    uint64_t part = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t st = (uint32_t)s8 + 8u * h;
+        const bool on = st < nstripes;                       // octet-uniform
+        const uint64_t v = on ? ld64(rem + 64 * st + 8 * i) : 0;
+        const uint64_t t = stripe_term(v, h ? k.k1 : k.k0);  // shuffles stay wave-converged
+        part += on ? t : 0;
+    }
+    acc += reduce_stripes(part);
+    acc += stripe_term(ld64(rem + R - 64 + 8 * i), k.last);  // last stripe: the final 64 bytes of the input
+    const uint64_t mine = acc ^ k.merge;
+    const uint64_t other = __shfl_xor(mine, 1, 64);
+    uint64_t fold = ((i & 1) == 0) ? fold128(mine, other) : 0;
+    fold += __shfl_xor(fold, 2, 64);
+    fold += __shfl_xor(fold, 4, 64);
+    return avalanche(n * P64_1 + fold);
+}
+
+__device__ __forceinline__ uint64_t init_acc(int lane) {
+    const uint64_t init[8] = {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1};
+    uint64_t a = init[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) a = ((lane & 7) == j) ? init[j] : a;
+    return a;
+}
+
+// whole input in one piece
+__device__ __forceinline__ uint64_t one_shot(const uint8_t *d, uint64_t n, const Keys &k, int lane) {
+    if (n <= 240) return short_hash(d, n);  // every lane computes it (wave-uniform branch); cheap
+    uint64_t acc = init_acc(lane);
+    const uint64_t nblk = (n - 1) / 1024;
+    blocks(acc, d, nblk, k, lane);
+    return finish_long(acc, d + nblk * 1024, (uint32_t)(n - nblk * 1024), n, k, lane);
+}
+
+// global memory written by some lanes of this wave is about to be read by others (or the reverse): complete the
+// outstanding accesses first (workgroup-scope fences: one L1 per CU, no cache maintenance, just the waits)
+__device__ __forceinline__ void mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, int lane) {
+    for (uint32_t j = lane; j < n; j += 64) dst[j] = src[j];
+}
+
+// one piece of an input that arrives in several pieces (stream windows). flags: 1 = first piece, 2 = last piece.
+// Blocks are consumed only while at least one more byte is known to follow (XXH3 treats the final <= 1024 bytes
+// specially), so between pieces 1..1024 bytes wait in State::pend.
+__device__ __forceinline__ bool piece(State *st, const uint8_t *p, uint64_t L, uint32_t flags, const Keys &k, int lane,
+                                      uint64_t *result) {
+    const bool first = (flags & 1u) != 0;
+    uint64_t acc = first ? init_acc(lane) : st->acc[lane & 7];
+    uint32_t pend = first ? 0u : st->pend_len;
+    const uint64_t before = first ? 0ull : st->total;
+    const uint64_t T = (uint64_t)pend + L;
+    uint64_t nproc = T ? (T - 1) / 1024 : 0;  // leaves 1..1024 bytes pending
+    uint64_t used = 0;                        // bytes of p consumed by full blocks
+    if (nproc) {
+        if (pend) {  // complete the pending block in place, consume it from there
+            const uint32_t take = 1024u - pend;
+            wave_copy(st->pend + pend, p, take, lane);
+            mem_sync();
+            blocks(acc, st->pend, 1, k, lane);
+            used = take;
+            --nproc;
+        }
+        blocks(acc, p + used, nproc, k, lane);
+        used += nproc * 1024;
+        // history = the 64 bytes in front of the new pending tail
+        uint8_t hb = 0;
+        if (used >= 64) hb = p[used - 64 + lane];
+        else hb = (lane < 64 - (int)used) ? st->pend[1024 - (64 - used) + lane] : p[lane - (64 - used)];
+        mem_sync();  // the pending block has been read by every lane before it is overwritten
+        st->hist[lane] = hb;
+        const uint32_t rest = (uint32_t)(L - used);
+        wave_copy(st->pend, p + used, rest, lane);
+        pend = rest;
+    } else if (L) {
+        wave_copy(st->pend + pend, p, (uint32_t)L, lane);
+        pend = (uint32_t)T;
+    }
+    const uint64_t total = before + L;
+    if (lane < 8) st->acc[lane] = acc;
+    if (lane == 0) { st->total = total; st->pend_len = pend; st->started = 1; }
+    mem_sync();  // pend / hist written by other lanes are read below
+    if (!(flags & 2u)) return false;
+    if (total <= 240) *result = short_hash(st->pend, total);  // nothing was ever consumed: pend holds the whole input
+    else *result = finish_long(acc, st->pend, pend, total, k, lane);
+    return true;
+}
+}  // namespace xxh
+
+// Work item of the XXH3 kernel: hash bytes [ptr, ptr + len). flags bit0 = first piece of its input, bit1 = last piece;
+// both set = a whole input (no state). Pieces of one input must be issued in order on one stream.
+__global__ __launch_bounds__(256) void k_xxh3(const XxhItem *items, uint32_t nitems, const uint8_t *data,
+                                              const pbsgpu_segment *segs, xxh::State *states, uint64_t *out,
+                                              uint32_t *queue) {
     using namespace xxh;
     const int lane = threadIdx.x & 63;
-    const int li = lane & 7;          // accumulator index
-    const int ol = lane & ~7;         // first lane of this octet
-    // per-lane secret words: stripe s of a block uses secret[8*(s+li) ..], scramble uses secret[128+8*li ..]
-    uint64_t sk[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) sk[s] = sec64_dyn(8 * (s + li));
-    const uint64_t sk_scr = sec64_dyn(128 + 8 * li);
-    const uint64_t sk_last = sec64_dyn(121 + 8 * li);
-    const uint64_t sk_merge = sec64_dyn(11 + 8 * li);
-    const uint64_t init[8] = {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1};
-
-    // Wave-uniform outer loop: every trip each live octet takes ONE range. The queue grab is done
-    // with all 64 lanes converged (ballot + one atomic per wave); inside the body the only shuffles
-    // are intra-octet and the control flow around them is octet-uniform.
-    bool done = false;
-    while (!__all(done)) {
-        const unsigned long long need = __ballot(!done && li == 0);
-        uint32_t first = 0;
-        if (need) {
-            const int leader = __ffsll((long long)need) - 1;
-            if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(need));
-            first = __shfl(first, leader, 64);
+    const Keys k = make_keys(lane);
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(queue, 1u);
+        idx = __shfl(idx, 0, 64);
+        if (idx >= nitems) break;
+        const uint8_t *p;
+        uint64_t len;
+        uint32_t flags = 3u, state = 0, oi = idx;
+        if (items) {
+            const XxhItem it = items[idx];
+            p = it.ptr;
+            len = it.len;
+            flags = it.flags;
+            state = it.state;
+            oi = it.out;
+        } else {
+            p = data + segs[idx].offset;
+            len = segs[idx].length;
         }
-        uint32_t idx = first + (uint32_t)__popcll(need & ((1ull << ol) - 1ull));  // rank of this octet
-        if (!done && idx >= nseg) done = true;
-        if (!done) {
-            const uint8_t *d = data + segs[idx].offset;
-            const uint64_t n = segs[idx].length;
-            if (n <= 240) {
-                if (li == 0) out[idx] = short_hash(d, n);
-            } else {
-                uint64_t acc = init[0];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) acc = (li == i) ? init[i] : acc;
-                auto stripe = [&](const uint8_t *sp, uint64_t key) {
-                    uint64_t v;
-                    __builtin_memcpy(&v, sp + 8 * li, 8);
-                    const uint64_t k = v ^ key;
-                    const uint64_t nb = __shfl_xor(v, 1, 64);  // data of accumulator li^1
-                    acc += nb;
-                    acc += (uint64_t)(uint32_t)k * (uint64_t)(uint32_t)(k >> 32);
-                };
-                const uint64_t nb_blocks = (n - 1) / 1024;
-                for (uint64_t b = 0; b < nb_blocks; ++b) {
-                    const uint8_t *bp = d + b * 1024;
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) stripe(bp + 64 * s, sk[s]);
-                    acc ^= acc >> 47;
-                    acc ^= sk_scr;
-                    acc *= P32_1;
-                }
-                const uint64_t nstripes = ((n - 1) - 1024 * nb_blocks) / 64;
-                const uint8_t *bp = d + nb_blocks * 1024;
-                for (uint64_t s = 0; s < nstripes; ++s) stripe(bp + 64 * s, sec64_dyn(8 * ((int)s + li)));
-                stripe(d + n - 64, sk_last);
-                // merge: pairs (acc[2k] ^ secret[11+16k], acc[2k+1] ^ secret[11+16k+8])
-                const uint64_t mine = acc ^ sk_merge;
-                const uint64_t other = __shfl_xor(mine, 1, 64);
-                uint64_t part = ((li & 1) == 0) ? fold128(mine, other) : 0;
-                part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64);
-                if (li == 0) out[idx] = avalanche(n * P64_1 + part);
-            }
+        uint64_t h = 0;
+        bool done;
+        if ((flags & 3u) == 3u) {
+            h = one_shot(p, len, k, lane);
+            done = true;
+        } else {
+            done = piece(states + state, p, len, flags, k, lane, &h);
         }
+        if (done && lane == 0) out[oi] = h;
     }
 }
 
 hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
                        int num_cus, hipStream_t st) {
     if (nseg == 0) return hipSuccess;
-    unsigned grid = (unsigned)num_cus * 4u;
-    const unsigned need = (nseg + 31) / 32;
+    unsigned grid = (unsigned)num_cus * 2u;  // 8 waves per CU
+    const unsigned need = (nseg + 3) / 4;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, data, segs, nseg, out, queue);
+    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, (const XxhItem *)nullptr, nseg, data, segs,
+                       (xxh::State *)nullptr, out, queue);
+    return hipGetLastError();
+}
+
+size_t xxh3_state_bytes() { return sizeof(xxh::State); }
+
+hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, void *states, uint64_t *out, uint32_t *queue,
+                             int num_cus, hipStream_t st) {
+    if (nitems == 0) return hipSuccess;
+    unsigned grid = (unsigned)num_cus * 2u;
+    const unsigned need = (nitems + 3) / 4;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, items, nitems, (const uint8_t *)nullptr,
+                       (const pbsgpu_segment *)nullptr, (xxh::State *)states, out, queue);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ using namespace pbse;
 // shared jobs it is bounded by the lane count while every chunk still starts within one lane-turnaround.
 namespace pbse {
 
-constexpr int kHashLanes = 8;
+constexpr int kHashLanes = 6;
 
 int hd_init(pbsgpu_engine *e) {
     HashDispatcher &hd = e->hd;
@@ -43,7 +43,7 @@ void hd_destroy(pbsgpu_engine *e) {
     for (auto st : hd.lanes)
         if (st) (void)hipStreamSynchronize(st);
     for (auto &j : hd.jobs) {
-        for (DevBuf *b : {&j->d_desc, &j->d_order, &j->d_queue}) b->release();
+        j->d_queue.release();
         for (PinnedBuf *b : {&j->h_desc, &j->h_order, &j->h_dig}) b->release();
         if (j->done) (void)hipEventDestroy(j->done);
     }
@@ -113,8 +113,6 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev) 
     CHK(j->h_desc.ensure(room * sizeof(pbsk::HashDesc)));
     CHK(j->h_order.ensure(room * 4));
     CHK(j->h_dig.ensure(room * 32));
-    CHK(j->d_desc.ensure(room * sizeof(pbsk::HashDesc)));
-    CHK(j->d_order.ensure(room * 4));
     CHK(j->d_queue.ensure(64));
     std::memcpy(j->h_desc.p, j->descs.data(), (size_t)n * sizeof(pbsk::HashDesc));
     // longest first (the launch lasts as long as its longest chain) + the CU budget that keeps the launch at that bound
@@ -129,12 +127,11 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev) 
     }
     uint64_t lanes_needed = (total_blocks * 125 / 100 + longest - 1) / longest;
     unsigned wgs = (unsigned)std::min<uint64_t>((lanes_needed + 127) / 128, (uint64_t)hd.num_cus);
-    HIPCHK(hipMemcpyAsync(j->d_desc.p, j->h_desc.p, (size_t)n * sizeof(pbsk::HashDesc), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(j->d_order.p, j->h_order.p, (size_t)n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(j->d_queue.p, 0, 64, st));
-    // the digests are written by the kernel straight into mapped pinned memory: a D2H copy queued behind a 0.4 s kernel
-    // would block the copy queue it shares with every other stream (kernels.hip, k_publish)
-    HIPCHK(pbsk::launch_sha256_descs(j->d_desc.as<pbsk::HashDesc>(), n, j->d_order.as<uint32_t>(), j->h_dig.as<uint8_t>(),
+    // No copy engine anywhere in a job: the kernel reads descriptors + order from, and writes the digests to, mapped
+    // pinned memory. A small H2D copy would queue behind the streams' payload pieces in the shared SDMA queues, and a
+    // D2H copy parked behind this 0.4 s kernel would block that queue for every other stream (kernels.hip, k_publish).
+    HIPCHK(pbsk::launch_sha256_descs(j->h_desc.as<pbsk::HashDesc>(), n, j->h_order.as<uint32_t>(), j->h_dig.as<uint8_t>(),
                                      j->d_queue.as<uint32_t>(), wgs, st));
     HIPCHK(hipEventRecord(j->done, st));
     j->n = n;
@@ -183,16 +180,38 @@ int hd_ensure_launched(pbsgpu_engine *e, HashJob *j, bool block) {
 // -------------------------------------------------------------------------------------
 // streaming writer
 // -------------------------------------------------------------------------------------
-// A stream owns everything it touches on the cut side (a private work context, its window buffers, pinned staging, a
-// copy stream): several streams of one engine run concurrently from different threads without ever taking the
-// engine lock. Windows are CUT synchronously (scan + resolve: well under a millisecond of GPU time) because the
-// next window needs to know where the still-open chunk starts; their chunks are HASHED asynchronously through the
-// engine's shared jobs. Records are delivered strictly in stream order.
+// A stream owns everything it touches on the cut side (two private work contexts on ONE HIP stream, its window
+// buffers, pinned staging): several streams of one engine run concurrently from different threads without ever
+// taking the engine lock. The writer thread never waits for the GPU in steady state:
+//   * a full window's cut (scan + resolve + the per-file XXH3 tee) is only ENQUEUED behind its last H2D piece; the
+//     writer moves on to the next window buffer at once, writing new bytes behind a max-chunk-sized headroom;
+//   * at the NEXT flush the previous cut (long finished) is read back: its complete chunks go to the engine's shared
+//     hash jobs, its still-open tail chunk is copied into the headroom in front of the new bytes (a cut only depends
+//     on bytes before it, so re-examining the open chunk with more data reproduces the serial chunker);
+//   * digests arrive asynchronously with the shared jobs; records are delivered strictly in stream order.
 struct WindowInFlight {
     int buf = -1;
     HashJob *job = nullptr;
     uint32_t first = 0;                  // index of this window's first descriptor in the job
     std::vector<pbsgpu_record> recs;     // end (absolute) / size / section filled in; digests arrive with the job
+};
+
+struct FileSpan {                        // a file body inside the stream (begin_file .. end_file), in WRITTEN-byte coordinates
+    uint64_t index = 0, w_start = 0, w_end = 0;
+    bool closed = false, started = false;
+    uint32_t state = 0;                  // which of the two streaming XXH3 states carries it across windows
+};
+
+struct PendingCut {                      // a window whose cut has been enqueued but not read back yet
+    bool active = false;
+    int ctx = 0, buf = -1;
+    uint64_t base = 0;                   // absolute stream offset (incl. injected bytes) of the window's first byte
+    uint64_t carry = 0, total = 0;       // the window is [headroom - carry, headroom - carry + total) of its buffer
+    uint32_t section = 0;
+    bool final = false;
+    std::vector<uint64_t> sugg_rel;      // suggested boundaries relative to the window start (for a capacity retry)
+    std::vector<pbsgpu_file_hash> files; // files whose last piece was in this window (xxh3 filled in at read-back)
+    std::vector<uint32_t> file_out;      // ... and the tee output slot of each
 };
 
 constexpr size_t kStreamStage = 32u << 20;
@@ -203,22 +222,28 @@ constexpr int kStreamStages = 3;
 struct pbsgpu_stream {
     pbsgpu_engine *eng = nullptr;
     uint64_t window = 0;           // new bytes per device window
+    uint64_t headroom = 0;         // = max chunk size: room for the carried open chunk in front of the new bytes
     size_t devcap = 0;
     size_t max_bufs = 0;           // ring limit (back-pressure beyond it)
-    std::vector<DevBuf> dev;       // window buffers: [carry | new bytes]
-    std::vector<char> dev_busy;    // held by a window whose chunks are still being hashed
+    std::vector<DevBuf> dev;       // window buffers: [headroom (carry right-aligned) | new bytes]
+    std::vector<char> dev_busy;    // held by a window whose chunks are still being hashed, or by the pending cut
     int cur = 0;
-    uint64_t carry = 0;            // bytes of the still-open chunk at the front of dev[cur]
-    uint64_t fill = 0;             // new bytes already copied behind the carry
-    Slot cut;                      // private cut context (never shared)
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copied = nullptr;
+    uint64_t carry = 0;            // bytes of the still-open chunk in front of the new bytes of dev[cur]
+    uint64_t fill = 0;             // new bytes already copied into dev[cur]
+    Slot cut[2];                   // private cut contexts, alternating; cut[1] borrows cut[0]'s HIP stream
+    int cut_next = 0;
+    hipStream_t hs = nullptr;      // == cut[0].stream: cuts, the tee and the carry copy, in order
+    // H2D payload pieces ride the ENGINE's shared copy streams and never wait for a kernel: a copy that depends on a
+    // kernel parks at the head of the SDMA queue it shares with other copies and stalls all of them (measured: 8
+    // producers with copies on their cut streams reached 22 GiB/s, 2 producers 46). hs waits for the pieces' events.
+    hipEvent_t piece_ev[2] = {};   // last piece of the current window on each of the engine's copy streams
+    bool piece_used[2] = {false, false};
+    PendingCut pend;
     PinnedBuf stage[kStreamStages];
     hipEvent_t stage_ev[kStreamStages] = {};
     int stage_idx = 0;
     int reserved = -1;             // staging buffer handed out by pbsgpu_stream_reserve
-    PinnedBuf h_recs;              // readback of a window's records
-    uint64_t base = 0;             // absolute stream offset (incl. injected bytes) of dev[cur][0]
+    uint64_t base = 0;             // absolute stream offset (incl. injected bytes) of the carry's first byte
     uint64_t written = 0;
     uint64_t inject_total = 0;
     uint32_t section = 0;
@@ -227,10 +252,23 @@ struct pbsgpu_stream {
     std::deque<WindowInFlight> inflight;
     std::deque<pbsgpu_record> out;
     std::vector<pbsk::HashDesc> descs;
-    std::vector<uint64_t> sugg_rel;
+    // per-file XXH3-64 tee
+    std::deque<FileSpan> files;      // files not yet completely hashed, in stream order
+    uint64_t next_file = 0;
+    uint32_t n_stateful = 0;
+    bool file_open = false;
+    uint64_t entry_left = 0;         // begin_entry: content bytes still expected
+    bool in_entry = false;
+    DevBuf tee_states, tee_queue;
+    PinnedBuf h_tee_items, h_tee_out;  // mapped: read / written by the tee kernel directly
+    std::deque<pbsgpu_file_hash> file_out;
 };
 
 namespace {
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // move the oldest window's records (now with digests) to the output queue, release its buffer
 int stream_complete_oldest(pbsgpu_stream *s, bool block) {
@@ -260,7 +298,7 @@ int stream_complete_oldest(pbsgpu_stream *s, bool block) {
     return PBSGPU_OK;
 }
 
-// a window buffer that is neither current nor still being hashed; grows the ring up to max_bufs, then waits
+// a window buffer that is neither current nor held; grows the ring up to max_bufs, then waits for the oldest window
 int stream_free_buffer(pbsgpu_stream *s, int *out) {
     for (;;) {
         for (size_t i = 0; i < s->dev.size(); ++i)
@@ -278,96 +316,175 @@ int stream_free_buffer(pbsgpu_stream *s, int *out) {
     }
 }
 
-// cut [carry | fill] of the current window; hand all complete chunks to the shared hash jobs; when not `final` the
-// tail chunk stays open and its bytes move to the front of the next window buffer (a cut only depends on bytes before
-// it, so re-examining them with more data reproduces the serial chunker)
-static double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+// queue the per-file XXH3 pieces of the current window's NEW bytes (written-byte range [w0, w0 + fill))
+int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
+    if (s->files.empty()) return PBSGPU_OK;
+    pbsgpu_engine *e = s->eng;
+    const uint64_t w0 = s->written - s->fill, w1 = s->written;
+    const uint8_t *newp = s->dev[s->cur].as<uint8_t>() + s->headroom;
+    const size_t maxitems = s->files.size();
+    CHK(s->h_tee_items.ensure(std::max<size_t>(maxitems, 4096) * sizeof(pbsk::XxhItem)));
+    CHK(s->h_tee_out.ensure(std::max<size_t>(maxitems, 4096) * 8));
+    pbsk::XxhItem *items = s->h_tee_items.as<pbsk::XxhItem>();
+    uint32_t n = 0;
+    for (auto &f : s->files) {
+        if (f.w_start > w1 || (f.w_start == w1 && !(f.closed && f.w_end == f.w_start))) break;  // starts behind this window
+        const uint64_t lo = std::max(f.w_start, w0);
+        const uint64_t hi = f.closed ? std::min(f.w_end, w1) : w1;
+        const uint64_t len = hi > lo ? hi - lo : 0;
+        const bool first = !f.started && lo == f.w_start;
+        const bool last = f.closed && hi == f.w_end;
+        if (len == 0 && !last) continue;  // nothing of it here yet
+        pbsk::XxhItem it{};
+        it.ptr = newp + (lo - w0);
+        it.len = len;
+        it.flags = (first ? 1u : 0u) | (last ? 2u : 0u);
+        if (first && !last) f.state = s->n_stateful++ & 1u;  // at most two files span a window edge at any time
+        it.state = f.state;
+        it.out = n;
+        f.started = true;
+        if (last) {
+            pc.files.push_back(pbsgpu_file_hash{f.index, f.w_end - f.w_start, 0});
+            pc.file_out.push_back(n);
+        }
+        items[n++] = it;
+    }
+    while (!s->files.empty() && s->files.front().closed) s->files.pop_front();  // closed => its last piece is queued now
+    if (n == 0) return PBSGPU_OK;
+    CHK(s->tee_states.ensure(2 * pbsk::xxh3_state_bytes()));
+    CHK(s->tee_queue.ensure(64));
+    HIPCHK(hipMemsetAsync(s->tee_queue.p, 0, 64, s->hs));
+    HIPCHK(pbsk::launch_xxh3_items(items, n, s->tee_states.p, s->h_tee_out.as<uint64_t>(), s->tee_queue.as<uint32_t>(),
+                                   e->num_cus, s->hs));
+    return PBSGPU_OK;
 }
 
-int stream_flush(pbsgpu_stream *s, bool final) {
+// read back the pending window's cut: complete chunks -> shared hash jobs, open tail chunk -> headroom of dev[cur]
+int stream_resolve_pending(pbsgpu_stream *s) {
+    PendingCut &pc = s->pend;
+    if (!pc.active) return PBSGPU_OK;
     pbsgpu_engine *e = s->eng;
-    const uint64_t total = s->carry + s->fill;
-    if (total == 0) return PBSGPU_OK;
-    CHK(set_device(e));
-    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
-    const double t0 = trace ? now_ms() : 0;
-    double t_cut = 0, t_rb = 0, t_app = 0;
-    // the cut waits for the window's copies on the device, not on the host
-    HIPCHK(hipEventRecord(s->copied, s->copy_stream));
-    HIPCHK(hipStreamWaitEvent(s->cut.stream, s->copied, 0));
-    uint8_t *const bufp = s->dev[s->cur].as<uint8_t>();  // raw pointer: the ring (a vector) may grow below
-    // suggested boundaries that can still matter: at or after the open chunk's start, inside this window
-    while (!s->suggested.empty() && s->suggested.front() <= s->base) s->suggested.pop_front();
-    s->sugg_rel.clear();
-    for (uint64_t b : s->suggested) {
-        if (b > s->base + total) break;
-        s->sugg_rel.push_back(b - s->base);
-    }
-    const uint32_t sidx[2] = {0u, (uint32_t)s->sugg_rel.size()};
-    SuggestedHost sg{s->sugg_rel.data(), sidx};
+    Slot &ctx = s->cut[pc.ctx];
     uint64_t nrec = 0;
-    pbsgpu_segment seg{0, total};
-    CHK(cut_sync(e, s->cut, bufp, total, &seg, 1, s->sugg_rel.empty() ? nullptr : &sg, &nrec));
-    const uint64_t nemit = final ? nrec : (nrec ? nrec - 1 : 0);
-    if (trace) t_cut = now_ms();
-    if (nrec) {
-        CHK(s->h_recs.ensure((size_t)nrec * sizeof(pbsgpu_record)));
-        HIPCHK(pbsk::launch_publish(s->h_recs.p, s->cut.recs.p, (size_t)nrec * sizeof(pbsgpu_record), s->cut.stream));
-        HIPCHK(hipStreamSynchronize(s->cut.stream));
+    CHK(cut_finish(e, ctx, &nrec));  // waits for the cut AND the tee queued in front of it
+    pc.active = false;
+    for (size_t i = 0; i < pc.files.size(); ++i) {
+        pc.files[i].xxh3 = s->h_tee_out.as<uint64_t>()[pc.file_out[i]];
+        s->file_out.push_back(pc.files[i]);
     }
-    const pbsgpu_record *hr = s->h_recs.as<pbsgpu_record>();
-    if (trace) t_rb = now_ms();
+    pc.files.clear();
+    pc.file_out.clear();
+    uint8_t *const winp = s->dev[pc.buf].as<uint8_t>() + s->headroom - pc.carry;
+    const uint64_t nemit = pc.final ? nrec : (nrec ? nrec - 1 : 0);
+    const pbsgpu_record *hr = ctx.h_recs.as<pbsgpu_record>();
     if (nemit) {
         WindowInFlight w;
-        w.buf = s->cur;
+        w.buf = pc.buf;
         w.recs.resize((size_t)nemit);
         s->descs.resize((size_t)nemit);
         for (uint64_t i = 0; i < nemit; ++i) {
-            s->descs[(size_t)i] = pbsk::HashDesc{bufp + (hr[i].end - hr[i].size), hr[i].size};
+            s->descs[(size_t)i] = pbsk::HashDesc{winp + (hr[i].end - hr[i].size), hr[i].size};
             pbsgpu_record r{};
-            r.end = hr[i].end + s->base;
+            r.end = hr[i].end + pc.base;
             r.size = hr[i].size;
-            r.segment = s->section;
+            r.segment = pc.section;
             w.recs[(size_t)i] = r;
         }
         CHK(hd_append(e, s->descs.data(), (uint32_t)nemit, &w.job, &w.first));
-        s->dev_busy[s->cur] = 1;
-        s->inflight.push_back(std::move(w));
+        s->inflight.push_back(std::move(w));  // keeps pc.buf busy until its chunks are hashed
+    } else {
+        s->dev_busy[pc.buf] = 0;  // (a carry copy below still reads it: later writes to it follow on the same HIP stream)
     }
-    if (trace) t_app = now_ms();
-    if (final || nrec == 0) {
-        s->base += total;
+    if (pc.final || nrec == 0) {
+        s->base = pc.base + pc.total;
         s->carry = 0;
-        if (nemit) {  // the buffer is still being read by a hash job: continue in another one
-            int nb = -1;
-            CHK(stream_free_buffer(s, &nb));
-            s->cur = nb;
-        }
     } else {
         const pbsgpu_record &open = hr[nrec - 1];
         const uint64_t open_start = open.end - open.size;
-        int nb = -1;
-        CHK(stream_free_buffer(s, &nb));
-        // ordered on the copy stream in front of the next window's H2D pieces; the source buffer is either held by the
-        // window above or, if it emitted nothing, only ever rewritten by later copies on this same stream
-        HIPCHK(hipMemcpyAsync(s->dev[nb].p, bufp + open_start, open.size, hipMemcpyDeviceToDevice,
-                              s->copy_stream));
-        s->base += open_start;
+        HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->headroom - open.size, winp + open_start, open.size,
+                              hipMemcpyDeviceToDevice, s->hs));
+        // a window without a complete chunk released its buffer above: the copy must have read it before new pieces
+        // (other HIP stream) may overwrite it. Cannot happen in steady state (a full window holds >= max bytes).
+        if (!nemit) HIPCHK(hipStreamSynchronize(s->hs));
+        s->base = pc.base + open_start;
         s->carry = open.size;
-        s->cur = nb;
     }
+    return PBSGPU_OK;
+}
+
+// A window is complete (or the stream is being cut / finished): resolve the previous window, enqueue this one's cut
+// and tee, continue in a fresh buffer. `final`: the tail chunk is closed too (forced cut), resolved immediately.
+int stream_flush(pbsgpu_stream *s, bool final) {
+    pbsgpu_engine *e = s->eng;
+    CHK(set_device(e));
+    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
+    const double t0 = trace ? now_ms() : 0;
+    CHK(stream_resolve_pending(s));
+    const double t1 = trace ? now_ms() : 0;
+    const uint64_t total = s->carry + s->fill;
+    PendingCut &pc = s->pend;
+    for (int c = 0; c < 2; ++c)  // the cut and the tee read this window's pieces: device-side wait for the copy streams
+        if (s->piece_used[c]) {
+            HIPCHK(hipStreamWaitEvent(s->hs, s->piece_ev[c], 0));
+            s->piece_used[c] = false;
+        }
+    pc.sugg_rel.clear();
+    CHK(stream_enqueue_tee(s, pc));
+    if (total == 0) {
+        if (!pc.files.empty()) {  // zero-length last pieces only (end_file right after a flush): no cut to ride on
+            HIPCHK(hipStreamSynchronize(s->hs));
+            for (size_t i = 0; i < pc.files.size(); ++i) {
+                pc.files[i].xxh3 = s->h_tee_out.as<uint64_t>()[pc.file_out[i]];
+                s->file_out.push_back(pc.files[i]);
+            }
+            pc.files.clear();
+            pc.file_out.clear();
+        }
+        return PBSGPU_OK;
+    }
+    // suggested boundaries that can still matter: behind the open chunk's start, inside this window
+    while (!s->suggested.empty() && s->suggested.front() <= s->base) s->suggested.pop_front();
+    for (uint64_t b : s->suggested) {
+        if (b > s->base + total) break;
+        pc.sugg_rel.push_back(b - s->base);
+    }
+    const uint32_t sidx[2] = {0u, (uint32_t)pc.sugg_rel.size()};
+    SuggestedHost sg{pc.sugg_rel.data(), sidx};
+    pbsgpu_segment seg{0, total};
+    pc.ctx = s->cut_next;
+    s->cut_next ^= 1;
+    pc.buf = s->cur;
+    pc.base = s->base;
+    pc.carry = s->carry;
+    pc.total = total;
+    pc.section = s->section;
+    pc.final = final;
+    CHK(cut_enqueue(e, s->cut[pc.ctx], s->dev[s->cur].as<uint8_t>() + s->headroom - s->carry, total, &seg, 1,
+                    pc.sugg_rel.empty() ? nullptr : &sg));
+    pc.active = true;
+    s->dev_busy[s->cur] = 1;  // until the cut has been read back (then: until its chunks are hashed, or free)
+    int nb = -1;
+    CHK(stream_free_buffer(s, &nb));
+    s->cur = nb;
+    s->carry = 0;  // known again once the pending cut is resolved
     s->fill = 0;
+    if (final) CHK(stream_resolve_pending(s));
     if (trace)
-        fprintf(stderr, "[pbsgpu] stream %p window %.1f MiB: cut %.2f ms, readback %.2f ms, hash append %.2f ms, next buffer "
-                        "%.2f ms; %zu windows in flight, ring %zu\n", (void *)s, total / 1048576.0, t_cut - t0, t_rb - t_cut,
-                t_app - t_rb, now_ms() - t_app, s->inflight.size(), s->dev.size());
+        fprintf(stderr, "[pbsgpu] stream %p window %.1f MiB: previous cut read back in %.2f ms, enqueue %.2f ms; %zu windows "
+                        "in flight, ring %zu\n", (void *)s, total / 1048576.0, t1 - t0, now_ms() - t1, s->inflight.size(),
+                s->dev.size());
     return PBSGPU_OK;
 }
 
 // non-blocking: deliver windows whose hash job has finished
 int stream_reap(pbsgpu_stream *s) {
     CHK(set_device(s->eng));
+    if (s->pend.active) {  // read the previous window's cut back early if it is done (never wait here)
+        const hipError_t q = hipEventQuery(s->cut[s->pend.ctx].ev[EV_SHA1]);
+        if (q == hipSuccess) CHK(stream_resolve_pending(s));
+        else if (q == hipErrorNotReady) (void)hipGetLastError();
+        else HIPCHK(q);
+    }
     while (!s->inflight.empty()) {
         const int st = stream_complete_oldest(s, false);
         if (st == PBSGPU_E_BUSY) break;
@@ -378,18 +495,25 @@ int stream_reap(pbsgpu_stream *s) {
 
 int stream_drain(pbsgpu_stream *s) {
     CHK(set_device(s->eng));
+    CHK(stream_resolve_pending(s));
     while (!s->inflight.empty()) CHK(stream_complete_oldest(s, true));
     return PBSGPU_OK;
 }
 
 // H2D of one staged piece behind the window's current fill
 int stream_push_piece(pbsgpu_stream *s, int k, size_t n) {
-    HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->carry + s->fill, s->stage[k].p, n, hipMemcpyHostToDevice,
-                          s->copy_stream));
-    HIPCHK(hipEventRecord(s->stage_ev[k], s->copy_stream));
+    pbsgpu_engine *e = s->eng;
+    const int c = (int)(e->copy_rr.fetch_add(1, std::memory_order_relaxed) % e->copy_streams.size());
+    hipStream_t cs = e->copy_streams[(size_t)c];
+    HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->headroom + s->fill, s->stage[k].p, n, hipMemcpyHostToDevice,
+                          cs));
+    HIPCHK(hipEventRecord(s->stage_ev[k], cs));   // the staging buffer is reusable after this
+    HIPCHK(hipEventRecord(s->piece_ev[c], cs));   // ... and the window's cut waits for the last piece per copy stream
+    s->piece_used[c] = true;
     s->stage_idx = (k + 1) % kStreamStages;
     s->fill += n;
     s->written += n;
+    if (s->in_entry) s->entry_left -= std::min<uint64_t>(s->entry_left, n);
     if (s->fill == s->window) CHK(stream_flush(s, false));
     return PBSGPU_OK;
 }
@@ -440,24 +564,31 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     engine_ref(e);
     s->eng = e;
     s->window = window_bytes;
-    s->devcap = (size_t)window_bytes + (size_t)e->cfg.max + 256;
-    // ring limit: enough windows in flight to cover the hash latency (~0.5 s) at this stream's ingest rate, within ~6 GiB
-    size_t nb = (size_t)((6ull << 30) / s->devcap);
-    if (const char *v = getenv("PBSGPU_STREAM_WINDOWS")) nb = (size_t)atol(v);
-    s->max_bufs = std::min<size_t>(std::max<size_t>(nb, 3), 64);
+    s->headroom = ((uint64_t)e->cfg.max + 255) & ~255ull;
+    s->devcap = (size_t)window_bytes + (size_t)s->headroom + 256;
+    // Ring limit. Chunks of up to 16 MiB hash for ~0.45 s, so a stream needs (ingest rate x ~0.6 s) of windows in
+    // flight: 16 GiB carries ~25 GiB/s. Buffers are allocated on demand — a slow producer never grows its ring.
+    size_t budget_gib = 16;
+    if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) budget_gib = (size_t)std::max(1L, atol(v));
+    size_t nb = (size_t)((budget_gib << 30) / s->devcap);
+    s->max_bufs = std::min<size_t>(std::max<size_t>(nb, 4), 256);
     int st = set_device(e);
-    if (st == PBSGPU_OK) st = s->cut.init();
+    if (st == PBSGPU_OK) st = s->cut[0].init();
+    if (st == PBSGPU_OK) st = s->cut[1].init(s->cut[0].stream);
+    s->hs = s->cut[0].stream;
+    for (auto &ev : s->piece_ev)
+        if (st == PBSGPU_OK && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
     // everything a window can need is allocated here: a regrow later (hipFree / hipHostFree) would wait for the whole
     // device, i.e. for other windows' running hash jobs
-    if (st == PBSGPU_OK) st = presize_cut(e, s->cut, s->devcap);
-    if (st == PBSGPU_OK) st = s->h_recs.ensure((s->devcap / std::min(e->effmin, e->cfg.min) + 4) * sizeof(pbsgpu_record));
+    for (auto &c : s->cut) {
+        c.mapped_ctrl = true;
+        if (st == PBSGPU_OK) st = presize_cut(e, c, s->devcap);
+    }
     if (st == PBSGPU_OK) {
         s->dev.resize(2);
         s->dev_busy.assign(2, 0);
         st = s->dev[0].ensure(s->devcap);
     }
-    if (st == PBSGPU_OK && hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
-    if (st == PBSGPU_OK && hipEventCreateWithFlags(&s->copied, hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
     for (int i = 0; i < kStreamStages && st == PBSGPU_OK; ++i)
         if (hipEventCreateWithFlags(&s->stage_ev[i], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
     if (st != PBSGPU_OK) {
@@ -478,15 +609,19 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
             s->inflight.front().job->refs.fetch_sub(1);
             s->inflight.pop_front();
         }
-        if (s->copy_stream) {
-            (void)hipStreamSynchronize(s->copy_stream);
-            (void)hipStreamDestroy(s->copy_stream);
-        }
-        s->cut.destroy();
-        if (s->copied) (void)hipEventDestroy(s->copied);
+        for (int k = 0; k < kStreamStages; ++k)
+            if (s->stage_ev[k]) (void)hipEventSynchronize(s->stage_ev[k]);  // pieces still copying from our staging
+        for (auto &ev : s->piece_ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (s->hs) (void)hipStreamSynchronize(s->hs);
+        s->cut[1].destroy();
+        s->cut[0].destroy();
         for (auto &b : s->dev) b.release();
         for (auto &b : s->stage) b.release();
-        s->h_recs.release();
+        s->tee_states.release();
+        s->tee_queue.release();
+        s->h_tee_items.release();
+        s->h_tee_out.release();
         for (auto &ev : s->stage_ev)
             if (ev) (void)hipEventDestroy(ev);
     }
@@ -497,13 +632,14 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
 int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
     if (!s || (!data && len)) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
+    if (s->in_entry && len > s->entry_left) return PBSGPU_E_INVALID;  // more bytes than the entry header announced
     if (len) CHK(set_device(s->eng));
     const uint8_t *p = static_cast<const uint8_t *>(data);
     while (len) {
         size_t n = (size_t)std::min<uint64_t>(len, s->window - s->fill);
         n = std::min(n, kStreamStage);
-        // caller bytes -> library-owned pinned staging -> device window (async on the copy stream); the memcpy runs on
-        // the caller's thread with no lock held, so several streams copy in parallel
+        // caller bytes -> library-owned pinned staging -> device window (async); the memcpy runs on the caller's
+        // thread with no lock held, so several streams copy in parallel
         const int k = s->stage_idx;
         CHK(s->stage[k].ensure(kStreamStage));
         HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
@@ -524,7 +660,9 @@ int pbsgpu_stream_reserve(pbsgpu_stream *s, void **buf, size_t *cap) {
     HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
     s->reserved = k;
     *buf = s->stage[k].p;
-    *cap = (size_t)std::min<uint64_t>(kStreamStage, s->window - s->fill);
+    uint64_t room = std::min<uint64_t>(kStreamStage, s->window - s->fill);
+    if (s->in_entry) room = std::min(room, s->entry_left);
+    *cap = (size_t)room;
     return PBSGPU_OK;
 }
 
@@ -533,6 +671,7 @@ int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len) {
     if (s->reserved < 0) return PBSGPU_E_STATE;
     const int k = s->reserved;
     if (len > (size_t)std::min<uint64_t>(kStreamStage, s->window - s->fill)) return PBSGPU_E_INVALID;
+    if (s->in_entry && len > s->entry_left) return PBSGPU_E_INVALID;
     s->reserved = -1;
     if (len == 0) return PBSGPU_OK;
     CHK(set_device(s->eng));
@@ -543,14 +682,87 @@ int pbsgpu_stream_suggest(pbsgpu_stream *s, uint64_t offset) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished) return PBSGPU_E_STATE;
     if (!s->suggested.empty() && offset < s->suggested.back()) return PBSGPU_E_INVALID;  // ascending, like the channel
-    if (offset <= s->base) return PBSGPU_OK;  // at or before the open chunk's start: in the past, ignored
-    s->suggested.push_back(offset);
+    s->suggested.push_back(offset);  // boundaries at or before the open chunk's start are dropped at the next flush
     return PBSGPU_OK;
+}
+
+// ---- per-file XXH3-64 tee (writeBackedFile: tee := io.TeeReader(f, xxh3.New()), commit_reuse.go:450-461) ----------
+int pbsgpu_stream_begin_file(pbsgpu_stream *s) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->finished || s->file_open || s->reserved >= 0) return PBSGPU_E_STATE;
+    FileSpan f;
+    f.index = s->next_file++;
+    f.w_start = f.w_end = s->written;
+    s->files.push_back(f);
+    s->file_open = true;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_end_file(pbsgpu_stream *s, uint64_t *index) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (!s->file_open || s->reserved >= 0) return PBSGPU_E_STATE;
+    FileSpan &f = s->files.back();
+    f.w_end = s->written;
+    f.closed = true;
+    s->file_open = false;
+    if (index) *index = f.index;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_poll_files(pbsgpu_stream *s, pbsgpu_file_hash *out, uint64_t cap, uint64_t *n) {
+    if (!s || !n || (!out && cap)) return PBSGPU_E_INVALID;
+    uint64_t k = 0;
+    while (k < cap && !s->file_out.empty()) {
+        out[k++] = s->file_out.front();
+        s->file_out.pop_front();
+    }
+    *n = k;
+    return PBSGPU_OK;
+}
+
+// ---- pxar payload entries: 16-byte {type, 16 + size} header in front of every file body ----------------------------
+static int stream_write_header(pbsgpu_stream *s, uint64_t type, uint64_t full_size) {
+    uint8_t h[16];
+    for (int i = 0; i < 8; ++i) {
+        h[i] = (uint8_t)(type >> (8 * i));
+        h[8 + i] = (uint8_t)(full_size >> (8 * i));
+    }
+    return pbsgpu_stream_write(s, h, 16);
+}
+
+int pbsgpu_stream_write_marker(pbsgpu_stream *s, const pbsgpu_payload_format *fmt, int tail) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->in_entry || s->file_open) return PBSGPU_E_STATE;
+    pbsgpu_payload_format f;
+    if (fmt) f = *fmt; else (void)pbsgpu_payload_format_default(&f);
+    return stream_write_header(s, tail ? f.tail_type : f.start_type, 16);
+}
+
+int pbsgpu_stream_begin_entry(pbsgpu_stream *s, const pbsgpu_payload_format *fmt, uint64_t content_len,
+                              uint64_t *payload_offset) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (s->finished || s->in_entry || s->file_open || s->reserved >= 0) return PBSGPU_E_STATE;
+    pbsgpu_payload_format f;
+    if (fmt) f = *fmt; else (void)pbsgpu_payload_format_default(&f);
+    if (payload_offset) *payload_offset = s->written + s->inject_total;  // what WriteEntryRef / PAYLOAD_REF records
+    CHK(stream_write_header(s, f.payload_type, 16 + content_len));
+    CHK(pbsgpu_stream_begin_file(s));
+    s->in_entry = true;
+    s->entry_left = content_len;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_end_entry(pbsgpu_stream *s, uint64_t *file_index) {
+    if (!s) return PBSGPU_E_INVALID;
+    if (!s->in_entry || s->reserved >= 0) return PBSGPU_E_STATE;
+    if (s->entry_left != 0) return PBSGPU_E_STATE;  // short body: WriteEntryReader's "unexpected EOF"
+    s->in_entry = false;
+    return pbsgpu_stream_end_file(s, file_index);
 }
 
 int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
     if (!s) return PBSGPU_E_INVALID;
-    if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
+    if (s->finished || s->reserved >= 0 || s->in_entry) return PBSGPU_E_STATE;
     CHK(stream_flush(s, true));
     s->base += inject_bytes;
     s->inject_total += inject_bytes;
@@ -561,7 +773,7 @@ int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
 int pbsgpu_stream_finish(pbsgpu_stream *s) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished) return PBSGPU_OK;
-    if (s->reserved >= 0) return PBSGPU_E_STATE;
+    if (s->reserved >= 0 || s->file_open) return PBSGPU_E_STATE;
     CHK(stream_flush(s, true));
     CHK(stream_drain(s));
     s->finished = true;

@@ -343,6 +343,41 @@ class PayloadStream:
         check(self._L.pbsgpu_stream_bytes_written(self._h, C.byref(n)), "stream_bytes_written")
         return n.value
 
+    # ---- per-file XXH3-64 tee + pxar payload entries ---------------------------------------------------------
+    def begin_file(self) -> None:
+        check(self._L.pbsgpu_stream_begin_file(self._h), "stream_begin_file")
+
+    def end_file(self) -> int:
+        i = C.c_uint64()
+        check(self._L.pbsgpu_stream_end_file(self._h, C.byref(i)), "stream_end_file")
+        return i.value
+
+    def begin_entry(self, content_len: int) -> int:
+        """Append the 16-byte payload header of a file body of content_len bytes; returns its payload offset
+        (the PAYLOAD_REF / WriteEntryRef value) and opens the file tee."""
+        off = C.c_uint64()
+        check(self._L.pbsgpu_stream_begin_entry(self._h, None, int(content_len), C.byref(off)), "stream_begin_entry")
+        return off.value
+
+    def end_entry(self) -> int:
+        i = C.c_uint64()
+        check(self._L.pbsgpu_stream_end_entry(self._h, C.byref(i)), "stream_end_entry")
+        return i.value
+
+    def write_marker(self, tail: bool = False) -> None:
+        check(self._L.pbsgpu_stream_write_marker(self._h, None, int(tail)), "stream_write_marker")
+
+    def poll_files(self, cap: int = 4096) -> list:
+        """[(index, size, xxh3)] of the files hashed so far (in file order)."""
+        outs = []
+        while True:
+            buf = (_lib.FileHash * cap)()
+            n = C.c_uint64()
+            check(self._L.pbsgpu_stream_poll_files(self._h, buf, cap, C.byref(n)), "stream_poll_files")
+            outs += [(int(buf[i].index), int(buf[i].size), int(buf[i].xxh3)) for i in range(n.value)]
+            if n.value < cap:
+                return outs
+
     def suggest(self, offset: int | None = None) -> None:
         """Suggest a chunk boundary at absolute payload position `offset` (default: here)."""
         check(self._L.pbsgpu_stream_suggest(self._h, self.position() if offset is None else int(offset)),

@@ -374,3 +374,157 @@ def test_engine_may_be_closed_before_its_streams(gpu_lib, O):
     assert ck.scan(data) == int(want["end"][0])
     ps.close()
     ck.close()
+
+
+def test_xxh3_wave_kernel_all_length_classes_and_alignments(engines):
+    """k_xxh3 (one wave per input): every length class of XXH3-64 (0, 1-3, 4-8, 9-16, 17-128, 129-240, the 1 KiB block
+    edges, multi-block) at every byte alignment, against the xxhash C library."""
+    import xxhash
+
+    eng = engines(4096)
+    rng = np.random.default_rng(31)
+    data = rng.integers(0, 256, 6_000_000, dtype=np.uint8)
+    lens = [0, 1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 64, 65, 96, 97, 128, 129, 130, 161, 192, 239, 240, 241, 255, 256,
+            257, 511, 512, 513, 1023, 1024, 1025, 1087, 1088, 1089, 2047, 2048, 2049, 3000, 4096, 10_000, 65_536 + 5,
+            1_000_003, 3_145_728]
+    segs, off = [], 0
+    for i, n in enumerate(lens):
+        o = off + (i % 8)                      # rotate through all 8 byte alignments
+        segs.append((o, n))
+        off = (o + n + 15) & ~7
+    assert off <= data.size
+    buf = eng.alloc(data.size)
+    buf.upload(data)
+    got = eng.xxh3_many(buf, segs)
+    want = [xxhash.xxh3_64_intdigest(data[o:o + n].tobytes()) for o, n in segs]
+    bad = [(n, hex(int(g)), hex(w)) for (o, n), g, w in zip(segs, got, want) if int(g) != w]
+    assert not bad, bad[:5]
+    buf.free()
+
+
+def test_stream_file_tee_matches_xxhash_and_payload_layout(engines, O):
+    """A4: the per-file XXH3-64 tee of the stream writer + pxar payload entries. Files of every awkward size (0, tiny,
+    around the 240 / 1024 byte edges, larger than a window so that one file spans several windows, files ending exactly
+    on a window edge), written with random write sizes through small windows: every hash == xxhash of the file body,
+    the stream bytes == the .ppxar layout (start marker, {16-byte header, body}*, tail marker) and its cuts/digests ==
+    the oracle on that layout."""
+    import struct
+
+    import xxhash
+
+    from pbs_plus_amd import PayloadStream, _lib
+
+    eng = engines(4096)
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(5)
+    window = 1 << 16
+    sizes = [0, 1, 100, 240, 241, 1023, 1024, 1025, 5000, window - 16, window, 3 * window + 77, 17, 0, 200_000, 1088,
+             window * 2, 9]
+    fmt = _lib.PayloadFormat()
+    _lib.check(_lib.lib().pbsgpu_payload_format_default(fmt), "fmt")
+    ps = PayloadStream(eng, window_bytes=window)
+    expect = bytearray()
+    ps.write_marker(False)
+    expect += struct.pack("<QQ", fmt.start_type, 16)
+    bodies, offsets, idxs = [], [], []
+    for k, n in enumerate(sizes):
+        body = rng.integers(0, 256, n, dtype=np.uint8) if k % 5 else np.zeros(n, dtype=np.uint8)
+        off = ps.begin_entry(n)
+        assert off == len(expect)
+        expect += struct.pack("<QQ", fmt.payload_type, 16 + n)
+        pos = 0
+        while pos < n:
+            m = min(int(rng.integers(1, 50_000)), n - pos)
+            if k % 2:
+                ps.write(body[pos:pos + m])
+            else:                                 # zero-copy feed
+                r = ps.reserve()
+                m = min(m, r.size)
+                r[:m] = body[pos:pos + m]
+                ps.commit(m)
+            pos += m
+        idxs.append(ps.end_entry())
+        expect += body.tobytes()
+        bodies.append(body)
+        offsets.append(off)
+    ps.write_marker(True)
+    expect += struct.pack("<QQ", fmt.tail_type, 16)
+    ps.finish()
+    files = ps.poll_files()
+    assert [f[0] for f in files] == idxs == list(range(len(sizes)))
+    assert [f[1] for f in files] == sizes
+    bad = [(i, n) for (i, n, h), b in zip(files, bodies) if h != xxhash.xxh3_64_intdigest(b.tobytes())]
+    assert not bad, bad
+    got = ps.poll()
+    want = O.chunk_and_digest(cfg, np.frombuffer(bytes(expect), dtype=np.uint8))
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    assert ps.position() == len(expect)
+    # a short body is the Go writer's "unexpected EOF"
+    ps2 = PayloadStream(eng, window_bytes=window)
+    ps2.begin_entry(10)
+    ps2.write(np.zeros(4, np.uint8))
+    with pytest.raises(_lib.PbsGpuError):
+        ps2.end_entry()
+    with pytest.raises(_lib.PbsGpuError):
+        ps2.write(np.zeros(7, np.uint8))      # more than the header announced
+    ps2.close()
+    ps.close()
+
+
+def test_stream_tee_large_files_at_production_window(engines, O):
+    """The tee at production sizes: avg 4 MiB, 64 MiB windows, a 200 MiB file followed by a run of small ones."""
+    import xxhash
+
+    from pbs_plus_amd import PayloadStream
+
+    eng = engines(4 << 20)
+    big = O.fill(200 << 20, 3, 0)
+    small = [O.fill(n, 50 + i, 0) for i, n in enumerate([4096, 1 << 20, 333, 7 << 20])]
+    ps = PayloadStream(eng, window_bytes=64 << 20)
+    for body in [big] + small:
+        ps.begin_file()
+        for pos in range(0, body.size, 24 << 20):
+            ps.write(body[pos:pos + (24 << 20)])
+        ps.end_file()
+    ps.finish()
+    files = ps.poll_files()
+    assert [f[2] for f in files] == [xxhash.xxh3_64_intdigest(b.tobytes()) for b in [big] + small]
+    got = ps.poll()
+    want = O.chunk_and_digest(O.new_config(4 << 20), np.concatenate([big] + small))
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    ps.close()
+
+
+@pytest.mark.parametrize("workload,extra", [("stream64g", ["--slots", "2"]), ("corpus_dup", ["--file-mib", "8", "--scaling", "strong"]),
+                                             ("corpus_dup", ["--file-mib", "8"])])
+def test_bench_two_ranks_share_the_gpu(gpu_lib, workload, extra):
+    """bench.py's N > 1 branch with the REAL engine: two ranks over gloo on the one GPU of the test box (the driver
+    runs the same code with RCCL, one rank per GPU). Rank 0 prints the aggregate line; the digest-set reduce ran."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload, "--gib", "0.25",
+           "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--avg", str(1 << 20)] + extra
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PBS_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    lines = [[ln for ln in o.splitlines() if ln.startswith("{")] for o, _ in outs]
+    assert len(lines[0]) == 1 and not lines[1]
+    d = json.loads(lines[0][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    if workload == "corpus_dup":
+        dd = d["results"]["dedup"]
+        assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and dd["expected_duplicate_frac"] > 0.2
+    else:
+        assert d["results"]["dedup_last_step"]["nrecords"] > 0
