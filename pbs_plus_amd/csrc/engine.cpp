@@ -865,9 +865,22 @@ static int xxh3_many(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nbyt
     Slot *s = lease.s;
     const uint8_t *d = nullptr;
     CHK(stage_ranges(e, s, ptr, host, nbytes, segs, nseg, &d));
+    // work items + plan (which blocks exist) on the host, block sums and chains on the device
+    std::vector<pbsk::XxhItem> items(nseg);
+    for (uint32_t i = 0; i < nseg; ++i) {
+        items[i] = pbsk::XxhItem{};
+        items[i].ptr = d + segs[i].offset;
+        items[i].len = segs[i].length;
+        items[i].flags = 3u;
+        items[i].out = i;
+    }
+    const uint64_t total_blocks = pbsk::xxh3_plan_whole(items.data(), nseg);
+    CHK(s->tile_slots.ensure((size_t)nseg * sizeof(pbsk::XxhItem) + 64));
+    CHK(s->dense.ensure((size_t)total_blocks * 64 + 64));
     CHK(s->recs.ensure((size_t)nseg * 8 + 64));
-    HIPCHK(pbsk::launch_xxh3(d, s->segs.as<pbsgpu_segment>(), nseg, s->recs.as<uint64_t>(),
-                             s->scalars.as<uint32_t>() + SC_QUEUE, e->num_cus, s->stream));
+    CHK(staged_h2d(*s, s->tile_slots.p, items.data(), (size_t)nseg * sizeof(pbsk::XxhItem), s->stream));
+    HIPCHK(pbsk::launch_xxh3_items(s->tile_slots.as<pbsk::XxhItem>(), nseg, total_blocks, nullptr, s->dense.as<uint64_t>(),
+                                   s->recs.as<uint64_t>(), s->scalars.as<uint32_t>() + SC_QUEUE, e->num_cus, s->stream));
     return fetch_result(s, out, s->recs.p, (size_t)nseg * 8);
 }
 

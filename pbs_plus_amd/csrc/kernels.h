@@ -88,24 +88,29 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
                                   uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);
 
 // XXH3-64 (seed 0) of whole segments: out[i] for segs[i]; `queue` zero at launch
-hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
-                       int num_cus, hipStream_t st);
-// explicit work items (the stream writer's per-file tee): flags bit0 = first piece of its input, bit1 = last piece
-// (both = a whole input); pieces of one input carry state in states[state] and must be launched in order on one
-// stream; the hash of a finished input lands in out[out]
+// XXH3-64 (seed 0), two phases (kernels.hip): every 1 KiB block of every input is summed by some wave of the grid
+// (k_xxh3_sums -> `sums`, 64 bytes per block), then one wave per input runs the short serial scramble chain + tail.
+// Work items: flags bit0 = first piece of its input, bit1 = last piece (both = a whole input); pieces of one input carry
+// state in states[state] and must be launched in order on one stream; the hash of a finished input lands in out[out].
+// pend / nproc / s_off are the host's plan: bytes pending in front of the piece, full blocks to consume now, index of the
+// item's first entry in `sums` (items in s_off order).
 struct XxhItem {
     const uint8_t *ptr;
     uint64_t len;
     uint32_t flags;
     uint32_t state;
     uint32_t out;
+    uint32_t pend;
+    uint64_t s_off;
+    uint32_t nproc;
     uint32_t pad;
 };
+uint64_t xxh3_plan_whole(XxhItem *items, uint32_t n);  // plan for whole inputs; returns the total block count
 size_t xxh3_state_bytes();
-hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, void *states, uint64_t *out, uint32_t *queue,
-                             int num_cus, hipStream_t st);
+hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, uint64_t total_blocks, void *states, uint64_t *sums,
+                             uint64_t *out, uint32_t *queue, int num_cus, hipStream_t st);
 
-// device -> mapped pinned host memory by kernel (never through the shared SDMA copy queues; see kernels.hip)
+// device -> mapped pinned host memory by kernel// device -> mapped pinned host memory by kernel (never through the shared SDMA copy queues; see kernels.hip)
 hipError_t launch_publish(void *dst_host_mapped, const void *src, uint64_t nbytes, hipStream_t st);
 hipError_t launch_publish_records(pbsgpu_record *dst_host_mapped, const pbsgpu_record *src, const uint32_t *nrec,
                                   uint64_t cap, hipStream_t st);

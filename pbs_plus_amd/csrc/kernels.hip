@@ -555,6 +555,16 @@ __global__ __launch_bounds__(512, 2) void k_scan3(ScanParams p) {
 }
 #undef PBS_LOOKUP3
 
+// PBSGPU_SCAN_CU_RESERVE: CUs the cooperative scan leaves free (default 16 of 256)
+static int scan_cu_reserve(int num_cus) {
+    static const int v = []() {
+        const char *e = getenv("PBSGPU_SCAN_CU_RESERVE");
+        return e ? atoi(e) : -1;
+    }();
+    if (v >= 0) return std::min(v, num_cus - 1);
+    return num_cus >= 64 ? 16 : 0;
+}
+
 template <int LINES, int D>
 static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st) {
     constexpr size_t lds = 64 + 8 * 64 * 80;  // counters + 8 per-wave stages (40 KiB: also keeps SHA workgroups off this CU)
@@ -562,7 +572,13 @@ static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     uint64_t blocks = (p.ntiles + 7) / 8;
-    if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;
+    // The scan's workgroups are persistent (they drain the tile queue) and fill a CU completely (244 VGPRs x 2 waves per
+    // SIMD, 104 KiB LDS): while one runs on every CU, no other kernel can place a single wave anywhere for the 15-25 ms
+    // of a 64 GiB scan — measured with 4 batches in flight: the small resolve-chain kernels of the OTHER batches took
+    // 11 ms instead of 0.4-4.9 and their SHA launches started ~24 ms late. A few CUs are therefore left to everyone else
+    // (a SHA launch starts its longest chunks first, so the critical chain begins at once on them).
+    const uint64_t usable = (uint64_t)std::max(1, num_cus - scan_cu_reserve(num_cus));
+    if (blocks > usable) blocks = usable;
     hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, p);
     return hipGetLastError();
 }
@@ -1890,27 +1906,37 @@ __device__ __forceinline__ uint64_t reduce_stripes(uint64_t part) {  // sum over
     return part;
 }
 
-// consume nblk full 1 KiB blocks at p (all lanes; acc replicated over the 8 lanes with equal i)
-__device__ __forceinline__ void blocks(uint64_t &acc, const uint8_t *p, uint64_t nblk, const Keys &k, int lane) {
-    const uint8_t *q = p + 8 * lane;  // 64 * s8 + 8 * i == 8 * lane
-    uint64_t a0 = 0, a1 = 0;
-    if (nblk) {
-        a0 = ld64(q);
-        a1 = ld64(q + 512);
-    }
-    for (uint64_t b = 0; b < nblk; ++b) {
-        uint64_t n0 = 0, n1 = 0;
-        if (b + 1 < nblk) {  // next block's words in flight while this one is reduced
-            n0 = ld64(q + (b + 1) * 1024);
-            n1 = ld64(q + (b + 1) * 1024 + 512);
+// Phase A — block sums. S_b[i] = sum over the 16 stripes of block b of the accumulate term; it does not depend on the
+// accumulators, so every block of every input is an independent unit of work for any wave of the grid (perfect load
+// balance whatever the file-size mix). Returned in all lanes (replicated over the 8 lanes with equal i).
+__device__ __forceinline__ uint64_t block_sum(const uint8_t *blk, const Keys &k, int lane) {
+    const uint8_t *q = blk + 8 * lane;  // 64 * s8 + 8 * i == 8 * lane
+    return reduce_stripes(stripe_term(ld64(q), k.k0) + stripe_term(ld64(q + 512), k.k1));
+}
+
+// Phase B — the only serial part of a long input: acc = scramble(acc + S_b), block after block (~10 instructions each).
+// S entries are 8 u64 per block; the next entries are in flight while one is applied.
+__device__ __forceinline__ void chain(uint64_t &acc, const uint64_t *S, uint64_t nblk, const Keys &k, int lane) {
+    const uint64_t *q = S + (lane & 7);
+    constexpr int U = 8;
+    uint64_t b = 0;
+    for (; b + U <= nblk; b += U) {
+        uint64_t v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = q[(b + j) * 8];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            acc += v[j];
+            acc ^= acc >> 47;
+            acc ^= k.scr;
+            acc *= P32_1;
         }
-        uint64_t part = stripe_term(a0, k.k0) + stripe_term(a1, k.k1);
-        acc += reduce_stripes(part);
+    }
+    for (; b < nblk; ++b) {
+        acc += q[b * 8];
         acc ^= acc >> 47;
         acc ^= k.scr;
         acc *= P32_1;
-        a0 = n0;
-        a1 = n1;
     }
 }
 
@@ -1947,12 +1973,12 @@ __device__ __forceinline__ uint64_t init_acc(int lane) {
     return a;
 }
 
-// whole input in one piece
-__device__ __forceinline__ uint64_t one_shot(const uint8_t *d, uint64_t n, const Keys &k, int lane) {
+// whole input in one piece; S = its block sums (phase A)
+__device__ __forceinline__ uint64_t one_shot(const uint8_t *d, uint64_t n, const uint64_t *S, const Keys &k, int lane) {
     if (n <= 240) return short_hash(d, n);  // every lane computes it (wave-uniform branch); cheap
     uint64_t acc = init_acc(lane);
     const uint64_t nblk = (n - 1) / 1024;
-    blocks(acc, d, nblk, k, lane);
+    chain(acc, S, nblk, k, lane);
     return finish_long(acc, d + nblk * 1024, (uint32_t)(n - nblk * 1024), n, k, lane);
 }
 
@@ -1970,32 +1996,23 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
 
 // one piece of an input that arrives in several pieces (stream windows). flags: 1 = first piece, 2 = last piece.
 // Blocks are consumed only while at least one more byte is known to follow (XXH3 treats the final <= 1024 bytes
-// specially), so between pieces 1..1024 bytes wait in State::pend.
-__device__ __forceinline__ bool piece(State *st, const uint8_t *p, uint64_t L, uint32_t flags, const Keys &k, int lane,
-                                      uint64_t *result) {
+// specially), so between pieces 1..1024 bytes wait in State::pend. The HOST mirrors the pending length (pure
+// arithmetic on the piece lengths) and passes it with the number of blocks to consume now (nproc); phase A has already
+// completed the pending block in place (if any) and summed all nproc blocks into S.
+__device__ __forceinline__ bool piece(State *st, const uint8_t *p, uint64_t L, uint32_t flags, uint32_t pend,
+                                      uint64_t nproc, const uint64_t *S, const Keys &k, int lane, uint64_t *result) {
     const bool first = (flags & 1u) != 0;
     uint64_t acc = first ? init_acc(lane) : st->acc[lane & 7];
-    uint32_t pend = first ? 0u : st->pend_len;
     const uint64_t before = first ? 0ull : st->total;
     const uint64_t T = (uint64_t)pend + L;
-    uint64_t nproc = T ? (T - 1) / 1024 : 0;  // leaves 1..1024 bytes pending
-    uint64_t used = 0;                        // bytes of p consumed by full blocks
     if (nproc) {
-        if (pend) {  // complete the pending block in place, consume it from there
-            const uint32_t take = 1024u - pend;
-            wave_copy(st->pend + pend, p, take, lane);
-            mem_sync();
-            blocks(acc, st->pend, 1, k, lane);
-            used = take;
-            --nproc;
-        }
-        blocks(acc, p + used, nproc, k, lane);
-        used += nproc * 1024;
+        chain(acc, S, nproc, k, lane);
+        const uint64_t used = nproc * 1024 - pend;  // bytes of p inside the consumed blocks
         // history = the 64 bytes in front of the new pending tail
-        uint8_t hb = 0;
+        uint8_t hb;
         if (used >= 64) hb = p[used - 64 + lane];
         else hb = (lane < 64 - (int)used) ? st->pend[1024 - (64 - used) + lane] : p[lane - (64 - used)];
-        mem_sync();  // the pending block has been read by every lane before it is overwritten
+        mem_sync();  // the completed pending block has been read by every lane before it is overwritten
         st->hist[lane] = hb;
         const uint32_t rest = (uint32_t)(L - used);
         wave_copy(st->pend, p + used, rest, lane);
@@ -2015,11 +2032,58 @@ __device__ __forceinline__ bool piece(State *st, const uint8_t *p, uint64_t L, u
 }
 }  // namespace xxh
 
-// Work item of the XXH3 kernel: hash bytes [ptr, ptr + len). flags bit0 = first piece of its input, bit1 = last piece;
-// both set = a whole input (no state). Pieces of one input must be issued in order on one stream.
-__global__ __launch_bounds__(256) void k_xxh3(const XxhItem *items, uint32_t nitems, const uint8_t *data,
-                                              const pbsgpu_segment *segs, xxh::State *states, uint64_t *out,
-                                              uint32_t *queue) {
+// Work item of the XXH3 kernels: hash bytes [ptr, ptr + len). flags bit0 = first piece of its input, bit1 = last piece;
+// both set = a whole input (no state). Pieces of one input must be issued in order on one stream. pend / nproc / s_off
+// are filled by the host (xxh3_plan): pending bytes in front of this piece, full 1 KiB blocks to consume now, index of
+// the item's first block-sum entry.
+// Phase A: one unit = kRun consecutive blocks of the global block list (all inputs back to back).
+constexpr uint32_t kXxhRun = 16;
+__global__ __launch_bounds__(256) void k_xxh3_sums(const XxhItem *items, uint32_t nitems, uint64_t total_blocks,
+                                                   xxh::State *states, uint64_t *S) {
+    using namespace xxh;
+    const int lane = threadIdx.x & 63;
+    const Keys k = make_keys(lane);
+    const uint64_t nunits = (total_blocks + kXxhRun - 1) / kXxhRun;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t u = wave; u < nunits; u += nwaves) {
+        uint64_t g = u * kXxhRun;
+        const uint64_t gend = min(g + kXxhRun, total_blocks);
+        // item that owns block g: last item with s_off <= g (items are in s_off order; empty items share an offset)
+        uint32_t lo = 0, hi = nitems;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (items[mid].s_off <= g) lo = mid; else hi = mid;
+        }
+        uint32_t it = lo;
+        while (g < gend) {
+            while (it + 1 < nitems && (items[it].nproc == 0 || g >= items[it].s_off + items[it].nproc)) ++it;
+            const XxhItem item = items[it];
+            const uint64_t j = g - item.s_off;  // block of this item
+            const uint8_t *blk;
+            if (item.pend) {
+                State *st = states + item.state;
+                const uint32_t take = 1024u - item.pend;
+                if (j == 0) {  // complete the pending block in place (this wave is its only reader in this phase)
+                    wave_copy(st->pend + item.pend, item.ptr, take, lane);
+                    mem_sync();
+                    blk = st->pend;
+                } else {
+                    blk = item.ptr + take + (j - 1) * 1024;
+                }
+            } else {
+                blk = item.ptr + j * 1024;
+            }
+            const uint64_t sum = block_sum(blk, k, lane);
+            if (lane < 8) S[g * 8 + lane] = sum;
+            ++g;
+        }
+    }
+}
+
+// Phase B: one wave per item
+__global__ __launch_bounds__(256) void k_xxh3(const XxhItem *items, uint32_t nitems, xxh::State *states, const uint64_t *S,
+                                              uint64_t *out, uint32_t *queue) {
     using namespace xxh;
     const int lane = threadIdx.x & 63;
     const Keys k = make_keys(lane);
@@ -2028,53 +2092,46 @@ __global__ __launch_bounds__(256) void k_xxh3(const XxhItem *items, uint32_t nit
         if (lane == 0) idx = atomicAdd(queue, 1u);
         idx = __shfl(idx, 0, 64);
         if (idx >= nitems) break;
-        const uint8_t *p;
-        uint64_t len;
-        uint32_t flags = 3u, state = 0, oi = idx;
-        if (items) {
-            const XxhItem it = items[idx];
-            p = it.ptr;
-            len = it.len;
-            flags = it.flags;
-            state = it.state;
-            oi = it.out;
-        } else {
-            p = data + segs[idx].offset;
-            len = segs[idx].length;
-        }
+        const XxhItem it = items[idx];
         uint64_t h = 0;
         bool done;
-        if ((flags & 3u) == 3u) {
-            h = one_shot(p, len, k, lane);
+        if ((it.flags & 3u) == 3u) {
+            h = one_shot(it.ptr, it.len, S + it.s_off * 8, k, lane);
             done = true;
         } else {
-            done = piece(states + state, p, len, flags, k, lane, &h);
+            done = piece(states + it.state, it.ptr, it.len, it.flags, it.pend, it.nproc, S + it.s_off * 8, k, lane, &h);
         }
-        if (done && lane == 0) out[oi] = h;
+        if (done && lane == 0) out[it.out] = h;
     }
 }
 
-hipError_t launch_xxh3(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint64_t *out, uint32_t *queue,
-                       int num_cus, hipStream_t st) {
-    if (nseg == 0) return hipSuccess;
-    unsigned grid = (unsigned)num_cus * 2u;  // 8 waves per CU
-    const unsigned need = (nseg + 3) / 4;
-    if (grid > need) grid = need;
-    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, (const XxhItem *)nullptr, nseg, data, segs,
-                       (xxh::State *)nullptr, out, queue);
-    return hipGetLastError();
+// fills pend-independent plan fields of whole inputs and returns the total number of blocks (host side)
+uint64_t xxh3_plan_whole(XxhItem *items, uint32_t n) {
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        items[i].pend = 0;
+        items[i].nproc = items[i].len > 240 ? (uint32_t)((items[i].len - 1) / 1024) : 0u;
+        items[i].s_off = total;
+        total += items[i].nproc;
+    }
+    return total;
 }
 
 size_t xxh3_state_bytes() { return sizeof(xxh::State); }
 
-hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, void *states, uint64_t *out, uint32_t *queue,
-                             int num_cus, hipStream_t st) {
+hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, uint64_t total_blocks, void *states, uint64_t *sums,
+                             uint64_t *out, uint32_t *queue, int num_cus, hipStream_t st) {
     if (nitems == 0) return hipSuccess;
-    unsigned grid = (unsigned)num_cus * 2u;
+    if (total_blocks) {
+        const uint64_t units = (total_blocks + kXxhRun - 1) / kXxhRun;
+        unsigned grid = (unsigned)std::min<uint64_t>((units + 3) / 4, (uint64_t)num_cus * 8u);
+        hipLaunchKernelGGL(k_xxh3_sums, dim3(grid), dim3(256), 0, st, items, nitems, total_blocks, (xxh::State *)states, sums);
+    }
+    unsigned grid = (unsigned)num_cus * 2u;  // 8 waves per CU
     const unsigned need = (nitems + 3) / 4;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, items, nitems, (const uint8_t *)nullptr,
-                       (const pbsgpu_segment *)nullptr, (xxh::State *)states, out, queue);
+    hipLaunchKernelGGL(k_xxh3, dim3(grid), dim3(256), 0, st, items, nitems, (xxh::State *)states, (const uint64_t *)sums, out,
+                       queue);
     return hipGetLastError();
 }
 

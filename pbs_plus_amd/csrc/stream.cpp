@@ -200,6 +200,7 @@ struct FileSpan {                        // a file body inside the stream (begin
     uint64_t index = 0, w_start = 0, w_end = 0;
     bool closed = false, started = false;
     uint32_t state = 0;                  // which of the two streaming XXH3 states carries it across windows
+    uint32_t pend = 0;                   // host mirror of xxh::State::pend_len (pure arithmetic on the piece lengths)
 };
 
 struct PendingCut {                      // a window whose cut has been enqueued but not read back yet
@@ -259,7 +260,7 @@ struct pbsgpu_stream {
     bool file_open = false;
     uint64_t entry_left = 0;         // begin_entry: content bytes still expected
     bool in_entry = false;
-    DevBuf tee_states, tee_queue;
+    DevBuf tee_states, tee_queue, tee_items, tee_sums;
     PinnedBuf h_tee_items, h_tee_out;  // mapped: read / written by the tee kernel directly
     std::deque<pbsgpu_file_hash> file_out;
 };
@@ -327,6 +328,7 @@ int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
     CHK(s->h_tee_out.ensure(std::max<size_t>(maxitems, 4096) * 8));
     pbsk::XxhItem *items = s->h_tee_items.as<pbsk::XxhItem>();
     uint32_t n = 0;
+    uint64_t total_blocks = 0;
     for (auto &f : s->files) {
         if (f.w_start > w1 || (f.w_start == w1 && !(f.closed && f.w_end == f.w_start))) break;  // starts behind this window
         const uint64_t lo = std::max(f.w_start, w0);
@@ -342,6 +344,19 @@ int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
         if (first && !last) f.state = s->n_stateful++ & 1u;  // at most two files span a window edge at any time
         it.state = f.state;
         it.out = n;
+        // the plan: which 1 KiB blocks this piece completes (XXH3 keeps the final 1..1024 bytes for its tail rules)
+        if (first && last) {
+            it.pend = 0;
+            it.nproc = len > 240 ? (uint32_t)((len - 1) / 1024) : 0u;
+        } else {
+            if (first) f.pend = 0;
+            const uint64_t T = (uint64_t)f.pend + len;
+            it.pend = f.pend;
+            it.nproc = T ? (uint32_t)((T - 1) / 1024) : 0u;
+            f.pend = (uint32_t)(T - (uint64_t)it.nproc * 1024);
+        }
+        it.s_off = total_blocks;
+        total_blocks += it.nproc;
         f.started = true;
         if (last) {
             pc.files.push_back(pbsgpu_file_hash{f.index, f.w_end - f.w_start, 0});
@@ -353,8 +368,12 @@ int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
     if (n == 0) return PBSGPU_OK;
     CHK(s->tee_states.ensure(2 * pbsk::xxh3_state_bytes()));
     CHK(s->tee_queue.ensure(64));
+    CHK(s->tee_items.ensure(std::max<size_t>(maxitems, 4096) * sizeof(pbsk::XxhItem)));
+    CHK(s->tee_sums.ensure((size_t)(s->window / 1024 + 64) * 64));  // presized at create: never regrown
     HIPCHK(hipMemsetAsync(s->tee_queue.p, 0, 64, s->hs));
-    HIPCHK(pbsk::launch_xxh3_items(items, n, s->tee_states.p, s->h_tee_out.as<uint64_t>(), s->tee_queue.as<uint32_t>(),
+    HIPCHK(pbsk::launch_publish(s->tee_items.p, items, (size_t)n * sizeof(pbsk::XxhItem), s->hs));  // host -> device by kernel
+    HIPCHK(pbsk::launch_xxh3_items(s->tee_items.as<pbsk::XxhItem>(), n, total_blocks, s->tee_states.p,
+                                   s->tee_sums.as<uint64_t>(), s->h_tee_out.as<uint64_t>(), s->tee_queue.as<uint32_t>(),
                                    e->num_cus, s->hs));
     return PBSGPU_OK;
 }
@@ -620,6 +639,8 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
         for (auto &b : s->stage) b.release();
         s->tee_states.release();
         s->tee_queue.release();
+        s->tee_items.release();
+        s->tee_sums.release();
         s->h_tee_items.release();
         s->h_tee_out.release();
         for (auto &ev : s->stage_ev)
