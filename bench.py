@@ -58,7 +58,8 @@ CHAIN_US_PER_BLOCK = 1.655  # measured serial chain of the wave-pair kernel: 64 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 20; hostfeed 48: its final drain is one chunk chain, ~0.6 s, whatever the length)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="stream64g",
                     choices=("stream64g", "manyfiles", "corpus_dup", "rechunk", "hostfeed", "verify"))
@@ -78,6 +79,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=2)
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 48 if a.workload == "hostfeed" else 20
     if a.file_mib is None:
         a.file_mib = 1.0 if a.workload == "verify" else 64.0
     return a
@@ -833,6 +836,7 @@ def hostfeed_main(a, rank, local_rank, world, ctx):
             nrec += st.poll().size
             nfiles[i] += len(st.poll_files())
             out[i] = (nrec, st.bytes_written() - b0)
+            gate.wait()          # every record of every stream delivered: end of the timed region
             st.close()
         except Exception as exc:  # noqa: BLE001
             errs.append(repr(exc))
@@ -847,12 +851,13 @@ def hostfeed_main(a, rank, local_rank, world, ctx):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     gate.wait()
-    for t in ths:
-        t.join()
+    gate.wait()
     torch.cuda.synchronize()
     if ctx.dist is not None:
         ctx.dist.barrier()
     elapsed = time.perf_counter() - t0
+    for t in ths:
+        t.join()
     if errs:
         raise SystemExit("hostfeed producer failed: " + "; ".join(errs))
     total = float(sum(o[1] for o in out))

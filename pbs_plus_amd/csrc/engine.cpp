@@ -100,6 +100,7 @@ static void free_engine(pbsgpu_engine *e) {
         (void)hipStreamSynchronize(cs);
         (void)hipStreamDestroy(cs);
     }
+    for (auto &b : e->win_pool) b.release();
     for (auto &s : e->slots) s->destroy();
     for (auto &s : e->aux) s->destroy();
     if (e->d_table_rot) (void)hipFree(e->d_table_rot);

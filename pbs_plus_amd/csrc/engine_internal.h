@@ -185,6 +185,7 @@ struct HashJob {
     hipEvent_t done = nullptr;
     uint32_t n = 0;          // descriptors launched
     int lane = -1;
+    double launched_ms = 0;  // when it was launched (the oldest running job is the next to finish)
     enum State { OPEN, LAUNCHED } state = OPEN;
     std::atomic<int> refs{0};  // windows that still have to read their digests
     const uint8_t *digest(uint32_t i) const { return h_dig.as<uint8_t>() + (size_t)i * 32; }
@@ -197,6 +198,17 @@ struct HashDispatcher {
     std::vector<std::unique_ptr<HashJob>> jobs;   // pool (all jobs ever created)
     HashJob *open = nullptr;                      // accumulating
     int num_cus = 256;
+    // Launch policy. A job lasts ~0.45 s (the chain of a max-size chunk) whatever it holds, and its windows are
+    // released together when it ends. Greedy launching (default) hands the first few windows a lane each and then lumps
+    // everything that arrives while all lanes are busy into one job: completions come in bursts. With several writers
+    // that is harmless (the lump is spread over many rings) and measured fastest (8 writers: 42 GiB/s greedy vs 31-35
+    // with launches spaced by job time / lanes); ONE writer near its ring limit can stall on a lump (the last 8 GiB of a
+    // 24 GiB single-stream run took 0.75 s instead of 0.35) — PBSGPU_HASH_INTERVAL_MS=75 spaces launches for that case
+    // (a launch still goes at once when >= 1 GiB is waiting).
+    uint64_t open_bytes = 0;
+    double last_launch_ms = -1e18;
+    double t0_ms = 0;  // trace time base
+    double min_interval_ms = 60.0;
 };
 
 }  // namespace pbse
@@ -224,6 +236,10 @@ struct pbsgpu_engine {
     // between them). Measured: one HIP copy stream per payload stream maps 8 streams unevenly onto the SDMA engines
     // (17 GiB/s aggregate, some streams 4x slower than others); two always-busy copy queues carry ~50 GiB/s whatever
     // the number of producers. Only ready copies are ever enqueued here (nothing that waits for a kernel).
+    // window buffers returned by destroyed streams, re-used by later ones (hipFree waits for the whole device: a
+    // stream teardown that frees a 16 GiB ring stalls for as long as other streams' hash jobs run)
+    std::mutex pool_mu;
+    std::vector<pbse::DevBuf> win_pool;
     std::vector<hipStream_t> copy_streams;
     std::atomic<uint32_t> copy_rr{0};
     pbse::HashDispatcher hd;

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <thread>
 
 #include "engine_internal.h"
 
@@ -27,13 +28,18 @@ using namespace pbse;
 // shared jobs it is bounded by the lane count while every chunk still starts within one lane-turnaround.
 namespace pbse {
 
-constexpr int kHashLanes = 6;
+constexpr int kHashLanes = 6;  // + 2 copy streams + one stream per payload stream: within the 24 hardware queues for 8 writers
 
 int hd_init(pbsgpu_engine *e) {
     HashDispatcher &hd = e->hd;
     hd.num_cus = e->num_cus;
-    hd.lanes.assign(kHashLanes, nullptr);
-    hd.lane_job.assign(kHashLanes, nullptr);
+    int nlanes = kHashLanes;
+    if (const char *v = getenv("PBSGPU_HASH_LANES")) nlanes = std::min(16, std::max(1, atoi(v)));
+    hd.lanes.assign((size_t)nlanes, nullptr);
+    hd.lane_job.assign((size_t)nlanes, nullptr);
+    hd.min_interval_ms = 0.0;  // greedy by default: measured best with several writers (engine_internal.h)
+    hd.t0_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (const char *v = getenv("PBSGPU_HASH_INTERVAL_MS")) hd.min_interval_ms = atof(v);
     for (auto &st : hd.lanes) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return PBSGPU_OK;
 }
@@ -79,12 +85,18 @@ HashJob *hd_new_job(HashDispatcher &hd) {
 
 // hd.mu held. Seal the open job and launch it if a lane is free. Returns PBSGPU_OK with *launched = false when every
 // lane is still busy (the caller may wait on *busy_ev, outside the lock, and retry).
-int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev) {
+static double hd_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev, bool force = false) {
     HashDispatcher &hd = e->hd;
     *launched = false;
     if (busy_ev) *busy_ev = nullptr;
     HashJob *j = hd.open;
     if (!j || j->descs.empty()) return PBSGPU_OK;
+    // pacing (engine_internal.h): go at once when a good amount of work is waiting, otherwise keep launches spaced
+    if (!force && hd.open_bytes < (1ull << 30) && hd_now_ms() - hd.last_launch_ms < hd.min_interval_ms) return PBSGPU_OK;
     int lane = -1;
     for (int i = 0; i < (int)hd.lanes.size() && lane < 0; ++i) {
         HashJob *lj = hd.lane_job[i];
@@ -104,7 +116,12 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev) 
         }
     }
     if (lane < 0) {
-        if (busy_ev) *busy_ev = hd.lane_job[0]->done;
+        if (busy_ev) {  // the job launched first is the next to finish (all last about one max-size chunk chain)
+            HashJob *oldest = hd.lane_job[0];
+            for (auto *lj : hd.lane_job)
+                if (lj->launched_ms < oldest->launched_ms) oldest = lj;
+            *busy_ev = oldest->done;
+        }
         return PBSGPU_OK;
     }
     const uint32_t n = (uint32_t)j->descs.size();
@@ -139,7 +156,17 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev) 
     j->state = HashJob::LAUNCHED;
     hd.lane_job[lane] = j;
     hd.open = nullptr;
+    hd.open_bytes = 0;
+    hd.last_launch_ms = hd_now_ms();
+    j->launched_ms = hd.last_launch_ms;
     *launched = true;
+    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
+    if (trace) {
+        int busy = 0;
+        for (auto *lj : hd.lane_job) busy += lj != nullptr;
+        fprintf(stderr, "[pbsgpu] t=%.1f ms hash job: %u chunks, %.1f MiB, longest %.1f MiB, %u workgroups, lane %d (%d busy)%s\n",
+                hd.last_launch_ms - hd.t0_ms, n, total_blocks / 16384.0, longest / 16384.0, wgs, lane, busy, force ? " forced" : "");
+    }
     return PBSGPU_OK;
 }
 
@@ -154,6 +181,7 @@ int hd_append(pbsgpu_engine *e, const pbsk::HashDesc *d, uint32_t n, HashJob **j
     HashJob *j = hd.open;
     *first = (uint32_t)j->descs.size();
     j->descs.insert(j->descs.end(), d, d + n);
+    for (uint32_t i = 0; i < n; ++i) hd.open_bytes += d[i].len;
     j->refs.fetch_add(1);
     *job = j;
     bool launched;
@@ -173,7 +201,8 @@ int hd_ensure_launched(pbsgpu_engine *e, HashJob *j, bool block) {
             if (launched || j->state == HashJob::LAUNCHED) return PBSGPU_OK;
         }
         if (!block) return PBSGPU_OK;
-        if (busy) HIPCHK(hipEventSynchronize(busy));  // a lane frees up when its job ends
+        if (busy) HIPCHK(hipEventSynchronize(busy));  // a lane frees up when its (oldest) job ends
+        else std::this_thread::sleep_for(std::chrono::milliseconds(2));  // pacing: streams finishing together share a job
     }
 }
 
@@ -299,13 +328,29 @@ int stream_complete_oldest(pbsgpu_stream *s, bool block) {
     return PBSGPU_OK;
 }
 
+// a window buffer of devcap bytes: from the engine's pool of returned buffers if one fits, else a fresh allocation
+int stream_buffer_ensure(pbsgpu_stream *s, DevBuf &b) {
+    if (b.cap >= s->devcap) return PBSGPU_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->eng->pool_mu);
+        auto &pool = s->eng->win_pool;
+        for (size_t i = 0; i < pool.size(); ++i)
+            if (pool[i].cap >= s->devcap && pool[i].cap <= s->devcap + s->devcap / 4) {
+                b = std::move(pool[i]);
+                pool.erase(pool.begin() + (long)i);
+                return PBSGPU_OK;
+            }
+    }
+    return b.ensure(s->devcap);
+}
+
 // a window buffer that is neither current nor held; grows the ring up to max_bufs, then waits for the oldest window
 int stream_free_buffer(pbsgpu_stream *s, int *out) {
     for (;;) {
         for (size_t i = 0; i < s->dev.size(); ++i)
             if (!s->dev_busy[i] && (int)i != s->cur) {
                 *out = (int)i;
-                return s->dev[i].ensure(s->devcap);
+                return stream_buffer_ensure(s, s->dev[i]);
             }
         if (s->dev.size() < s->max_bufs) {
             s->dev.emplace_back();
@@ -606,7 +651,7 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     if (st == PBSGPU_OK) {
         s->dev.resize(2);
         s->dev_busy.assign(2, 0);
-        st = s->dev[0].ensure(s->devcap);
+        st = stream_buffer_ensure(s, s->dev[0]);
     }
     for (int i = 0; i < kStreamStages && st == PBSGPU_OK; ++i)
         if (hipEventCreateWithFlags(&s->stage_ev[i], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
@@ -635,6 +680,11 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
         if (s->hs) (void)hipStreamSynchronize(s->hs);
         s->cut[1].destroy();
         s->cut[0].destroy();
+        {   // window buffers go back to the engine (freed with it); the pool is capped at what one ring holds
+            std::lock_guard<std::mutex> lk(e->pool_mu);
+            for (auto &b : s->dev)
+                if (b.p && e->win_pool.size() < 256) e->win_pool.push_back(std::move(b));
+        }
         for (auto &b : s->dev) b.release();
         for (auto &b : s->stage) b.release();
         s->tee_states.release();

@@ -1,0 +1,5 @@
+for P in 1 8; do python scripts/r2_probe_feed.py $P 24 2>&1 | tail -1; done
+for args in "--producers 8" "--producers 8 --steps 48" "--producers 8 --steps 24 --tee" "--producers 4" "--producers 2" "--producers 1"; do
+timeout 300 python bench.py --workload hostfeed $args 2>/dev/null | python -c "
+import json,sys; d=json.load(sys.stdin); print('hostfeed $args', d['value'], d['roofline']['frac_of_measured_h2d'], d['config']['xxh3_tee_files'], d['stream_records_match_oracle'])"; done
+timeout 1800 python -m pytest tests/test_gpu_round2.py -x -q -m gpu 2>&1 | tail -3

@@ -528,3 +528,134 @@ def test_bench_two_ranks_share_the_gpu(gpu_lib, workload, extra):
         assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and dd["expected_duplicate_frac"] > 0.2
     else:
         assert d["results"]["dedup_last_step"]["nrecords"] > 0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_stream_random_programs_match_the_model(engines, O, seed):
+    """Randomised programs over the whole stream surface — write / reserve+commit with random sizes, suggested
+    boundaries announced ahead of the data, InjectChunks cuts, file tees, payload entries, polls at random points,
+    window sizes from 16 KiB up — checked against a host model built from the oracle (payload chunker per section)
+    and the xxhash library. Exercises the deferred-cut / headroom-carry / shared-hash-job machinery at every edge."""
+    import struct
+
+    import xxhash
+
+    from pbs_plus_amd import PayloadStream, _lib
+
+    avg = [256, 4096, 4096, 65536][seed % 4]
+    eng = engines(avg)
+    cfg = O.new_config(avg)
+    rng = np.random.default_rng(1000 + seed)
+    window = int(rng.choice([cfg.max, cfg.max * 2, cfg.max * 4 + 4096]))
+    fmt = _lib.PayloadFormat()
+    _lib.check(_lib.lib().pbsgpu_payload_format_default(fmt), "fmt")
+    ps = PayloadStream(eng, window_bytes=window)
+    sections = [bytearray()]          # bytes of each section (between injects)
+    sec_start = [0]                   # absolute payload position of each section's first byte
+    sugg = [[]]                       # suggested boundaries per section, relative
+    files, got_recs, got_files = [], [], []
+    pos = 0                           # absolute payload position (written + injected)
+    last_sugg = 0
+
+    def feed(data):
+        nonlocal pos
+        data = np.frombuffer(bytes(data), dtype=np.uint8)
+        o = 0
+        while o < data.size:
+            n = min(int(rng.integers(1, 3 * cfg.max)), data.size - o)
+            if rng.random() < 0.5:
+                ps.write(data[o:o + n])
+            else:
+                r = ps.reserve()
+                n = min(n, r.size)
+                r[:n] = data[o:o + n]
+                ps.commit(n)
+            o += n
+            if rng.random() < 0.2:
+                got_recs.append(ps.poll())
+            if rng.random() < 0.1:
+                got_files.extend(ps.poll_files())
+        sections[-1] += bytes(data)
+        pos += data.size
+
+    for _ in range(int(rng.integers(4, 14))):
+        op = rng.random()
+        body = O.fill(int(rng.integers(0, 6 * cfg.max)), int(rng.integers(1, 1 << 30)), int(rng.integers(0, 4))) \
+            if rng.random() < 0.9 else np.zeros(int(rng.integers(0, 300)), dtype=np.uint8)
+        if op < 0.15 and len(sections[-1]) >= 0:
+            inj = int(rng.integers(0, 5 * cfg.max))
+            ps.inject(inj)
+            pos += inj
+            sections.append(bytearray())
+            sec_start.append(pos)
+            sugg.append([])
+            continue
+        # boundaries somewhere in the bytes about to be written (announced now, i.e. ahead of the data)
+        span = body.size + (16 if op >= 0.6 else 0)
+        for b in sorted(int(x) for x in rng.integers(0, max(span, 1) + 1, int(rng.integers(0, 4)))):
+            a = pos + b
+            if a >= last_sugg:
+                ps.suggest(a)
+                last_sugg = a
+                sugg[-1].append(a - sec_start[-1])
+        if op < 0.6:
+            tee = rng.random() < 0.5
+            if tee:
+                ps.begin_file()
+            feed(body)
+            if tee:
+                files.append((ps.end_file(), body.size, xxhash.xxh3_64_intdigest(body.tobytes())))
+        else:
+            off = ps.begin_entry(body.size)
+            assert off == pos
+            sections[-1] += struct.pack("<QQ", fmt.payload_type, 16 + body.size)
+            pos += 16
+            feed(body)
+            files.append((ps.end_entry(), body.size, xxhash.xxh3_64_intdigest(body.tobytes())))
+    assert ps.position() == pos
+    ps.finish()
+    got_recs.append(ps.poll())
+    got_files.extend(ps.poll_files())
+    got = np.concatenate(got_recs)
+    want_end, want_dig, want_sec = [], [], []
+    for k, (sec, st, sg) in enumerate(zip(sections, sec_start, sugg)):
+        if not sec:
+            continue
+        w = O.chunk_and_digest_suggested(cfg, np.frombuffer(bytes(sec), dtype=np.uint8), [(0, len(sec))], [sorted(sg)])
+        want_end.append(w["end"] + np.uint64(st))
+        want_dig.append(w["digest"])
+        want_sec += [k] * w.size
+    if want_end:
+        assert np.array_equal(got["end"], np.concatenate(want_end)), (seed, got["end"][:6], np.concatenate(want_end)[:6])
+        assert np.array_equal(got["digest"], np.concatenate(want_dig)), seed
+        assert got["segment"].tolist() == want_sec
+    else:
+        assert got.size == 0
+    assert got_files == files, (seed, got_files[:3], files[:3])
+    ps.close()
+
+
+@pytest.mark.parametrize("workload", ["manyfiles", "corpus_dup", "rechunk"])
+def test_bench_workloads_at_full_scale_check_against_the_oracle(gpu_lib, workload):
+    """BASELINE configs[2..4] at their full single-GPU shapes (2 x 128 GiB of 64 MiB files / a 128 GiB corpus share
+    with 40 % duplicated segments / the share after 2 % edits): bench.py's sampled oracle check must hold on the
+    records of a full-size pass, and the workload-level result must be the planted one."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "4", "--warmup", "0",
+                          "--cpu-sample-gib", "0.5"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["cpu_baseline"]["records_match_gpu"] is True and d["cpu_baseline"]["records_checked"] > 50
+    assert d["config"]["resident_bytes_per_gpu"] >= 120 * (1 << 30)
+    if workload == "manyfiles":
+        assert d["config"]["files_per_batch"] == 2048 and d["config"]["chunks_per_batch"] > 20_000
+    if workload == "corpus_dup":
+        dd = d["results"]["dedup"]
+        assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and 0.3 < dd["expected_duplicate_frac"] < 0.5
+    if workload == "rechunk":
+        assert 0.5 < d["results"]["reused_chunk_bytes_frac"] < 0.95
