@@ -29,6 +29,7 @@ struct ScanParams {
     uint32_t *tile_cnt;       // [ntiles] true count (may exceed cap)
     uint32_t *tile_slots;     // [ntiles * cap] end offset within tile (1..kScanTile), a-coords
     unsigned long long *tile_queue;  // device counter, zero at launch: next tile to hand out
+    uint32_t tiles_per_wave;         // k_scan3: 0 = persistent workgroups, else a wave retires after this many tiles
 };
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st);

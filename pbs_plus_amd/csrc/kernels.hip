@@ -536,7 +536,10 @@ __global__ __launch_bounds__(512, 2) void k_scan3(ScanParams p) {
     const uint64_t A = p.nbytes + p.lead;
     const uint8_t *lds0 = reinterpret_cast<const uint8_t *>(tab);
 
-    for (;;) {
+    // tiles_per_wave > 0: the workgroup retires after that many tiles per wave, so that the chip's dispatcher can place
+    // other kernels' workgroups (the small resolve-chain kernels and SHA launches of the other batches in flight) on the
+    // CU every fraction of a millisecond instead of after the whole scan (see launch_scan3)
+    for (uint32_t done = 0; p.tiles_per_wave == 0 || done < p.tiles_per_wave; ++done) {
         unsigned long long g0 = 0;
         if (lane == 0) g0 = atomicAdd(p.tile_queue, 1ull);
         const uint64_t t_idx = __shfl(g0, 0, 64);
@@ -565,6 +568,14 @@ static int scan_cu_reserve(int num_cus) {
     return num_cus >= 64 ? 16 : 0;
 }
 
+static uint32_t scan_tiles_per_wave() {
+    static const int v = []() {
+        const char *e = getenv("PBSGPU_SCAN_TILES_PER_WAVE");
+        return e ? atoi(e) : 0;
+    }();
+    return v > 0 ? (uint32_t)v : 0u;
+}
+
 template <int LINES, int D>
 static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st) {
     constexpr size_t lds = 64 + 8 * 64 * 80;  // counters + 8 per-wave stages (40 KiB: also keeps SHA workgroups off this CU)
@@ -572,14 +583,23 @@ static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     uint64_t blocks = (p.ntiles + 7) / 8;
-    // The scan's workgroups are persistent (they drain the tile queue) and fill a CU completely (244 VGPRs x 2 waves per
-    // SIMD, 104 KiB LDS): while one runs on every CU, no other kernel can place a single wave anywhere for the 15-25 ms
-    // of a 64 GiB scan — measured with 4 batches in flight: the small resolve-chain kernels of the OTHER batches took
-    // 11 ms instead of 0.4-4.9 and their SHA launches started ~24 ms late. A few CUs are therefore left to everyone else
-    // (a SHA launch starts its longest chunks first, so the critical chain begins at once on them).
-    const uint64_t usable = (uint64_t)std::max(1, num_cus - scan_cu_reserve(num_cus));
-    if (blocks > usable) blocks = usable;
-    hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, p);
+    // A scan workgroup fills its CU completely (244 VGPRs x 2 waves per SIMD, 104 KiB LDS). With PERSISTENT workgroups
+    // (one per CU draining the tile queue) no other kernel can place a single wave anywhere for the 15-25 ms of a 64 GiB
+    // scan — measured with 4 batches in flight: the small resolve-chain kernels of the OTHER batches took 11 ms instead
+    // of 0.4-4.9 and their SHA launches started ~24 ms late. Two remedies, both switchable: a few CUs never taken
+    // (PBSGPU_SCAN_CU_RESERVE, default 16), and workgroups that retire after a few tiles so that the dispatcher
+    // interleaves everyone else (PBSGPU_SCAN_TILES_PER_WAVE, default 0 = persistent: measured with 4 batches in flight
+    // the resolve chains drop from 13 to 9 ms but the scans stretch from 25 to 40 ms, no net gain — what stretches the
+    // SHA launches under overlap is not placement but the chip clock under the scan's power draw).
+    ScanParams q = p;
+    q.tiles_per_wave = scan_tiles_per_wave();
+    if (q.tiles_per_wave) {
+        blocks = (p.ntiles + 8ull * q.tiles_per_wave - 1) / (8ull * q.tiles_per_wave);
+    } else {
+        const uint64_t usable = (uint64_t)std::max(1, num_cus - scan_cu_reserve(num_cus));
+        if (blocks > usable) blocks = usable;
+    }
+    hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, q);
     return hipGetLastError();
 }
 
