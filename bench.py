@@ -792,9 +792,13 @@ def hostfeed_main(a, rank, local_rank, world, ctx):
     P = max(1, a.producers)
     per_gib = 1.0 if a.gib is None else a.gib            # bytes each producer writes per step
     per = int(per_gib * GiB) & ~7
-    from oracle import oracle as O                        # only to synthesise host bytes + the cpu_baseline leg
-    O.build()
-    src = [O.fill(min(per, 1 << 30), a.seed + 17 * (rank * P + i), 0) for i in range(P)]
+    # host source bytes: generated by the engine's own device generator and copied back (no oracle in the fed path)
+    src = []
+    gen = eng.alloc(min(per, 1 << 30))
+    for i in range(P):
+        eng.fill(gen.ptr, gen.nbytes, seed=a.seed + 17 * (rank * P + i), kind=0)
+        src.append(gen.download())
+    gen.free()
     wsize = 32 << 20
     h2d = eng.h2d_bandwidth(1 << 30) if hasattr(eng, "h2d_bandwidth") else None
 
@@ -868,14 +872,19 @@ def hostfeed_main(a, rank, local_rank, world, ctx):
         tb = torch.tensor([total], dtype=torch.float64, device=ctx.comm_dev)
         ctx.dist.all_reduce(tb, op=ctx.dist.ReduceOp.SUM)
         total = float(tb.item())
-    # parity spot check: one producer's stream cut again through the batch path must give the same records
+    # checker + cpu_baseline leg (the only place this workload touches the oracle): one producer's first 256 MiB through a
+    # fresh stream must give the oracle's records; the oracle's time on that sample is the one-core CPU figure
+    from oracle import oracle as O
+    O.build()
     chk = pbs_plus_amd.PayloadStream(eng, 64 << 20)
     n_chk = min(src[0].size, 256 << 20)
     chk.write(src[0][:n_chk])
     chk.finish()
     srecs = chk.poll()
     chk.close()
+    tc0 = time.perf_counter()
     orecs = O.chunk_and_digest(O.new_config(a.avg), src[0][:n_chk], [(0, n_chk)], impl=1)
+    cpu_dt = time.perf_counter() - tc0
     same = bool(srecs.size == orecs.size and np.array_equal(srecs["end"], orecs["end"])
                 and np.array_equal(srecs["digest"], orecs["digest"]))
     if rank == 0:
@@ -895,6 +904,9 @@ def hostfeed_main(a, rank, local_rank, world, ctx):
                          "measured_h2d_GBps": h2d,
                          "frac_of_measured_h2d": None if not h2d else round(gbs / world / h2d, 3)},
             "stream_records_match_oracle": same,
+            "cpu_baseline": {"value": round(n_chk / GiB / cpu_dt, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
+                             "sample": f"{n_chk >> 20} MiB of one producer's bytes, oracle chunk_and_digest (byte-serial Buzhash + "
+                                       f"SHA-NI), {os.cpu_count()} host cores present", "records_match_gpu": same},
         }
         print(json.dumps(outj), flush=True)
     eng.close()

@@ -237,6 +237,33 @@ class PayloadWriter {
         }
         return {};
     }
+    // The whole payload half of ArchiveWriter.WriteEntryReader for a regular file: 16-byte pxar payload header, `size`
+    // bytes from r (zero-copy), per-file XXH3-64 tee (writeBackedFile, commit_reuse.go:427-468). *payloadOffset = the
+    // header's payload position (what WriteEntryRef / PAYLOAD_REF records, commit_walk.go:455); the hash arrives
+    // later through BackedHashes() under *fileIndex.
+    std::string WritePayloadEntry(std::istream &r, uint64_t size, uint64_t *payloadOffset, uint64_t *fileIndex) {
+        int st = pbsgpu_stream_begin_entry(s_, nullptr, size, payloadOffset);
+        if (st != PBSGPU_OK) return errorf("begin entry", st);
+        if (std::string e = WriteEntryReader(r, size); !e.empty()) return e;
+        st = pbsgpu_stream_end_entry(s_, fileIndex);
+        return st == PBSGPU_OK ? drain() : errorf("end entry", st);
+    }
+    std::string WriteMarker(bool tail) {
+        const int st = pbsgpu_stream_write_marker(s_, nullptr, tail ? 1 : 0);
+        return st == PBSGPU_OK ? std::string() : errorf("write marker", st);
+    }
+    // backedHashes (commit_reuse.go:461): (file index, size, XXH3-64) of every file whose last byte has been cut
+    std::vector<pbsgpu_file_hash> BackedHashes() {
+        std::vector<pbsgpu_file_hash> out;
+        pbsgpu_file_hash buf[256];
+        for (;;) {
+            uint64_t n = 0;
+            if (pbsgpu_stream_poll_files(s_, buf, 256, &n) != PBSGPU_OK) break;
+            out.insert(out.end(), buf, buf + n);
+            if (n < 256) break;
+        }
+        return out;
+    }
     // WriteEntry(entry, content []byte)
     std::string WriteEntry(const void *data, size_t len) {
         const int st = pbsgpu_stream_write(s_, data, len);

@@ -679,21 +679,37 @@ int pbsgpu_wait(pbsgpu_engine *e, uint64_t ticket, uint64_t *nrecords) {
 
 int pbsgpu_ticket_done(pbsgpu_engine *e, uint64_t ticket, int *done) {
     if (!e || !done) return PBSGPU_E_INVALID;
-    return with_ticket(e, ticket, [&](Slot &s) -> int {
-        if (s.synced) {
-            *done = 1;
-            return PBSGPU_OK;
-        }
-        const hipError_t q = hipStreamQuery(s.stream);
-        if (q == hipErrorNotReady) {
-            (void)hipGetLastError();
-            *done = 0;
-            return PBSGPU_OK;
-        }
-        HIPCHK(q);
+    Slot *s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (auto &c : e->slots)
+            if (c->busy && c->ready && c->ticket == ticket) s = c.get();
+    }
+    if (!s) return PBSGPU_E_TICKET;
+    // never blocks: if another thread is waiting on / collecting this very ticket, it simply is not done yet for us
+    std::unique_lock<std::mutex> op(s->op, std::try_to_lock);
+    if (!op.owns_lock()) {
+        *done = 0;
+        return PBSGPU_OK;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!s->busy || !s->ready || s->ticket != ticket) return PBSGPU_E_TICKET;
+    }
+    if (s->synced) {
         *done = 1;
         return PBSGPU_OK;
-    });
+    }
+    CHK(set_device(e));
+    const hipError_t q = hipStreamQuery(s->stream);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *done = 0;
+        return PBSGPU_OK;
+    }
+    HIPCHK(q);
+    *done = 1;
+    return PBSGPU_OK;
 }
 
 int pbsgpu_collect(pbsgpu_engine *e, uint64_t ticket, pbsgpu_record *out, uint64_t cap, uint64_t *nrecords) {

@@ -659,3 +659,54 @@ def test_bench_workloads_at_full_scale_check_against_the_oracle(gpu_lib, workloa
         assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and 0.3 < dd["expected_duplicate_frac"] < 0.5
     if workload == "rechunk":
         assert 0.5 < d["results"]["reused_chunk_bytes_frac"] < 0.95
+
+
+def test_cpp_mirror_payload_entries_and_tee(gpu_lib, O, tmp_path):
+    """include/pbsgpu.hpp, round-2 surface: WritePayloadEntry (header + body + XXH3 tee), WriteMarker, InjectChunks,
+    SuggestBoundary, BackedHashes — a C++ program written against the mirror, checked against xxhash and the oracle
+    run on the layout the program is supposed to have produced."""
+    import os
+    import struct
+    import subprocess
+
+    import xxhash
+
+    from pbs_plus_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_cpp_tee")
+    libdir = os.path.join(root, "pbs_plus_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(root, "tests", "native", "test_cpp_tee.cpp"),
+                    "-L" + libdir, "-lpbsgpu", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "cpp-tee-ok" in out.stdout, out.stdout + out.stderr
+    fmt = _lib.PayloadFormat()
+    _lib.check(_lib.lib().pbsgpu_payload_format_default(fmt), "fmt")
+    sizes = [300000, 0, 17, 70000, 1024, 200001]
+    bodies = [O.fill(n, 100 + k, 0) for k, n in enumerate(sizes)]
+    inj = 123456
+    sec0 = struct.pack("<QQ", fmt.start_type, 16)
+    sec1, offs, pos = b"", [], 16
+    sugg1 = []
+    for k, b in enumerate(bodies):
+        hdr = struct.pack("<QQ", fmt.payload_type, 16 + b.size)
+        if k <= 1:
+            offs.append(len(sec0))
+            sec0 += hdr + b.tobytes()
+        else:
+            if k == 3:
+                sugg1.append(len(sec1))
+            offs.append(len(sec0) + inj + len(sec1))
+            sec1 += hdr + b.tobytes()
+    sec1 += struct.pack("<QQ", fmt.tail_type, 16)
+    cfg = O.new_config(4096)
+    w0 = O.chunk_and_digest(cfg, np.frombuffer(sec0, dtype=np.uint8))
+    w1 = O.chunk_and_digest_suggested(cfg, np.frombuffer(sec1, dtype=np.uint8), [(0, len(sec1))], [sugg1])
+    want = [(int(r["end"]), int(r["size"]), bytes(r["digest"]).hex()) for r in w0] + \
+           [(int(r["end"]) + len(sec0) + inj, int(r["size"]), bytes(r["digest"]).hex()) for r in w1]
+    flines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("F ")]
+    clines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("C ")]
+    assert [(int(f[1]), int(f[2]), int(f[3], 16), int(f[4])) for f in flines] == \
+        [(k, sizes[k], xxhash.xxh3_64_intdigest(bodies[k].tobytes()), offs[k]) for k in range(6)]
+    assert [(int(c[1]), int(c[2]), c[3]) for c in clines] == want
+    assert int(out.stdout.split("cpp-tee-ok")[1]) == len(sec0) + inj + len(sec1)
