@@ -126,7 +126,7 @@ struct PinnedBuf {
 
 // device scalars of one slot (uint32 each)
 enum : int { SC_NCAND = 0, SC_NREC = 1, SC_MAXCNT = 2, SC_QUEUE = 3, SC_WGLIMIT = 4, SC_ZERO = 5 /* stays 0 */,
-             SC_TILEQ = 6 /* u64 */, SC_COUNT = 8 };
+             SC_TILEQ = 6 /* u64 */, SC_PARFB = 8 /* parallel resolve handed the job back */, SC_COUNT = 10 };
 
 enum : int { EV_BEGIN = 0, EV_SCAN0, EV_SCAN1, EV_RESOLVE1, EV_SHA1, EV_COUNT };
 
@@ -139,6 +139,7 @@ struct Slot {
     DevBuf data;  // staged copy of host submits
     DevBuf tile_cnt, tile_off, tile_slots, dense, scan_tmp, scalars, segs, seg_cnt, seg_off, recs, order;
     DevBuf sugg, sugg_idx;  // suggested boundaries (optional)
+    DevBuf par;             // scratch of the parallel single-stream resolve (doubling tables)
     PinnedBuf h_scalars;    // readback of SC_*
     PinnedBuf h_segs;       // pinned copy of the segment table
     PinnedBuf h_sugg;       // pinned copy of suggested offsets + index

@@ -7,6 +7,10 @@
 
 namespace {
 
+// casync / Proxmox BUZHASH_TABLE. EXTERNAL and UNPINNED: typed from memory of the public sources (the oracle carries an
+// independent copy); what corroborates it is the table's designed balance (exactly 128 one-bits per bit column, checked in
+// tests/test_oracle_buzhash.py) and the two hash-determined chunk sizes recalled from upstream's tests. The table is an
+// INPUT everywhere (pbsgpu_config_init(avg, table, ...)): inject the module's own constant when wiring this in.
 const uint32_t kDefaultTable[256] = {
     0x458be752, 0xc10748cc, 0xfbbcdbb8, 0x6ded5b68, 0xb10a82b5, 0x20d75648, 0xdfc5665f, 0xa8428801,
     0x7ebf5191, 0x841135c7, 0x65cc53b3, 0x280a597c, 0x16f60255, 0xc78cbc3e, 0x294415f5, 0xb938d494,
@@ -47,7 +51,10 @@ const uint32_t kDefaultTable[256] = {
 extern "C" {
 
 extern const uint8_t pbsgpu_didx_magic[8];
-const uint8_t pbsgpu_didx_magic[8] = {28, 145, 78, 165, 25, 186, 179, 205};  // DYNAMIC_SIZED_CHUNK_INDEX_1_0
+// DYNAMIC_SIZED_CHUNK_INDEX_1_0 of the Proxmox Backup file formats. EXTERNAL and UNPINNED: typed from memory of the
+// published format, no .didx fixture exists under the reference tree to check it against; a
+// maintainer must confirm it (and the 4096-byte header layout in stream.cpp) against datastore.ParseDynamicIndex.
+const uint8_t pbsgpu_didx_magic[8] = {28, 145, 78, 165, 25, 186, 179, 205};
 
 const char *pbsgpu_strerror(int status) {
     switch (status) {
@@ -120,7 +127,10 @@ int pbsgpu_didx_decode(const uint8_t *in, uint64_t nbytes, pbsgpu_record *out, u
 
 int pbsgpu_payload_format_default(pbsgpu_payload_format *out) {
     if (!out) return PBSGPU_E_INVALID;
-    out->payload_type = 0x28147a1b0b7c1a25ull;  // PXAR_PAYLOAD            (pxar v2 constants, EXTERNAL)
+    // pxar v2 type constants: EXTERNAL and UNPINNED (typed from memory of the published format; no fixture in the
+    // reference tree pins them). Injectable through pbsgpu_payload_format; a maintainer must confirm them against the
+    // module's format package.
+    out->payload_type = 0x28147a1b0b7c1a25ull;  // PXAR_PAYLOAD
     out->start_type = 0x834c68c2194a4ed2ull;    // PXAR_PAYLOAD_START_MARKER
     out->tail_type = 0x6c72b78b984c81b5ull;     // PXAR_PAYLOAD_TAIL_MARKER
     out->with_start = 1;

@@ -30,6 +30,7 @@ struct ScanParams {
     uint32_t *tile_slots;     // [ntiles * cap] end offset within tile (1..kScanTile), a-coords
     unsigned long long *tile_queue;  // device counter, zero at launch: next tile to hand out
     uint32_t tiles_per_wave;         // k_scan3: 0 = persistent workgroups, else a wave retires after this many tiles
+    uint32_t shared_chip;            // other batches of the engine are in flight (their SHA chains are running)
 };
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st);
@@ -46,6 +47,14 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
                           uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st);
+
+// one long stream without suggested boundaries: the cut chain followed by pointer doubling (kernels.hip); `scratch` holds
+// resolve_par_scratch_bytes(node_cap, levels); falls back to the serial walk when there are more candidates than node_cap - 1
+size_t resolve_par_scratch_bytes(uint32_t node_cap, uint32_t levels);
+hipError_t launch_resolve_single_par(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs, uint32_t effmin,
+                                     uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec, pbsgpu_record *recs,
+                                     uint64_t rec_cap, void *scratch, uint32_t node_cap, uint32_t levels, uint32_t *fallback,
+                                     hipStream_t st);
 
 // optional suggested boundaries (payload chunker): offsets[index[s] .. index[s+1]) ascending, relative to segment s
 struct Suggested {

@@ -568,6 +568,17 @@ static int scan_cu_reserve(int num_cus) {
     return num_cus >= 64 ? 16 : 0;
 }
 
+// PBSGPU_SCAN_CUS_SHARED: CUs the scan may take while OTHER batches are hashing (0 = no extra limit). A scan at full
+// tilt pulls the chip clock down and with it every running SHA chain (+21-40 % chain time on 240 CUs, +3.5 % on 64,
+// scripts/r2_probe_clock.py); the SHA chains are the critical path of every pass in flight, the scan is not.
+static int scan_cus_shared() {
+    static const int v = []() {
+        const char *e = getenv("PBSGPU_SCAN_CUS_SHARED");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 static uint32_t scan_tiles_per_wave() {
     static const int v = []() {
         const char *e = getenv("PBSGPU_SCAN_TILES_PER_WAVE");
@@ -596,7 +607,8 @@ static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st)
     if (q.tiles_per_wave) {
         blocks = (p.ntiles + 8ull * q.tiles_per_wave - 1) / (8ull * q.tiles_per_wave);
     } else {
-        const uint64_t usable = (uint64_t)std::max(1, num_cus - scan_cu_reserve(num_cus));
+        uint64_t usable = (uint64_t)std::max(1, num_cus - scan_cu_reserve(num_cus));
+        if (p.shared_chip && scan_cus_shared() > 0) usable = std::min<uint64_t>(usable, (uint64_t)scan_cus_shared());
         if (blocks > usable) blocks = usable;
     }
     hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, q);
@@ -835,10 +847,11 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
                                                  const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
                                                  uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
                                                  pbsgpu_record *recs, uint64_t rec_cap, const uint64_t *sugg,
-                                                 const uint32_t *sugg_idx, uint32_t cmin) {
+                                                 const uint32_t *sugg_idx, uint32_t cmin, const uint32_t *gate) {
     const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (seg >= nseg) return;
+    if (gate && *gate == 0) return;  // fallback launch behind k_resolve_par: only if that kernel handed the job back
     __builtin_amdgcn_s_setprio(2);  // a latency-bound serial walk: do not queue behind throughput waves on this SIMD
     const uint64_t n = *ncand_p;
     const uint64_t A = segs[seg].offset, B = A + segs[seg].length;
@@ -910,7 +923,7 @@ hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, co
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
                        maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0, sg.offsets,
-                       sg.index, sg.cmin);
+                       sg.index, sg.cmin, (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -920,7 +933,162 @@ hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, co
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
-                       maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin);
+                       maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin,
+                       (const uint32_t *)nullptr);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------
+// One long stream, resolved in parallel. The serial walk above costs ~0.26 us per chunk on a single wave (4.6 ms for
+// the 17.7 k chunks of a 64 GiB stream, 11 ms when that wave shares its SIMD with SHA waves). The cut chain is a
+// FUNCTION on nodes {stream start, every candidate}: next(v) = the first candidate cut reached from a cut at v (possibly
+// after some forced max-size cuts), so it can be followed by pointer doubling:
+//   1. every node computes next(v), the number of records of that hop (forced cuts + the closing one) and its end;
+//   2. doubling tables J_m = next^(2^m) and R_m = records along 2^m hops (log2(n) rounds, one workgroup);
+//   3. the k-th hop of the path from the stream start is found independently for every k by decomposing k in binary,
+//      and writes its records at the prefix count R gives it.
+// ~20 barrier-separated rounds of a few memory accesses each instead of 17 k dependent iterations. Falls back to the
+// serial walk when the node count exceeds the scratch capacity (dense / crafted inputs) — same kernel, wave 0.
+constexpr uint32_t kParEnd = 0xffffffffu;  // terminal node id
+
+__global__ __launch_bounds__(1024) void k_resolve_par(const uint64_t *cands, const uint32_t *ncand_p, const pbsgpu_segment *segs,
+                                                      uint32_t effmin, uint32_t maxsz, uint32_t *nrec_out, pbsgpu_record *recs,
+                                                      uint64_t rec_cap, uint32_t *J, uint32_t *R, uint64_t *endpos,
+                                                      uint32_t node_cap, uint32_t levels_cap, uint32_t *fallback) {
+    const uint64_t n64 = *ncand_p;
+    const uint64_t A = segs[0].offset, B = A + segs[0].length;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    // nodes: 0 = stream start (position A), i + 1 = candidate i
+    const uint64_t nodes64 = n64 + 1;
+    uint32_t levels = 1;
+    while ((1ull << levels) < nodes64 + 1) ++levels;
+    if (nodes64 > node_cap || levels > levels_cap || B == A) {  // uniform: let the serial kernel do it
+        if (tid == 0) *fallback = (B == A) ? 0u : 1u;
+        if (B == A && tid == 0) *nrec_out = 0;
+        return;
+    }
+    if (tid == 0) *fallback = 0;
+    const uint32_t nodes = (uint32_t)nodes64, n = (uint32_t)n64;
+    // ---- 1. next(v) for every node
+    for (uint32_t v = tid; v < nodes; v += nth) {
+        uint64_t s = (v == 0) ? A : cands[v - 1];
+        uint32_t k = 0, nx = kParEnd;
+        uint64_t e = B;
+        if (s >= B || (v && s <= A)) {  // a candidate at/after the end or before the start never becomes a cut
+            J[v] = kParEnd;
+            R[v] = 0;
+            endpos[v] = B;
+            continue;
+        }
+        uint32_t lo = v;  // candidates are ascending: the next cut lies behind this node's own candidate
+        for (;;) {
+            const uint64_t tlo = s + effmin, thi = s + maxsz;
+            uint32_t hi = n;  // first candidate index j >= lo with cands[j] >= tlo
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cands[mid] < tlo) lo = mid + 1; else hi = mid;
+            }
+            const uint64_t c = (lo < n) ? cands[lo] : ~0ull;
+            if (c < thi && c <= B) {  // a candidate closes the chunk
+                e = c;
+                nx = (c < B) ? lo + 1 : kParEnd;
+                ++k;
+                break;
+            }
+            if (thi >= B) {  // the stream end closes it
+                e = B;
+                nx = kParEnd;
+                ++k;
+                break;
+            }
+            if (lo >= n) {  // no candidate left at all: forced cuts to the end, in one step
+                const uint64_t more = (B - s + maxsz - 1) / maxsz;  // chunks from s to B
+                k += (uint32_t)more;
+                e = B;
+                nx = kParEnd;
+                break;
+            }
+            s = thi;  // forced cut at max size, keep walking
+            ++k;
+        }
+        J[v] = nx;
+        R[v] = k;
+        endpos[v] = e;
+    }
+    __syncthreads();
+    // ---- 2. doubling tables (level m at offset m * node_cap)
+    for (uint32_t m = 1; m < levels; ++m) {
+        const uint32_t *Jp = J + (size_t)(m - 1) * node_cap, *Rp = R + (size_t)(m - 1) * node_cap;
+        uint32_t *Jm = J + (size_t)m * node_cap, *Rm = R + (size_t)m * node_cap;
+        for (uint32_t v = tid; v < nodes; v += nth) {
+            const uint32_t a = Jp[v];
+            if (a == kParEnd) {
+                Jm[v] = kParEnd;
+                Rm[v] = Rp[v];
+            } else {
+                Jm[v] = Jp[a];
+                Rm[v] = Rp[v] + Rp[a];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 3. hops on the path from the start, and the total record count
+    __shared__ uint32_t s_hops, s_total;
+    if (tid == 0) {
+        uint32_t pos = 0, hops = 0, total = 0;
+        for (int m = (int)levels - 1; m >= 0; --m) {
+            const uint32_t a = J[(size_t)m * node_cap + pos];
+            if (a != kParEnd) {
+                total += R[(size_t)m * node_cap + pos];
+                hops += 1u << m;
+                pos = a;
+            }
+        }
+        s_hops = hops + 1;               // the last hop ends in the terminal node
+        s_total = total + R[pos];
+        *nrec_out = s_total;
+    }
+    __syncthreads();
+    const uint32_t hops = s_hops;
+    for (uint32_t h = tid; h < hops; h += nth) {
+        uint32_t pos = 0, off = 0;       // node of hop h and records written before it
+        for (int m = (int)levels - 1; m >= 0; --m)
+            if (h & (1u << m)) {
+                off += R[(size_t)m * node_cap + pos];
+                pos = J[(size_t)m * node_cap + pos];
+            }
+        uint64_t s = (pos == 0) ? A : cands[pos - 1];
+        const uint32_t k = R[pos];
+        const uint64_t e = endpos[pos];
+        for (uint32_t t = 0; t < k; ++t) {  // k - 1 forced max-size cuts, then the closing cut at e
+            const uint64_t end = (t + 1 < k) ? s + maxsz : e;
+            if ((uint64_t)off + t < rec_cap) {
+                pbsgpu_record *r = recs + off + t;
+                r->end = end - A;
+                r->segment = 0;
+                r->size = (uint32_t)(end - s);
+            }
+            s = end;
+        }
+    }
+}
+
+size_t resolve_par_scratch_bytes(uint32_t node_cap, uint32_t levels) {
+    return (size_t)node_cap * levels * 8 + (size_t)node_cap * 8 + 256;
+}
+
+hipError_t launch_resolve_single_par(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs, uint32_t effmin,
+                                     uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec, pbsgpu_record *recs,
+                                     uint64_t rec_cap, void *scratch, uint32_t node_cap, uint32_t levels, uint32_t *fallback,
+                                     hipStream_t st) {
+    uint32_t *J = static_cast<uint32_t *>(scratch);
+    uint32_t *R = J + (size_t)node_cap * levels;
+    uint64_t *endpos = reinterpret_cast<uint64_t *>(R + (size_t)node_cap * levels);
+    hipLaunchKernelGGL(k_resolve_par, dim3(1), dim3(1024), 0, st, cands, ncand, segs, effmin, maxsz, nrec, recs, rec_cap, J, R,
+                       endpos, node_cap, levels, fallback);
+    // the serial walk, gated: runs only if the parallel kernel handed the job back (*fallback != 0)
+    hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
+                       rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback);
     return hipGetLastError();
 }
 
@@ -929,7 +1097,7 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
                                  pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec,
-                       zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin);
+                       zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin, (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 

@@ -710,3 +710,41 @@ def test_cpp_mirror_payload_entries_and_tee(gpu_lib, O, tmp_path):
         [(k, sizes[k], xxhash.xxh3_64_intdigest(bodies[k].tobytes()), offs[k]) for k in range(6)]
     assert [(int(c[1]), int(c[2]), c[3]) for c in clines] == want
     assert int(out.stdout.split("cpp-tee-ok")[1]) == len(sec0) + inj + len(sec1)
+
+
+def test_parallel_resolve_equals_the_serial_walk_on_awkward_streams(gpu_lib):
+    """k_resolve_par (pointer doubling over the candidate list) on everything the serial walk handles: small averages
+    with thousands of candidates, zero runs (forced max-size cuts only), a candidate exactly at the stream end, streams
+    shorter than min, dense periodic candidates (falls back when they exceed the node capacity), min = 64. Forced on for
+    every size through PBSGPU_RESOLVE_PAR_MIN=0 in a subprocess (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "from pbs_plus_amd import Engine, buzhash\n"
+        "from tests.helpers import records_equal, describe_mismatch\n"
+        "rng = np.random.default_rng(7)\n"
+        "for avg in (256, 4096, 65536, 4 << 20):\n"
+        "    eng = Engine(buzhash.NewConfig(avg)); cfg = O.new_config(avg)\n"
+        "    cases = [O.fill(avg * 300 + 17, 5, 0), O.fill(avg * 200, 6, 3), np.zeros(avg * 40 + 5, np.uint8), O.fill(63, 7, 0),\n"
+        "             O.fill(cfg.min - 1, 8, 0), O.fill(cfg.max, 9, 1), O.fill(1, 10, 0), O.fill(avg * 64, 11, 2)]\n"
+        "    if avg == 4096:\n"
+        "        for _ in range(4000):\n"
+        "            block = rng.integers(0, 256, 64, dtype=np.uint8)\n"
+        "            if O.candidates(cfg, np.tile(block, 4)).size: break\n"
+        "        cases += [np.tile(block, 3000), np.tile(block, 600_000)]   # dense: 3 k candidates / 600 k (> node capacity -> serial)\n"
+        "        d = O.fill(avg * 50, 12, 0); c = O.candidates(cfg, d)\n"
+        "        cases.append(d[:int(c[len(c) // 2])])                      # a candidate exactly at the stream end\n"
+        "    for i, data in enumerate(cases):\n"
+        "        got, want = eng.chunk_and_digest(data), O.chunk_and_digest(cfg, data)\n"
+        "        assert records_equal(got, want), (avg, i, describe_mismatch(got, want))\n"
+        "    eng.close()\n"
+        "print('par-ok')\n" % root)
+    env = dict(os.environ, PBSGPU_RESOLVE_PAR_MIN="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "par-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
