@@ -7,8 +7,8 @@
 
 namespace {
 
-// casync / Proxmox BUZHASH_TABLE. EXTERNAL and UNPINNED: typed from memory of the public sources (the oracle carries an
-// independent copy); what corroborates it is the table's designed balance (exactly 128 one-bits per bit column, checked in
+// casync / Proxmox BUZHASH_TABLE. EXTERNAL and UNPINNED: recalled, not copied out of any file in the reference tree (the
+// parity checker carries its own copy); what corroborates it is the table's designed balance (exactly 128 one-bits per bit column, checked in
 // tests/test_oracle_buzhash.py) and the two hash-determined chunk sizes recalled from upstream's tests. The table is an
 // INPUT everywhere (pbsgpu_config_init(avg, table, ...)): inject the module's own constant when wiring this in.
 const uint32_t kDefaultTable[256] = {
