@@ -272,6 +272,7 @@ struct pbsgpu_stream {
     PinnedBuf stage[kStreamStages];
     hipEvent_t stage_ev[kStreamStages] = {};
     int stage_idx = 0;
+    size_t stage_fill = 0;         // bytes gathered in stage[stage_idx] and not yet pushed (small writes are coalesced)
     int reserved = -1;             // staging buffer handed out by pbsgpu_stream_reserve
     uint64_t base = 0;             // absolute stream offset (incl. injected bytes) of the carry's first byte
     uint64_t written = 0;
@@ -564,7 +565,8 @@ int stream_drain(pbsgpu_stream *s) {
     return PBSGPU_OK;
 }
 
-// H2D of one staged piece behind the window's current fill
+// H2D of one staged piece of n bytes (stage[k][0..n)) behind the window's current fill. `written` was advanced when the
+// bytes were accepted; `fill` advances here.
 int stream_push_piece(pbsgpu_stream *s, int k, size_t n) {
     pbsgpu_engine *e = s->eng;
     const int c = (int)(e->copy_rr.fetch_add(1, std::memory_order_relaxed) % e->copy_streams.size());
@@ -576,10 +578,16 @@ int stream_push_piece(pbsgpu_stream *s, int k, size_t n) {
     s->piece_used[c] = true;
     s->stage_idx = (k + 1) % kStreamStages;
     s->fill += n;
-    s->written += n;
-    if (s->in_entry) s->entry_left -= std::min<uint64_t>(s->entry_left, n);
     if (s->fill == s->window) CHK(stream_flush(s, false));
     return PBSGPU_OK;
+}
+
+// push whatever small writes have gathered in the current staging buffer (before a cut / finish / reserve)
+int stream_push_staged(pbsgpu_stream *s) {
+    if (s->stage_fill == 0) return PBSGPU_OK;
+    const size_t n = s->stage_fill;
+    s->stage_fill = 0;
+    return stream_push_piece(s, s->stage_idx, n);
 }
 
 }  // namespace
@@ -707,17 +715,24 @@ int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
     if (len) CHK(set_device(s->eng));
     const uint8_t *p = static_cast<const uint8_t *>(data);
     while (len) {
-        size_t n = (size_t)std::min<uint64_t>(len, s->window - s->fill);
-        n = std::min(n, kStreamStage);
-        // caller bytes -> library-owned pinned staging -> device window (async); the memcpy runs on the caller's
-        // thread with no lock held, so several streams copy in parallel
+        // caller bytes -> library-owned pinned staging -> device window (async). Writes are COALESCED in the staging
+        // buffer (an io.Copy feeds 32 KiB at a time, a payload header is 16 bytes): one H2D piece per 32 MiB or per
+        // window edge, not per call. The memcpy runs on the caller's thread with no lock held, so several streams copy
+        // in parallel.
         const int k = s->stage_idx;
-        CHK(s->stage[k].ensure(kStreamStage));
-        HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
-        std::memcpy(s->stage[k].p, p, n);
-        CHK(stream_push_piece(s, k, n));
+        if (s->stage_fill == 0) {
+            CHK(s->stage[k].ensure(kStreamStage));
+            HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
+        }
+        size_t n = std::min(len, kStreamStage - s->stage_fill);
+        n = (size_t)std::min<uint64_t>(n, s->window - s->fill - s->stage_fill);
+        std::memcpy(s->stage[k].as<uint8_t>() + s->stage_fill, p, n);
+        s->stage_fill += n;
+        s->written += n;
+        if (s->in_entry) s->entry_left -= std::min<uint64_t>(s->entry_left, n);
         p += n;
         len -= n;
+        if (s->stage_fill == kStreamStage || s->fill + s->stage_fill == s->window) CHK(stream_push_staged(s));
     }
     return PBSGPU_OK;
 }
@@ -726,6 +741,7 @@ int pbsgpu_stream_reserve(pbsgpu_stream *s, void **buf, size_t *cap) {
     if (!s || !buf || !cap) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
     CHK(set_device(s->eng));
+    CHK(stream_push_staged(s));  // bytes gathered by earlier small writes go first; the reserved buffer starts empty
     const int k = s->stage_idx;
     CHK(s->stage[k].ensure(kStreamStage));
     HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
@@ -746,6 +762,8 @@ int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len) {
     s->reserved = -1;
     if (len == 0) return PBSGPU_OK;
     CHK(set_device(s->eng));
+    s->written += len;
+    if (s->in_entry) s->entry_left -= std::min<uint64_t>(s->entry_left, len);
     return stream_push_piece(s, k, len);
 }
 
@@ -834,6 +852,8 @@ int pbsgpu_stream_end_entry(pbsgpu_stream *s, uint64_t *file_index) {
 int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0 || s->in_entry) return PBSGPU_E_STATE;
+    CHK(set_device(s->eng));
+    CHK(stream_push_staged(s));
     CHK(stream_flush(s, true));
     s->base += inject_bytes;
     s->inject_total += inject_bytes;
@@ -845,6 +865,8 @@ int pbsgpu_stream_finish(pbsgpu_stream *s) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished) return PBSGPU_OK;
     if (s->reserved >= 0 || s->file_open) return PBSGPU_E_STATE;
+    CHK(set_device(s->eng));
+    CHK(stream_push_staged(s));
     CHK(stream_flush(s, true));
     CHK(stream_drain(s));
     s->finished = true;
