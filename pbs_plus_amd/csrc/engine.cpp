@@ -167,11 +167,7 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
     p.tile_cnt = s.tile_cnt.as<uint32_t>();
     p.tile_slots = s.tile_slots.as<uint32_t>();
     p.tile_queue = reinterpret_cast<unsigned long long *>(s.scalars.as<uint32_t>() + SC_TILEQ);
-    {   // racy read on purpose (a hint): are other tickets in flight?
-        int busy = 0;
-        for (auto &c : e->slots) busy += c->busy ? 1 : 0;
-        p.shared_chip = busy > 1 ? 1u : 0u;
-    }
+    p.shared_chip = e->tickets_out.load(std::memory_order_relaxed) > 1 ? 1u : 0u;  // a hint: other batches are hashing
     HIPCHK(hipEventRecord(s.ev[EV_SCAN0], s.stream));
     HIPCHK(pbsk::launch_scan(p, e->num_cus, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SCAN1], s.stream));
@@ -269,6 +265,7 @@ static Slot *acquire_pool_slot(pbsgpu_engine *e) {
         if (!s->busy) {
             s->busy = true;
             s->ready = false;
+            e->tickets_out.fetch_add(1, std::memory_order_relaxed);
             return s.get();
         }
     return nullptr;
@@ -276,6 +273,7 @@ static Slot *acquire_pool_slot(pbsgpu_engine *e) {
 
 static void release_pool_slot(pbsgpu_engine *e, Slot *s) {
     std::lock_guard<std::mutex> lk(e->mu);
+    if (s->busy) e->tickets_out.fetch_sub(1, std::memory_order_relaxed);
     s->busy = false;
     s->ready = false;
 }

@@ -229,6 +229,7 @@ struct pbsgpu_engine {
     std::vector<std::unique_ptr<pbse::Slot>> aux;    // leased to synchronous helper calls
     std::vector<char> aux_busy;
     uint64_t next_ticket = 1;
+    std::atomic<int> tickets_out{0};  // pool slots in use (read without the lock as a scheduling hint)
     std::atomic<uint32_t> cap_hint{0};       // per-tile slot capacity that a density retry settled on
     std::atomic<uint32_t> cap_hint_tile{0};  // ... for this tile size
     std::mutex mu;
