@@ -493,15 +493,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     ctx = Ctx()
     backend = os.environ.get("PBS_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; gloo only for CPU tests / 1-GPU debugging
-    if world > 1:
+    # PBS_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, collectives, FIFO collection) even
+    # with ONE rank — the only way to exercise the RCCL ("nccl") calls on a single-GPU box
+    if world > 1 or os.environ.get("PBS_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ngpu0 = torch.cuda.device_count()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(ngpu0, 1))
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank % max(ngpu0, 1)}"))
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank % max(ngpu0, 1)}"))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
         ctx.dist = dist
     ngpu = torch.cuda.device_count()
     if world > 1 and backend != "nccl":

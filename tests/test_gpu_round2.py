@@ -748,3 +748,34 @@ def test_parallel_resolve_equals_the_serial_walk_on_awkward_streams(gpu_lib):
     env = dict(os.environ, PBSGPU_RESOLVE_PAR_MIN="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "par-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("workload", ["stream64g", "corpus_dup"])
+def test_bench_rccl_code_path_with_one_rank(gpu_lib, workload):
+    """The "nccl" (= RCCL) branch of bench.py on real hardware: process-group init with device_id, barrier, all_reduce
+    (MAX / SUM), all_gather_into_tensor of the uint8 record payload, destroy — forced on with ONE rank
+    (PBS_BENCH_FORCE_DIST), because the test box has a single GPU. The 8-GPU runs of the driver take exactly this path."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               PBS_BENCH_FORCE_DIST="1", PBS_BENCH_BACKEND="nccl")
+    extra = ["--slots", "2"] if workload == "stream64g" else ["--file-mib", "8"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", workload, "--gib", "0.25",
+                          "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--avg", str(1 << 20)] + extra,
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    if workload == "corpus_dup":
+        dd = d["results"]["dedup"]
+        assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9
+    else:
+        assert d["results"]["dedup_last_step"]["nrecords"] > 0
