@@ -209,8 +209,21 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
         const char *v = getenv("PBSGPU_RESOLVE_PAR_MIN");
         return v ? strtoull(v, nullptr, 10) : (64ull << 20);
     }();
-    if (s.nseg == 1 && !s.nsugg && !par_off && s.nbytes >= par_min &&
-        s.par.ensure(pbsk::resolve_par_scratch_bytes(kParNodes, kParLevels)) == PBSGPU_OK) {
+    // expected candidates = 3 per (mask + 1) bytes; twice that is the node budget (dense / crafted inputs fall back)
+    const uint64_t expect = (uint64_t)(3.0 * (double)s.nbytes / ((double)e->cfg.mask + 1.0)) + 64;
+    uint32_t big_nodes = 0, big_levels = 0;
+    if (2 * expect + 2 > kParNodes && 2 * expect + 2 <= (1ull << 22)) {  // many candidates: the grid-wide variant
+        big_nodes = 1u << 19;
+        while (big_nodes < 2 * expect + 2) big_nodes <<= 1;
+        while ((1ull << big_levels) < (uint64_t)big_nodes + 1) ++big_levels;
+    }
+    const bool par_ok = s.nseg == 1 && !s.nsugg && !par_off && s.nbytes >= par_min;
+    if (par_ok && big_nodes && s.par.ensure(pbsk::resolve_par_scratch_bytes(big_nodes, big_levels)) == PBSGPU_OK) {
+        HIPCHK(pbsk::launch_resolve_single_par_grid(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, e->effmin, e->cfg.max,
+                                                    sc + SC_ZERO, sc + SC_NREC, s.recs.as<pbsgpu_record>(), s.rec_cap,
+                                                    s.par.p, big_nodes, big_levels, sc + SC_PARFB, sc + SC_PARHOPS,
+                                                    s.stream));
+    } else if (par_ok && !big_nodes && s.par.ensure(pbsk::resolve_par_scratch_bytes(kParNodes, kParLevels)) == PBSGPU_OK) {
         HIPCHK(pbsk::launch_resolve_single_par(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, e->effmin, e->cfg.max,
                                                sc + SC_ZERO, sc + SC_NREC, s.recs.as<pbsgpu_record>(), s.rec_cap, s.par.p,
                                                kParNodes, kParLevels, sc + SC_PARFB, s.stream));

@@ -126,7 +126,7 @@ struct PinnedBuf {
 
 // device scalars of one slot (uint32 each)
 enum : int { SC_NCAND = 0, SC_NREC = 1, SC_MAXCNT = 2, SC_QUEUE = 3, SC_WGLIMIT = 4, SC_ZERO = 5 /* stays 0 */,
-             SC_TILEQ = 6 /* u64 */, SC_PARFB = 8 /* parallel resolve handed the job back */, SC_COUNT = 10 };
+             SC_TILEQ = 6 /* u64 */, SC_PARFB = 8 /* parallel resolve handed the job back */, SC_PARHOPS = 9, SC_COUNT = 10 };
 
 enum : int { EV_BEGIN = 0, EV_SCAN0, EV_SCAN1, EV_RESOLVE1, EV_SHA1, EV_COUNT };
 

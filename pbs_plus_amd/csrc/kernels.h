@@ -56,6 +56,12 @@ hipError_t launch_resolve_single_par(const uint64_t *cands, const uint32_t *ncan
                                      uint64_t rec_cap, void *scratch, uint32_t node_cap, uint32_t levels, uint32_t *fallback,
                                      hipStream_t st);
 
+// ... the same for many candidates (small average chunk sizes): one grid-wide launch per phase / doubling level
+hipError_t launch_resolve_single_par_grid(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                          uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
+                                          pbsgpu_record *recs, uint64_t rec_cap, void *scratch, uint32_t node_cap, uint32_t levels,
+                                          uint32_t *fallback, uint32_t *hops, hipStream_t st);
+
 // optional suggested boundaries (payload chunker): offsets[index[s] .. index[s+1]) ascending, relative to segment s
 struct Suggested {
     const uint64_t *offsets = nullptr;  // device

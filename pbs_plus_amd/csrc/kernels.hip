@@ -1073,6 +1073,144 @@ __global__ __launch_bounds__(1024) void k_resolve_par(const uint64_t *cands, con
     }
 }
 
+// ---- the same algorithm for MANY candidates (small average chunk sizes: a 64 GiB stream at avg 64 KiB has 1.5 M
+// candidates and 1.1 M chunks — the serial walk takes 278 ms there, the single workgroup above would crawl): one
+// grid-wide launch per phase / doubling level instead of barriers inside one workgroup.
+__device__ __forceinline__ bool par_active(const uint32_t *ncand_p, uint32_t node_cap) {
+    return (uint64_t)*ncand_p + 1 <= node_cap;
+}
+
+__global__ __launch_bounds__(256) void k_par_next(const uint64_t *cands, const uint32_t *ncand_p, const pbsgpu_segment *segs,
+                                                  uint32_t effmin, uint32_t maxsz, uint32_t *J, uint32_t *R, uint64_t *endpos,
+                                                  uint32_t node_cap, uint32_t *fallback, uint32_t *nrec_out) {
+    const uint64_t A = segs[0].offset, B = A + segs[0].length;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = par_active(ncand_p, node_cap) && B > A;
+    if (v == 0) {
+        *fallback = (ok || B == A) ? 0u : 1u;
+        if (B == A) *nrec_out = 0;
+    }
+    if (!ok) return;
+    const uint32_t n = *ncand_p, nodes = n + 1;
+    if (v >= nodes) return;
+    uint64_t s = (v == 0) ? A : cands[v - 1];
+    uint32_t k = 0, nx = kParEnd;
+    uint64_t e = B;
+    if (s >= B || (v && s <= A)) {
+        J[v] = kParEnd;
+        R[v] = 0;
+        endpos[v] = B;
+        return;
+    }
+    uint32_t lo = v;
+    for (;;) {
+        const uint64_t tlo = s + effmin, thi = s + maxsz;
+        uint32_t hi = n;
+        // the next cut is close: gallop before the binary search (keeps the search inside a few cache lines)
+        uint32_t step = 1;
+        while (lo + step < n && cands[lo + step] < tlo) { lo += step; step <<= 1; }
+        hi = min(n, lo + step + 1);
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cands[mid] < tlo) lo = mid + 1; else hi = mid;
+        }
+        const uint64_t c = (lo < n) ? cands[lo] : ~0ull;
+        if (c < thi && c <= B) { e = c; nx = (c < B) ? lo + 1 : kParEnd; ++k; break; }
+        if (thi >= B) { e = B; nx = kParEnd; ++k; break; }
+        if (lo >= n) { k += (uint32_t)((B - s + maxsz - 1) / maxsz); e = B; nx = kParEnd; break; }
+        s = thi;
+        ++k;
+    }
+    J[v] = nx;
+    R[v] = k;
+    endpos[v] = e;
+}
+
+__global__ __launch_bounds__(256) void k_par_double(const uint32_t *Jp, const uint32_t *Rp, uint32_t *Jm, uint32_t *Rm,
+                                                    const uint32_t *ncand_p, uint32_t node_cap, const pbsgpu_segment *segs) {
+    if (!par_active(ncand_p, node_cap) || segs[0].length == 0) return;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= *ncand_p + 1) return;
+    const uint32_t a = Jp[v];
+    if (a == kParEnd) {
+        Jm[v] = kParEnd;
+        Rm[v] = Rp[v];
+    } else {
+        Jm[v] = Jp[a];
+        Rm[v] = Rp[v] + Rp[a];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_par_count(const uint32_t *J, const uint32_t *R, uint32_t levels, uint32_t node_cap,
+                                                  const uint32_t *ncand_p, const pbsgpu_segment *segs, uint32_t *nrec_out,
+                                                  uint32_t *hops_out) {
+    if (threadIdx.x) return;
+    if (!par_active(ncand_p, node_cap) || segs[0].length == 0) { *hops_out = 0; return; }
+    uint32_t pos = 0, hops = 0, total = 0;
+    for (int m = (int)levels - 1; m >= 0; --m) {
+        const uint32_t a = J[(size_t)m * node_cap + pos];
+        if (a != kParEnd) {
+            total += R[(size_t)m * node_cap + pos];
+            hops += 1u << m;
+            pos = a;
+        }
+    }
+    *hops_out = hops + 1;
+    *nrec_out = total + R[pos];
+}
+
+__global__ __launch_bounds__(256) void k_par_emit(const uint64_t *cands, const pbsgpu_segment *segs, uint32_t maxsz,
+                                                  const uint32_t *J, const uint32_t *R, const uint64_t *endpos, uint32_t levels,
+                                                  uint32_t node_cap, const uint32_t *hops_p, pbsgpu_record *recs, uint64_t rec_cap) {
+    const uint32_t hops = *hops_p;
+    const uint64_t A = segs[0].offset;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < hops; h += stride) {
+        uint32_t pos = 0, off = 0;
+        for (int m = (int)levels - 1; m >= 0; --m)
+            if (h & (1u << m)) {
+                off += R[(size_t)m * node_cap + pos];
+                pos = J[(size_t)m * node_cap + pos];
+            }
+        uint64_t s = (pos == 0) ? A : cands[pos - 1];
+        const uint32_t k = R[pos];
+        const uint64_t e = endpos[pos];
+        for (uint32_t t = 0; t < k; ++t) {
+            const uint64_t end = (t + 1 < k) ? s + maxsz : e;
+            if ((uint64_t)off + t < rec_cap) {
+                pbsgpu_record *r = recs + off + t;
+                r->end = end - A;
+                r->segment = 0;
+                r->size = (uint32_t)(end - s);
+            }
+            s = end;
+        }
+    }
+}
+
+hipError_t launch_resolve_single_par_grid(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
+                                          uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
+                                          pbsgpu_record *recs, uint64_t rec_cap, void *scratch, uint32_t node_cap, uint32_t levels,
+                                          uint32_t *fallback, uint32_t *hops, hipStream_t st) {
+    uint32_t *J = static_cast<uint32_t *>(scratch);
+    uint32_t *R = J + (size_t)node_cap * levels;
+    uint64_t *endpos = reinterpret_cast<uint64_t *>(R + (size_t)node_cap * levels);
+    const unsigned nb = (node_cap + 255) / 256;
+    hipLaunchKernelGGL(k_par_next, dim3(nb), dim3(256), 0, st, cands, ncand, segs, effmin, maxsz, J, R, endpos, node_cap, fallback,
+                       nrec);
+    for (uint32_t m = 1; m < levels; ++m)
+        hipLaunchKernelGGL(k_par_double, dim3(nb), dim3(256), 0, st, J + (size_t)(m - 1) * node_cap, R + (size_t)(m - 1) * node_cap,
+                           J + (size_t)m * node_cap, R + (size_t)m * node_cap, ncand, node_cap, segs);
+    hipLaunchKernelGGL(k_par_count, dim3(1), dim3(64), 0, st, (const uint32_t *)J, (const uint32_t *)R, levels, node_cap, ncand, segs,
+                       nrec, hops);
+    hipLaunchKernelGGL(k_par_emit, dim3(std::min(nb, 4096u)), dim3(256), 0, st, cands, segs, maxsz, (const uint32_t *)J,
+                       (const uint32_t *)R, (const uint64_t *)endpos, levels, node_cap, (const uint32_t *)hops, recs, rec_cap);
+    // the serial walk, gated: runs only if there were more candidates than nodes (*fallback != 0)
+    hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
+                       rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback);
+    return hipGetLastError();
+}
+
 size_t resolve_par_scratch_bytes(uint32_t node_cap, uint32_t levels) {
     return (size_t)node_cap * levels * 8 + (size_t)node_cap * 8 + 256;
 }

@@ -733,6 +733,8 @@ def test_parallel_resolve_equals_the_serial_walk_on_awkward_streams(gpu_lib):
         "    eng = Engine(buzhash.NewConfig(avg)); cfg = O.new_config(avg)\n"
         "    cases = [O.fill(avg * 300 + 17, 5, 0), O.fill(avg * 200, 6, 3), np.zeros(avg * 40 + 5, np.uint8), O.fill(63, 7, 0),\n"
         "             O.fill(cfg.min - 1, 8, 0), O.fill(cfg.max, 9, 1), O.fill(1, 10, 0), O.fill(avg * 64, 11, 2)]\n"
+        "    if avg == 256:\n"
+        "        cases += [O.fill(64 << 20, 13, 0), O.fill(48 << 20, 14, 3)]   # ~400 k candidates: the grid-wide doubling variant\n"
         "    if avg == 4096:\n"
         "        for _ in range(4000):\n"
         "            block = rng.integers(0, 256, 64, dtype=np.uint8)\n"
