@@ -50,7 +50,10 @@ HBM_BYTES = 288e9           # spec capacity
 # Integer VALU issue ceiling for the SHA-256 instruction mix (v_alignbit / v_bitop3 / v_add3 / v_bfi, all VOP3):
 # 620 G wave64-instructions/s chip-wide at 8 waves/SIMD (profiles/r01_ubench_int_valu_issue.log) = 39.7 T lane-ops/s
 VALU_PEAK_TOPS = 39.7
-SHA_OPS_PER_BYTE = 21.9     # 1400 VALU instructions per 64-byte block (64 x 14 rounds + 48 x 10 schedule + 16 perm + 8)
+# VALU instructions per 64-byte block that gfx950's ISA cannot go below: 64 rounds x 14 + 48 schedule words x 11
+# (sigma0/sigma1 = 2 v_alignbit + v_lshrrev + v_bitop3 each, three adds incl. K) + 16 K adds + 16 v_perm + 8 = 1464.
+# The kernels emit 906 (consumer) + 744 (producer, incl. addressing) = 1650: profiles/r02_sha_isa_counts.txt
+SHA_OPS_PER_BYTE = 1464 / 64.0
 SHA_VALU_GBS = VALU_PEAK_TOPS * 1e3 / SHA_OPS_PER_BYTE
 CHAIN_US_PER_BLOCK = 1.655  # measured serial chain of the wave-pair kernel: 64 rounds x 14 instr x 4.25 cycles at 2.4 GHz
 

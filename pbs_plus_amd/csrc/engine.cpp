@@ -885,8 +885,15 @@ static int sha256_many(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nb
     const uint8_t *d = nullptr;
     CHK(stage_ranges(e, s, ptr, host, nbytes, segs, nseg, &d));
     CHK(s->recs.ensure((size_t)nseg * 32));
+    uint64_t total_blocks = 0, longest = 1;
+    for (uint32_t i = 0; i < nseg; ++i) {
+        const uint64_t blocks = (segs[i].length + 8) / 64 + 1;
+        total_blocks += blocks;
+        longest = std::max(longest, blocks);
+    }
     HIPCHK(pbsk::launch_sha256_segments(d, s->segs.as<pbsgpu_segment>(), nseg, s->recs.as<uint8_t>(),
-                                        s->scalars.as<uint32_t>() + SC_QUEUE, e->num_cus, s->stream));
+                                        s->scalars.as<uint32_t>() + SC_QUEUE, e->num_cus,
+                                        pbsk::sha256_dense_pays(total_blocks, longest, e->num_cus), s->stream));
     return fetch_result(s, digests, s->recs.p, (size_t)nseg * 32);
 }
 

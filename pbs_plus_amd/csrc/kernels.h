@@ -97,11 +97,15 @@ struct HashDesc {
     const uint8_t *ptr;
     uint64_t len;
 };
+// `dense` = run four producer/consumer pairs per CU instead of two (sha256_dense_pays() decides; kernels.hip)
 hipError_t launch_sha256_descs(const HashDesc *descs, uint32_t n, const uint32_t *order, uint8_t *digests,
-                               uint32_t *queue, unsigned workgroups, hipStream_t st);
+                               uint32_t *queue, unsigned workgroups, bool dense, hipStream_t st);
+// true when a hash launch of `total_blocks` 64-byte blocks whose longest item has `longest_blocks` is bound by issue
+// slots rather than by that longest chain (the device-side twin of this test lives in k_order)
+bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus);
 // SHA-256 of whole segments (verification path): digests[32*i] for segs[i]
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
-                                  uint8_t *digests, uint32_t *queue, int num_cus, hipStream_t st);
+                                  uint8_t *digests, uint32_t *queue, int num_cus, bool dense, hipStream_t st);
 
 // XXH3-64 (seed 0) of whole segments: out[i] for segs[i]; `queue` zero at launch
 // XXH3-64 (seed 0), two phases (kernels.hip): every 1 KiB block of every input is summed by some wave of the grid

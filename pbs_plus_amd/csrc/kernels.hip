@@ -1308,6 +1308,45 @@ __device__ __forceinline__ void sha256_iv(uint32_t (&H)[8]) {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// Raw little-endian words of a block that is NOT 64 full data bytes (the last data bytes + 0x80 marker, zero fill, and
+// the big-endian bit length in the final block): the funnel-shifted data words come from aligned dword loads whose
+// addresses are clamped to the range's last valid dword (nothing beyond the chunk is touched), then everything behind the
+// data is masked off and the marker / length are or-ed in. ~130 instructions with 17 independent loads in flight — the
+// byte-at-a-time assembly this replaces cost dozens of DEPENDENT byte loads per tail, which at small chunk sizes (a tail
+// every ~1000 blocks per lane, i.e. one per ~16 wave iterations) is what held the hash kernels back.
+__device__ __forceinline__ void sha256_tail_words(const uint8_t *base, uint64_t len, uint64_t off, bool last, uint32_t (&R)[17]) {
+    const int64_t rem = (int64_t)len - (int64_t)off;                // data bytes from `off` on (<= 0: padding-only block)
+    const uint32_t valid = rem <= 0 ? 0u : (rem >= 64 ? 64u : (uint32_t)rem);
+    uint32_t q[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) q[j] = 0;
+    uint32_t o = 0;
+    if (valid) {
+        const uint8_t *p = base + off;
+        o = (uint32_t)((uintptr_t)p & 3u);
+        const uint32_t *a = reinterpret_cast<const uint32_t *>(p - o);
+        const uint32_t jmax = (o + valid - 1u) >> 2;               // last dword that holds a valid byte
+#pragma unroll
+        for (int j = 0; j < 17; ++j) q[j] = a[min((uint32_t)j, jmax)];
+    }
+    const uint32_t sh = o * 8u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        uint32_t w = sh ? ((q[j] >> sh) | (q[j + 1] << (32u - sh))) : q[j];  // bytes off+4j .. off+4j+3, little-endian
+        const int32_t k = (int32_t)valid - 4 * j;                  // valid bytes in this word
+        const uint32_t mask = k >= 4 ? 0xffffffffu : (k <= 0 ? 0u : ((1u << (8 * k)) - 1u));
+        w &= mask;
+        if (rem >= 0 && rem < 64 && k >= 0 && k < 4) w |= 0x80u << (8 * k);  // the marker byte sits at position len
+        R[j] = w;
+    }
+    if (last) {  // big-endian bit length in bytes 56..63 (R is little-endian raw)
+        const uint64_t bits = len * 8;
+        R[14] = __builtin_bswap32((uint32_t)(bits >> 32));
+        R[15] = __builtin_bswap32((uint32_t)bits);
+    }
+    R[16] = 0;
+}
+
 // Work source for the SHA kernel: item i -> (byte pointer, length, digest destination)
 struct RecordSource {
     const uint8_t *data;
@@ -1358,7 +1397,7 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
                                                uint32_t *queue, const uint32_t *wg_limit) {
     // k_order's budget counts 128-lane workgroups of the pair kernel = two of these waves; waves beyond it leave
     // their SIMD slot to the other batches in flight (the queue is dynamic, the remaining waves drain it)
-    if (wg_limit && blockIdx.x >= *wg_limit * 2u) return;
+    if (wg_limit && blockIdx.x >= (*wg_limit & 0x7fffffffu) * 2u) return;  // bit 31 = dense hint of the pair kernel
     const int lane = threadIdx.x & 63;
     const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
 
@@ -1392,27 +1431,8 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
             R[12] = v3.x; R[13] = v3.y; R[14] = v3.z; R[15] = v3.w;
             R[16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
             sel = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
-        } else {  // tail / padding block (at most two per range): assemble bytes
-            const uint64_t bits = len * 8;
-            const bool last = (blk + 1 == nblk);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t w = 0;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint64_t q = off + (uint64_t)(4 * j + t);
-                    uint32_t byte = 0;
-                    if (q < len) byte = base[q];
-                    else if (q == len) byte = 0x80u;
-                    w |= byte << (8 * t);
-                }
-                R[j] = w;
-            }
-            if (last) {  // big-endian bit length in bytes 56..63 (R is little-endian raw)
-                R[14] = __builtin_bswap32((uint32_t)(bits >> 32));
-                R[15] = __builtin_bswap32((uint32_t)bits);
-            }
-            R[16] = 0;
+        } else {  // tail / padding block (at most two per range)
+            sha256_tail_words(base, len, off, blk + 1 == nblk, R);
             sel = 0x00010203u;
         }
     };
@@ -1479,26 +1499,49 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
 // loads, tail/padding, byte swap, message schedule, + K) and hands W[t]+K[t] through LDS;
 // the CONSUMER wave executes nothing but the 64 rounds (14 VALU each) and the digest store.
 // One s_barrier per block; LDS double-buffered (2 x 16 KiB).
-template <typename Source>
-__global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
-                                                     uint32_t *queue, const uint32_t *wg_limit) {
-    // surplus workgroups leave at once so their CUs can host another batch's kernel
-    if (wg_limit && blockIdx.x >= *wg_limit) return;
-    // One workgroup per CU (launch pads the LDS request): 4 waves on the CU's 4 SIMDs = 2 pairs.
-    // waves 0,1 = consumers of pair 0,1; waves 2,3 = their producers.
-    __shared__ uint4 wkbuf_[2][2][16][64];  // [pair][buffer][4 rounds][lane] -> 16 B per lane, contiguous rows
-    __shared__ uint32_t ctrl_[2][2][64];    // bit0 block valid, bit1 last block of its range
-    __shared__ uint8_t *dstp_[2][2][64];    // digest destination (valid when bit1)
-    __shared__ uint32_t alive[2][2];        // [pair][buffer]: producer still had blocks
-    __shared__ uint32_t tailbuf_[2][64][17];  // per-lane scratch for tail/padding blocks (17: bank spread)
+// DENSE form (same kernel, decided per launch on the device by k_order or by the host for descriptor jobs): when a job
+// holds more work than the two pairs can finish within its longest chain, the chain no longer bounds the job — issue
+// slots do, and a pair leaves them unused: the consumer issues ~960 instructions per block, the producer ~440, so the
+// producers' SIMDs idle more than half the time. The workgroup is therefore launched with EIGHT waves (4 pairs):
+// waves 4,5 = producers of pairs 2,3 (they land on the SIMDs of consumers 0,1), waves 6,7 = consumers of pairs 2,3
+// (on the SIMDs of producers 0,1; placement verified with HW_ID, profiles/r02_probe_simd_placement.log), so every SIMD
+// hosts one consumer and one producer. The gain is bounded by the instruction counts: per block the consumer issues
+// ~935 instructions and the producer ~860 (744 VALU: 48 x 11 schedule + K adds + perms + addressing), so four pairs
+// per ~1800 issue slots against two pairs per ~935 is +7 % at best; measured +5 % (SHA alone 65.3 -> 62.0 ms for
+// 64 GiB at 64 KiB average). Each chain is ~1.9x slower in this form, so it is used only when the chain does not bound.
+constexpr uint32_t kShaDenseBit = 0x80000000u;
+template <typename Source, bool DENSE>
+__global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
+                                                                   uint32_t *queue, const uint32_t *wg_limit) {
+    // Both forms are enqueued for a batch; *wg_limit (k_order) says which one works: bit 31 = dense, low bits = number
+    // of workgroups. Surplus workgroups (and the whole other form) leave at once so their CUs can host another
+    // batch's kernel. Two separate instantiations rather than a run-time switch: a branch on the form inside the
+    // consumer's block loop made the compiler wait for the LDS reads of block k+1 BEFORE the rounds of block k
+    // (+7 % on the chain, measured).
+    if (wg_limit) {
+        const uint32_t lim = *wg_limit;
+        if (((lim & kShaDenseBit) != 0) != DENSE || blockIdx.x >= (lim & ~kShaDenseBit)) return;
+    }
+    // One workgroup per CU (sparse: 69 KB static LDS + the launch's padding; dense: 137 KB).
+    // waves 0,1 = consumers of pair 0,1; waves 2,3 = their producers;
+    // dense only: waves 4,5 = producers of pair 2,3; waves 6,7 = their consumers.
+    constexpr int NP = DENSE ? 4 : 2;
+    __shared__ uint4 wkbuf_[NP][2][16][64];  // [pair][buffer][4 rounds][lane] -> 16 B per lane, contiguous rows
+    __shared__ uint32_t ctrl_[NP][2][64];    // bit0 block valid, bit1 last block of its range
+    __shared__ uint8_t *dstp_[NP][2][64];    // digest destination (valid when bit1)
+    __shared__ uint32_t alive[NP][2];        // [pair][buffer]: producer still had blocks
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int pr = wave & 1;
-    const bool producer = wave >= 2;
+    const int pr = (wave & 1) | (wave >= 4 ? 2 : 0);
+    const bool producer = (wave >= 2 && wave < 6);
     auto &wkbuf = wkbuf_[pr];
     auto &ctrl = ctrl_[pr];
     auto &dstp = dstp_[pr];
-    auto &tailbuf = tailbuf_[pr];
+    auto any_alive = [&](const int pb) -> uint32_t {
+        uint32_t a = alive[0][pb] | alive[1][pb];
+        if constexpr (DENSE) a |= alive[2][pb] | alive[3][pb];
+        return a;
+    };
 
     if (producer) {
         const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
@@ -1509,10 +1552,7 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
         bool have = false, exhausted = false;
         // FIFO of raw blocks in flight: a block is requested D iterations before it is expanded, so
         // HBM/TLB latency of the lane-private streams stays off the serial chain
-#ifndef PBS_SHA_FIFO
-#define PBS_SHA_FIFO 2
-#endif
-        constexpr int D = PBS_SHA_FIFO;  // even (buffer parity is derived from the slot index)
+        constexpr int D = 2;  // even (buffer parity is derived from the slot index)
         uint32_t R[D][17];
         uint32_t selv[D], cflag[D];
         uint8_t *dstv[D];
@@ -1524,7 +1564,6 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
             cflag[s] = 0;
             dstv[s] = nullptr;
         }
-        uint32_t *scratch = tailbuf[lane];
 
         auto acquire = [&](bool need) {
             const unsigned long long m = __ballot(need);
@@ -1563,22 +1602,8 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
                     R[s][12] = v3.x; R[s][13] = v3.y; R[s][14] = v3.z; R[s][15] = v3.w;
                     R[s][16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
                     selv[s] = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
-                } else {  // tail / padding block (<= 2 per range): assembled bytewise in LDS scratch
-                    uint8_t *sb = reinterpret_cast<uint8_t *>(scratch);
-                    for (uint32_t q = 0; q < 64; ++q) {
-                        const uint64_t g = off + q;
-                        uint8_t byte = 0;
-                        if (g < len) byte = base[g];
-                        else if (g == len) byte = 0x80u;
-                        sb[q] = byte;
-                    }
-                    if (blk + 1 == nblk) {  // big-endian bit length in bytes 56..63
-                        const uint64_t bits = len * 8;
-                        for (uint32_t q = 0; q < 8; ++q) sb[56 + q] = (uint8_t)(bits >> (56 - 8 * q));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) R[s][j] = scratch[j];
-                    R[s][16] = 0;
+                } else {  // tail / padding block (<= 2 per range)
+                    sha256_tail_words(base, len, off, blk + 1 == nblk, R[s]);
                     selv[s] = 0x00010203u;
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
@@ -1620,7 +1645,7 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
                     dstp[pb][lane] = cur_dst;
                     if (lane == 0) alive[pr][pb] = any_cur ? 1u : 0u;
                     __syncthreads();
-                    if (!(alive[0][pb] | alive[1][pb])) running = false;  // both pairs drained
+                    if (!any_alive(pb)) running = false;  // every pair drained
                 }
             }
         }
@@ -1637,7 +1662,7 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
             uint4 wk[16];
         };
         auto fetch = [&](Blk &x, const int pb) {
-            x.al = alive[0][pb] | alive[1][pb];
+            x.al = any_alive(pb);
             x.c = ctrl[pb][lane];
             x.d = dstp[pb][lane];
 #pragma unroll
@@ -1692,7 +1717,8 @@ __global__ __launch_bounds__(256) void k_sha256_pair(Source src, const uint32_t 
 // streams). Counting sort by size class (no comparison sort needed for a scheduling order).
 __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const uint32_t *nrec_p, uint32_t shift,
                                                 uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs,
-                                                const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct) {
+                                                const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
+                                                uint32_t dense_pct) {
     // a scan tile overflowed its slot list: this pass will be re-run with a larger capacity, so do not
     // spend a SHA pass on its (incomplete) cut list
     if (maxcnt && *maxcnt > cap) {
@@ -1733,7 +1759,10 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
         if (wgs > need) wgs = need;
         if (wgs < 1) wgs = 1;
         if (wgs > max_wgs) wgs = max_wgs;
-        *wg_limit = wgs;
+        // dense form of the SHA kernel (4 pairs per CU, each chain ~1.46x slower, twice the lanes): pays once the work
+        // per pair-mode lane exceeds ~1.5 longest chains
+        const bool dense = dense_pct && tot_blocks * 100ull > (unsigned long long)dense_pct * lg * 128ull * max_wgs;
+        *wg_limit = wgs | (dense ? 0x80000000u : 0u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1744,13 +1773,32 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
     }
 }
 
+// PBSGPU_SHA_DENSE_PCT: work per pair-mode lane, in percent of the longest chain, from which the SHA kernel runs its
+// dense (4 pairs per CU) form; 0 = never
+static uint32_t sha_dense_pct() {
+    static long pct = -1;
+    if (pct < 0) {
+        const char *e = getenv("PBSGPU_SHA_DENSE_PCT");
+        pct = e ? atol(e) : 150;
+        if (pct < 0) pct = 0;
+    }
+    return (uint32_t)pct;
+}
+
+bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus) {
+    const uint32_t pct = sha_dense_pct();
+    if (!pct) return false;
+    if (longest_blocks < 1) longest_blocks = 1;
+    return total_blocks * 100ull > (uint64_t)pct * longest_blocks * 128ull * (uint64_t)num_cus;
+}
+
 hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
                         uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
                         hipStream_t st) {
     uint32_t shift = 0;
     while (((uint64_t)max_chunk >> shift) >= 1024) ++shift;
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus,
-                       maxcnt, cap, slack_pct);
+                       maxcnt, cap, slack_pct, sha_dense_pct());
     return hipGetLastError();
 }
 
@@ -1782,6 +1830,22 @@ static int sha_mode() {
     return mode;
 }
 
+// host-decided form (descriptor jobs, whole-segment hashing): exactly one launch
+template <typename Source>
+static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source src, uint32_t nitems, uint32_t *queue) {
+    if (dense) {
+        hipLaunchKernelGGL((k_sha256_pair<Source, true>), dim3(grid), dim3(512), 0, st, src, (const uint32_t *)nullptr,
+                           nitems, queue, (const uint32_t *)nullptr);
+    } else {
+        const size_t pad = sha_lds_pad(16u << 10);  // ~69 KB static + 16 KB > 80 KB -> exactly one workgroup per CU
+        hipError_t e = allow_lds(&k_sha256_pair<Source, false>, pad);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sha256_pair<Source, false>), dim3(grid), dim3(256), pad, st, src,
+                           (const uint32_t *)nullptr, nitems, queue, (const uint32_t *)nullptr);
+    }
+    return hipGetLastError();
+}
+
 static inline unsigned sha_grid(int num_cus) { return (unsigned)num_cus * 8u; }  // 2 waves per SIMD
 
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
@@ -1789,11 +1853,15 @@ hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs
                                  const uint32_t *wg_limit, int num_cus, hipStream_t st) {
     RecordSource src{data, segs, recs, order};
     if (sha_mode() == 1) {
-        const size_t pad = sha_lds_pad(8u << 10);  // ~77 KB static + 8 KB -> exactly one workgroup per CU
-        hipError_t e = allow_lds(&k_sha256_pair<RecordSource>, pad);
+        // both forms are enqueued; k_order's verdict (bit 31 of *wg_limit) lets exactly one of them work
+        const size_t pad = sha_lds_pad(16u << 10);  // ~69 KB static + 16 KB > 80 KB -> exactly one workgroup per CU
+        hipError_t e = allow_lds(&k_sha256_pair<RecordSource, false>, pad);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sha256_pair<RecordSource>), dim3((unsigned)num_cus), dim3(256), pad, st, src, nrec, 0u,
-                           queue, wg_limit);
+        hipLaunchKernelGGL((k_sha256_pair<RecordSource, false>), dim3((unsigned)num_cus), dim3(256), pad, st, src, nrec,
+                           0u, queue, wg_limit);
+        if (sha_dense_pct())
+            hipLaunchKernelGGL((k_sha256_pair<RecordSource, true>), dim3((unsigned)num_cus), dim3(512), 0, st, src,
+                               nrec, 0u, queue, wg_limit);
     } else {
         const size_t pad = sha_lds_pad(36u << 10);  // four single-wave workgroups per CU
         hipError_t e = allow_lds(&k_sha256<RecordSource>, pad);
@@ -1805,36 +1873,28 @@ hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs
 }
 
 hipError_t launch_sha256_descs(const HashDesc *descs, uint32_t n, const uint32_t *order, uint8_t *digests,
-                               uint32_t *queue, unsigned workgroups, hipStream_t st) {
+                               uint32_t *queue, unsigned workgroups, bool dense, hipStream_t st) {
     if (n == 0) return hipSuccess;
     DescSource src{descs, digests, order};
-    const size_t pad = sha_lds_pad(8u << 10);
-    hipError_t e = allow_lds(&k_sha256_pair<DescSource>, pad);
-    if (e != hipSuccess) return e;
-    const unsigned need = (n + 127) / 128;
+    const unsigned need = (n + (dense ? 255u : 127u)) / (dense ? 256u : 128u);
     if (workgroups > need) workgroups = need;
     if (workgroups < 1) workgroups = 1;
-    hipLaunchKernelGGL((k_sha256_pair<DescSource>), dim3(workgroups), dim3(256), pad, st, src, (const uint32_t *)nullptr,
-                       n, queue, (const uint32_t *)nullptr);
+    return launch_pair(workgroups, dense, st, src, n, queue);
     return hipGetLastError();
 }
 
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests,
-                                  uint32_t *queue, int num_cus, hipStream_t st) {
+                                  uint32_t *queue, int num_cus, bool dense, hipStream_t st) {
     if (nseg == 0) return hipSuccess;
     SegmentSource src{data, segs, digests};
     unsigned grid = sha_grid(num_cus);
     const unsigned need = (nseg + 63) / 64;
     if (grid > need) grid = need;
     if (sha_mode() == 1) {
-        const size_t pad = sha_lds_pad(8u << 10);
-        hipError_t e = allow_lds(&k_sha256_pair<SegmentSource>, pad);
-        if (e != hipSuccess) return e;
         unsigned g2 = (unsigned)num_cus;
-        const unsigned need2 = (nseg + 127) / 128;
+        const unsigned need2 = (nseg + (dense ? 255u : 127u)) / (dense ? 256u : 128u);
         if (g2 > need2) g2 = need2;
-        hipLaunchKernelGGL((k_sha256_pair<SegmentSource>), dim3(g2), dim3(256), pad, st, src,
-                           (const uint32_t *)nullptr, nseg, queue, (const uint32_t *)nullptr);
+        return launch_pair(g2, dense, st, src, nseg, queue);
     } else {
         const size_t pad = sha_lds_pad(36u << 10);
         hipError_t e = allow_lds(&k_sha256<SegmentSource>, pad);

@@ -149,7 +149,8 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev, 
     // pinned memory. A small H2D copy would queue behind the streams' payload pieces in the shared SDMA queues, and a
     // D2H copy parked behind this 0.4 s kernel would block that queue for every other stream (kernels.hip, k_publish).
     HIPCHK(pbsk::launch_sha256_descs(j->h_desc.as<pbsk::HashDesc>(), n, j->h_order.as<uint32_t>(), j->h_dig.as<uint8_t>(),
-                                     j->d_queue.as<uint32_t>(), wgs, st));
+                                     j->d_queue.as<uint32_t>(), wgs,
+                                     pbsk::sha256_dense_pays(total_blocks, longest, hd.num_cus), st));
     HIPCHK(hipEventRecord(j->done, st));
     j->n = n;
     j->lane = lane;
