@@ -752,6 +752,51 @@ def test_parallel_resolve_equals_the_serial_walk_on_awkward_streams(gpu_lib):
     assert "par-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_dense_sha_form_stays_bit_exact(gpu_lib):
+    """The 4-pairs-per-CU form of the SHA-256 kernel (k_sha256_pair<..., true>) is chosen per batch when the work exceeds
+    PBSGPU_SHA_DENSE_PCT % of the longest chain per lane. PBSGPU_SHA_DENSE_PCT=1 (read once per process -> subprocess)
+    makes it the form of every launch that has >~330 longest-chunks' worth of blocks: batch records (k_order decides on
+    the device), whole-segment hashing with every padding length and misaligned starts (host decides), and the stream
+    writer's shared hash jobs (host decides) — all against the oracle / hashlib."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import hashlib, numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "from pbs_plus_amd import Engine, buzhash\n"
+        "from pbs_plus_amd.engine import PayloadStream\n"
+        "from tests.helpers import records_equal, describe_mismatch\n"
+        "for avg, n, kind in ((4096, 40_000_001, 0), (4096, 24_000_000, 3), (65536, 300_000_017, 0)):\n"
+        "    eng = Engine(buzhash.NewConfig(avg)); cfg = O.new_config(avg)\n"
+        "    data = O.fill(n, 21, kind)\n"
+        "    got, want = eng.chunk_and_digest(data), O.chunk_and_digest(cfg, data)\n"
+        "    assert records_equal(got, want), (avg, describe_mismatch(got, want))\n"
+        "    if avg == 4096:\n"
+        "        ps = PayloadStream(eng, window_bytes=32 << 20)\n"
+        "        for off in range(0, n, 7_000_003): ps.write(data[off:off + 7_000_003])\n"
+        "        ps.finish(); recs = ps.poll(); ps.close()\n"
+        "        assert records_equal(recs, want), ('stream', describe_mismatch(recs, want))\n"
+        "    eng.close()\n"
+        "eng = Engine(buzhash.NewConfig(4096))\n"
+        "blob = O.fill(6_000_000, 22, 0)\n"
+        "rng = np.random.default_rng(3)\n"
+        "segs = [(int(o), int(l)) for o, l in zip(rng.integers(0, 5_000_000, 30000), rng.integers(0, 200, 30000))]\n"
+        "segs += [(i, l) for i in range(4) for l in range(0, 131)]   # longest item 3 blocks: dense by a wide margin\n"
+        "dig = eng.sha256_many(blob, segs)\n"
+        "for i in list(range(0, 30000, 97)) + list(range(30000, len(segs))):\n"
+        "    o, l = segs[i]\n"
+        "    assert bytes(dig[i]) == hashlib.sha256(blob[o:o + l].tobytes()).digest(), (i, o, l)\n"
+        "eng.close()\n"
+        "print('dense-ok')\n" % root)
+    env = dict(os.environ, PBSGPU_SHA_DENSE_PCT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "dense-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("workload", ["stream64g", "corpus_dup"])
 def test_bench_rccl_code_path_with_one_rank(gpu_lib, workload):
     """The "nccl" (= RCCL) branch of bench.py on real hardware: process-group init with device_id, barrier, all_reduce
