@@ -250,8 +250,12 @@ static int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     const pbsgpu_segment *dsegs = s.segs_dev();
     HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
                               sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, e->sha_slack_pct, s.stream));
+    // form of the hash kernel: issue-bound (dense) or chain-bound (sparse), from what the host knows at submit time —
+    // the bytes of the batch and the longest chain the chunker can produce
+    const uint64_t longest = std::min<uint64_t>(e->cfg.max, std::max<uint64_t>(s.nbytes, 1)) / 64 + 1;
+    const bool dense = pbsk::sha256_dense_pays(s.nbytes / 64, longest, e->num_cus);
     HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
-                                       s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, s.stream));
+                                       s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, dense, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
     return PBSGPU_OK;
 }

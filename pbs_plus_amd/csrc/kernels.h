@@ -85,7 +85,7 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
 // `queue` is a device uint32 that must be zero at launch.
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
                                  const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
-                                 const uint32_t *wg_limit, int num_cus, hipStream_t st);
+                                 const uint32_t *wg_limit, int num_cus, bool dense, hipStream_t st);
 // longest-first queue order (counting sort by size class) + workgroup budget for the SHA kernel:
 // lanes = (1 + slack_pct/100) x total blocks / longest chunk's blocks
 hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,

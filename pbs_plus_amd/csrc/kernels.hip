@@ -1394,10 +1394,14 @@ struct DescSource {
 // ~1700 VALU ops of the compression even with a single wave on the SIMD.
 template <typename Source>
 __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
-                                               uint32_t *queue, const uint32_t *wg_limit) {
+                                               uint32_t *queue, const uint32_t *wg_limit, uint32_t whole_chip) {
     // k_order's budget counts 128-lane workgroups of the pair kernel = two of these waves; waves beyond it leave
-    // their SIMD slot to the other batches in flight (the queue is dynamic, the remaining waves drain it)
-    if (wg_limit && blockIdx.x >= (*wg_limit & 0x7fffffffu) * 2u) return;  // bit 31 = dense hint of the pair kernel
+    // their SIMD slot to the other batches in flight (the queue is dynamic, the remaining waves drain it).
+    // whole_chip (dense launches): every wave works unless k_order said "skip this pass" (0)
+    if (wg_limit) {
+        const uint32_t lim = *wg_limit;
+        if (whole_chip ? lim == 0 : blockIdx.x >= lim * 2u) return;
+    }
     const int lane = threadIdx.x & 63;
     const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
 
@@ -1499,28 +1503,29 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
 // loads, tail/padding, byte swap, message schedule, + K) and hands W[t]+K[t] through LDS;
 // the CONSUMER wave executes nothing but the 64 rounds (14 VALU each) and the digest store.
 // One s_barrier per block; LDS double-buffered (2 x 16 KiB).
-// DENSE form (same kernel, decided per launch on the device by k_order or by the host for descriptor jobs): when a job
-// holds more work than the two pairs can finish within its longest chain, the chain no longer bounds the job — issue
-// slots do, and a pair leaves them unused: the consumer issues ~960 instructions per block, the producer ~440, so the
-// producers' SIMDs idle more than half the time. The workgroup is therefore launched with EIGHT waves (4 pairs):
+// DENSE form (second instantiation, chosen per launch by the host: sha256_dense_pays): when a job holds more work than
+// the two pairs can finish within its longest chain, the chain no longer bounds the job — issue slots do, and a pair
+// leaves them unused: the producers' SIMDs idle part of every step. The workgroup is then EIGHT waves (4 pairs):
 // waves 4,5 = producers of pairs 2,3 (they land on the SIMDs of consumers 0,1), waves 6,7 = consumers of pairs 2,3
 // (on the SIMDs of producers 0,1; placement verified with HW_ID, profiles/r02_probe_simd_placement.log), so every SIMD
 // hosts one consumer and one producer. The gain is bounded by the instruction counts: per block the consumer issues
 // ~935 instructions and the producer ~860 (744 VALU: 48 x 11 schedule + K adds + perms + addressing), so four pairs
 // per ~1800 issue slots against two pairs per ~935 is +7 % at best; measured +5 % (SHA alone 65.3 -> 62.0 ms for
 // 64 GiB at 64 KiB average). Each chain is ~1.9x slower in this form, so it is used only when the chain does not bound.
-constexpr uint32_t kShaDenseBit = 0x80000000u;
 template <typename Source, bool DENSE>
 __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, const uint32_t *nitems_p, uint32_t nitems_imm,
                                                                    uint32_t *queue, const uint32_t *wg_limit) {
-    // Both forms are enqueued for a batch; *wg_limit (k_order) says which one works: bit 31 = dense, low bits = number
-    // of workgroups. Surplus workgroups (and the whole other form) leave at once so their CUs can host another
-    // batch's kernel. Two separate instantiations rather than a run-time switch: a branch on the form inside the
-    // consumer's block loop made the compiler wait for the LDS reads of block k+1 BEFORE the rounds of block k
-    // (+7 % on the chain, measured).
+    // The HOST picks the form per launch (sha256_dense_pays: from the batch's byte count and the chunker's maximum —
+    // k_order could decide more exactly on the device, but then both forms have to be enqueued and the idle one still
+    // waits for CUs with room for its LDS before it can leave: measured 2.7 ms avg / 14 ms max per batch on the default
+    // workload, 46 ms at 64 KiB average). Two instantiations rather than a run-time switch: launch bounds and LDS
+    // differ, and the sparse code stays exactly what was tuned (one 512-thread kernel with a switch ran the sparse chain
+    // at 463-465 ms per 64 GiB against 433-458; within box-to-box spread). Sparse: workgroups beyond
+    // k_order's budget leave at once so their CUs can host another batch's kernel; dense: the budget is the whole
+    // chip, only k_order's "skip this pass" (0) is honoured.
     if (wg_limit) {
         const uint32_t lim = *wg_limit;
-        if (((lim & kShaDenseBit) != 0) != DENSE || blockIdx.x >= (lim & ~kShaDenseBit)) return;
+        if (DENSE ? lim == 0 : blockIdx.x >= lim) return;
     }
     // One workgroup per CU (sparse: 69 KB static LDS + the launch's padding; dense: 137 KB).
     // waves 0,1 = consumers of pair 0,1; waves 2,3 = their producers;
@@ -1717,8 +1722,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
 // streams). Counting sort by size class (no comparison sort needed for a scheduling order).
 __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const uint32_t *nrec_p, uint32_t shift,
                                                 uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs,
-                                                const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
-                                                uint32_t dense_pct) {
+                                                const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct) {
     // a scan tile overflowed its slot list: this pass will be re-run with a larger capacity, so do not
     // spend a SHA pass on its (incomplete) cut list
     if (maxcnt && *maxcnt > cap) {
@@ -1759,10 +1763,7 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
         if (wgs > need) wgs = need;
         if (wgs < 1) wgs = 1;
         if (wgs > max_wgs) wgs = max_wgs;
-        // dense form of the SHA kernel (4 pairs per CU, each chain ~1.46x slower, twice the lanes): pays once the work
-        // per pair-mode lane exceeds ~1.5 longest chains
-        const bool dense = dense_pct && tot_blocks * 100ull > (unsigned long long)dense_pct * lg * 128ull * max_wgs;
-        *wg_limit = wgs | (dense ? 0x80000000u : 0u);
+        *wg_limit = wgs;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1798,7 +1799,7 @@ hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_
     uint32_t shift = 0;
     while (((uint64_t)max_chunk >> shift) >= 1024) ++shift;
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus,
-                       maxcnt, cap, slack_pct, sha_dense_pct());
+                       maxcnt, cap, slack_pct);
     return hipGetLastError();
 }
 
@@ -1848,26 +1849,43 @@ static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source 
 
 static inline unsigned sha_grid(int num_cus) { return (unsigned)num_cus * 8u; }  // 2 waves per SIMD
 
+// PBSGPU_SHA_DENSE_FORM=lanes: dense launches use the single-wave kernel at PBSGPU_SHA_LANE_WAVES (default 4) waves
+// per SIMD instead of four producer/consumer pairs per CU (A/B measurements)
+static int sha_dense_lanes() {
+    static int w = -1;
+    if (w < 0) {
+        const char *f = getenv("PBSGPU_SHA_DENSE_FORM");
+        const char *e = getenv("PBSGPU_SHA_LANE_WAVES");
+        w = (f && f[0] == 'l') ? (e ? atoi(e) : 4) : 0;
+        if (w < 0 || w > 8) w = 0;
+    }
+    return w;
+}
+
 hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
                                  const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
-                                 const uint32_t *wg_limit, int num_cus, hipStream_t st) {
+                                 const uint32_t *wg_limit, int num_cus, bool dense, hipStream_t st) {
     RecordSource src{data, segs, recs, order};
-    if (sha_mode() == 1) {
-        // both forms are enqueued; k_order's verdict (bit 31 of *wg_limit) lets exactly one of them work
-        const size_t pad = sha_lds_pad(16u << 10);  // ~69 KB static + 16 KB > 80 KB -> exactly one workgroup per CU
-        hipError_t e = allow_lds(&k_sha256_pair<RecordSource, false>, pad);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sha256_pair<RecordSource, false>), dim3((unsigned)num_cus), dim3(256), pad, st, src, nrec,
-                           0u, queue, wg_limit);
-        if (sha_dense_pct())
-            hipLaunchKernelGGL((k_sha256_pair<RecordSource, true>), dim3((unsigned)num_cus), dim3(512), 0, st, src,
+    if (dense && sha_dense_lanes()) {
+        hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u * (unsigned)sha_dense_lanes()), dim3(64), 0,
+                           st, src, nrec, 0u, queue, wg_limit, 1u);
+    } else if (sha_mode() == 1) {
+        if (dense) {
+            hipLaunchKernelGGL((k_sha256_pair<RecordSource, true>), dim3((unsigned)num_cus), dim3(512), 0, st, src, nrec,
+                               0u, queue, wg_limit);
+        } else {
+            const size_t pad = sha_lds_pad(16u << 10);  // ~69 KB static + 16 KB > 80 KB -> exactly one workgroup per CU
+            hipError_t e = allow_lds(&k_sha256_pair<RecordSource, false>, pad);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_sha256_pair<RecordSource, false>), dim3((unsigned)num_cus), dim3(256), pad, st, src,
                                nrec, 0u, queue, wg_limit);
+        }
     } else {
         const size_t pad = sha_lds_pad(36u << 10);  // four single-wave workgroups per CU
         hipError_t e = allow_lds(&k_sha256<RecordSource>, pad);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u), dim3(64), pad, st, src, nrec, 0u,
-                           queue, wg_limit);
+                           queue, wg_limit, 0u);
     }
     return hipGetLastError();
 }
@@ -1902,7 +1920,7 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
         grid = (unsigned)num_cus * 4u;
         if (grid > need) grid = need;
         hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), pad, st, src, (const uint32_t *)nullptr,
-                           nseg, queue, (const uint32_t *)nullptr);
+                           nseg, queue, (const uint32_t *)nullptr, 0u);
     }
     return hipGetLastError();
 }

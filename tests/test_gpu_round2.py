@@ -755,9 +755,10 @@ def test_parallel_resolve_equals_the_serial_walk_on_awkward_streams(gpu_lib):
 def test_dense_sha_form_stays_bit_exact(gpu_lib):
     """The 4-pairs-per-CU form of the SHA-256 kernel (k_sha256_pair<..., true>) is chosen per batch when the work exceeds
     PBSGPU_SHA_DENSE_PCT % of the longest chain per lane. PBSGPU_SHA_DENSE_PCT=1 (read once per process -> subprocess)
-    makes it the form of every launch that has >~330 longest-chunks' worth of blocks: batch records (k_order decides on
-    the device), whole-segment hashing with every padding length and misaligned starts (host decides), and the stream
-    writer's shared hash jobs (host decides) — all against the oracle / hashlib."""
+    makes it the form of every launch that has >~330 longest-chunks' worth of blocks: batch records (decided from the
+    batch's bytes and the chunker's maximum), whole-segment hashing with every padding length and misaligned starts, and
+    the stream writer's shared hash jobs (decided from the items of the launch) — all against the oracle / hashlib. The
+    single-wave alternative for dense launches (PBSGPU_SHA_DENSE_FORM=lanes) runs the batch part as well."""
     import os
     import subprocess
     import sys
@@ -792,9 +793,10 @@ def test_dense_sha_form_stays_bit_exact(gpu_lib):
         "    assert bytes(dig[i]) == hashlib.sha256(blob[o:o + l].tobytes()).digest(), (i, o, l)\n"
         "eng.close()\n"
         "print('dense-ok')\n" % root)
-    env = dict(os.environ, PBSGPU_SHA_DENSE_PCT="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert "dense-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    for extra in ({}, dict(PBSGPU_SHA_DENSE_FORM="lanes")):
+        env = dict(os.environ, PBSGPU_SHA_DENSE_PCT="1", **extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert "dense-ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-3000:]
 
 
 @pytest.mark.parametrize("workload", ["stream64g", "corpus_dup"])
