@@ -508,6 +508,12 @@ def main():
             torch.cuda.set_device(local_rank % max(ngpu0, 1))
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device(f"cuda:{local_rank % max(ngpu0, 1)}"))
+            # first collective now, before the workload takes 256 GiB of the 288 GB: RCCL allocates its channel buffers
+            # lazily, and a communicator that first runs out of HBM inside the timed region would take the job down
+            warm = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank % max(ngpu0, 1)}")
+            dist.all_reduce(warm, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         ctx.dist = dist
