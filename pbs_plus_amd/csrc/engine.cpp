@@ -186,7 +186,7 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     CHK(s.seg_cnt.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.seg_off.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.recs.ensure((size_t)s.rec_cap * sizeof(pbsgpu_record) + 64));
-    CHK(s.order.ensure((size_t)s.rec_cap * 4 + 64));
+    CHK(s.order.ensure((size_t)s.rec_cap * pbsk::kQueueDescBytes + 64));
     CHK(enqueue_candidates(e, s, s.dptr, s.nbytes, cap, s.nseg));
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs_dev();
@@ -248,14 +248,14 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
 static int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs_dev();
-    HIPCHK(pbsk::launch_order(s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint32_t>(),
+    HIPCHK(pbsk::launch_order(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint4>(),
                               sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, e->sha_slack_pct, s.stream));
     // form of the hash kernel: issue-bound (dense) or chain-bound (sparse), from what the host knows at submit time —
     // the bytes of the batch and the longest chain the chunker can produce
     const uint64_t longest = std::min<uint64_t>(e->cfg.max, std::max<uint64_t>(s.nbytes, 1)) / 64 + 1;
     const bool dense = pbsk::sha256_dense_pays(s.nbytes / 64, longest, e->num_cus);
-    HIPCHK(pbsk::launch_sha256_records(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE,
-                                       s.order.as<uint32_t>(), sc + SC_WGLIMIT, e->num_cus, dense, s.stream));
+    HIPCHK(pbsk::launch_sha256_records(s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE, s.order.as<uint4>(),
+                                       sc + SC_WGLIMIT, e->num_cus, dense, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
     return PBSGPU_OK;
 }
@@ -486,7 +486,7 @@ int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes) {
     CHK(s.seg_cnt.ensure(64));
     CHK(s.seg_off.ensure(64));
     CHK(s.recs.ensure((size_t)rec_cap * sizeof(pbsgpu_record) + 64));
-    CHK(s.order.ensure((size_t)rec_cap * 4 + 64));
+    CHK(s.order.ensure((size_t)rec_cap * pbsk::kQueueDescBytes + 64));
     CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
     CHK(s.h_segs.ensure(4 * sizeof(pbsgpu_segment)));
     CHK(s.h_sugg.ensure(64 << 10));

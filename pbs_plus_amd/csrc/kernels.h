@@ -83,13 +83,14 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
 
 // SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
 // `queue` is a device uint32 that must be zero at launch.
-hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
-                                 const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
+hipError_t launch_sha256_records(pbsgpu_record *recs, const uint32_t *nrec, uint32_t *queue, const uint4 *qdesc,
                                  const uint32_t *wg_limit, int num_cus, bool dense, hipStream_t st);
 // longest-first queue order (counting sort by size class) + workgroup budget for the SHA kernel:
 // lanes = (1 + slack_pct/100) x total blocks / longest chunk's blocks
-hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
-                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
+// (writes the queue as 16-byte descriptors {address lo, hi, size, record index}: kQueueDescBytes per record)
+constexpr size_t kQueueDescBytes = 16;
+hipError_t launch_order(const uint8_t *data, const pbsgpu_segment *segs, const pbsgpu_record *recs, const uint32_t *nrec,
+                        uint32_t max_chunk, uint4 *qdesc, uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
                         hipStream_t st);
 // SHA-256 of explicit (pointer, length) descriptors — the shared hash jobs of the streaming writers. digests[32*i]
 // for descs[i]; `order` = longest-first permutation (may be null); `workgroups` = CU budget of the launch.

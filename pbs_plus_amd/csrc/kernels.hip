@@ -1349,18 +1349,17 @@ __device__ __forceinline__ void sha256_tail_words(const uint8_t *base, uint64_t 
 
 // Work source for the SHA kernel: item i -> (byte pointer, length, digest destination)
 struct RecordSource {
-    const uint8_t *data;
-    const pbsgpu_segment *segs;
     pbsgpu_record *recs;
-    const uint32_t *order;  // queue position -> record index (longest chunks first), may be null
+    // queue position -> {chunk address lo, hi, size, record index}, longest chunks first (k_order). ONE 16-byte load
+    // per chunk a lane takes from the queue: the chain order[i] -> record -> segment offset was three dependent round
+    // trips (~1-2 us each under load) at every chunk boundary of every lane, and all pairs of a workgroup wait at the
+    // block barrier while one producer sits in them.
+    const uint4 *qdesc;
     __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
-        if (order) i = order[i];
-        const pbsgpu_record *r = recs + i;
-        const uint64_t end = r->end;
-        const uint32_t size = r->size;
-        ptr = data + segs[r->segment].offset + end - size;
-        len = size;
-        dst = recs[i].digest;
+        const uint4 d = qdesc[i];
+        ptr = reinterpret_cast<const uint8_t *>(((uint64_t)d.y << 32) | d.x);
+        len = d.z;
+        dst = recs[d.w].digest;
     }
 };
 struct SegmentSource {
@@ -1570,15 +1569,35 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             dstv[s] = nullptr;
         }
 
+        // Dense form: a wave RESERVES kReserve extra queue positions with every atomic and serves its lanes from that
+        // reserve, so most chunk boundaries cost no atomic round trip at all (items >> lanes there; a few positions held
+        // back by a wave at the very end are handed to its own lanes). The sparse form must not hoard — it has more
+        // lanes than chunks, and the longest-first order is what keeps its makespan at the longest chain.
+        constexpr uint32_t kReserve = 16;
+        uint32_t res_next = 0, res_end = 0;  // the wave's reserved positions [res_next, res_end): same value in every lane
         auto acquire = [&](bool need) {
             const unsigned long long m = __ballot(need);
             if (m == 0) return;
             uint32_t first = 0;
             const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(m));
-            first = __shfl(first, leader, 64);
+            uint32_t avail = 0;
+            if constexpr (DENSE) {
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                avail = res_end - res_next;
+                if (cnt > avail) {
+                    if (lane == leader) first = atomicAdd(queue, cnt - avail + kReserve);
+                    first = __shfl(first, leader, 64);
+                }
+            } else {
+                if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(m));
+                first = __shfl(first, leader, 64);
+            }
             if (need) {
-                const uint32_t i = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                uint32_t i = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if constexpr (DENSE) {
+                    const uint32_t r = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    i = r < avail ? res_next + r : first + (r - avail);
+                }
                 if (i < nitems) {
                     src.get(i, base, len, dst);
                     blk = 0;
@@ -1587,6 +1606,15 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 } else {
                     exhausted = true;
                     have = false;
+                }
+            }
+            if constexpr (DENSE) {
+                const uint32_t cnt = (uint32_t)__popcll(m);
+                if (cnt > avail) {
+                    res_next = first + (cnt - avail);
+                    res_end = res_next + kReserve;
+                } else {
+                    res_next += cnt;
                 }
             }
         };
@@ -1720,8 +1748,9 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
 // and letting lanes pull the short ones afterwards reaches that bound with FEWER lanes than
 // chunks, which leaves CUs free for the next batch's kernels (batches overlap on separate
 // streams). Counting sort by size class (no comparison sort needed for a scheduling order).
-__global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const uint32_t *nrec_p, uint32_t shift,
-                                                uint32_t *order, uint32_t *wg_limit, uint32_t max_wgs,
+__global__ __launch_bounds__(1024) void k_order(const uint8_t *data, const pbsgpu_segment *segs, const pbsgpu_record *recs,
+                                                const uint32_t *nrec_p, uint32_t shift, uint4 *qdesc, uint32_t *wg_limit,
+                                                uint32_t max_wgs,
                                                 const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct) {
     // a scan tile overflowed its slot list: this pass will be re-run with a larger capacity, so do not
     // spend a SHA pass on its (incomplete) cut list
@@ -1770,7 +1799,8 @@ __global__ __launch_bounds__(1024) void k_order(const pbsgpu_record *recs, const
         uint32_t b = recs[i].size >> shift;
         if (b >= BINS) b = BINS - 1;
         const uint32_t pos = atomicAdd(&base[BINS - 1 - b], 1u);
-        order[pos] = i;
+        const uint64_t p = (uint64_t)(uintptr_t)(data + segs[recs[i].segment].offset + recs[i].end - recs[i].size);
+        qdesc[pos] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), recs[i].size, i);
     }
 }
 
@@ -1793,12 +1823,12 @@ bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_c
     return total_blocks * 100ull > (uint64_t)pct * longest_blocks * 128ull * (uint64_t)num_cus;
 }
 
-hipError_t launch_order(const pbsgpu_record *recs, const uint32_t *nrec, uint32_t max_chunk, uint32_t *order,
-                        uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
+hipError_t launch_order(const uint8_t *data, const pbsgpu_segment *segs, const pbsgpu_record *recs, const uint32_t *nrec,
+                        uint32_t max_chunk, uint4 *qdesc, uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
                         hipStream_t st) {
     uint32_t shift = 0;
     while (((uint64_t)max_chunk >> shift) >= 1024) ++shift;
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, recs, nrec, shift, order, wg_limit, (uint32_t)num_cus,
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, data, segs, recs, nrec, shift, qdesc, wg_limit, (uint32_t)num_cus,
                        maxcnt, cap, slack_pct);
     return hipGetLastError();
 }
@@ -1862,10 +1892,9 @@ static int sha_dense_lanes() {
     return w;
 }
 
-hipError_t launch_sha256_records(const uint8_t *data, const pbsgpu_segment *segs, pbsgpu_record *recs,
-                                 const uint32_t *nrec, uint32_t *queue, const uint32_t *order,
+hipError_t launch_sha256_records(pbsgpu_record *recs, const uint32_t *nrec, uint32_t *queue, const uint4 *qdesc,
                                  const uint32_t *wg_limit, int num_cus, bool dense, hipStream_t st) {
-    RecordSource src{data, segs, recs, order};
+    RecordSource src{recs, qdesc};
     if (dense && sha_dense_lanes()) {
         hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u * (unsigned)sha_dense_lanes()), dim3(64), 0,
                            st, src, nrec, 0u, queue, wg_limit, 1u);
