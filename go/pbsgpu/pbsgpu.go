@@ -93,6 +93,7 @@ func NewEngine(device int, cfg Config, inflight int) (*Engine, error) {
 // Close releases the handle. Streams and Chunkers created from the engine keep the device state alive until
 // they are closed too (the C library reference-counts), so finalizer order does not matter.
 func (e *Engine) Close() {
+	runtime.SetFinalizer(e, nil)
 	if e.h != nil {
 		C.pbsgpu_engine_destroy(e.h)
 		e.h = nil
@@ -142,6 +143,7 @@ var ErrBusy = errors.New("pbsgpu: all in-flight tickets used")
 // chunker state, forced cut at its end). The Go slice is copied to pinned staging before the call returns.
 // suggested (optional): one ascending list of suggested boundaries per segment, relative to the segment start.
 func (e *Engine) Submit(buf []byte, offsets, lengths []uint64, suggested [][]uint64) (Ticket, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	segs, err := toSegments(offsets, lengths)
 	if err != nil {
 		return 0, err
@@ -189,6 +191,7 @@ func (e *Engine) Submit(buf []byte, offsets, lengths []uint64, suggested [][]uin
 
 // Done reports, without blocking, whether Collect would return at once.
 func (e *Engine) Done(t Ticket) (bool, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	var d C.int
 	err := check(C.pbsgpu_ticket_done(e.h, C.uint64_t(t), &d), "ticket_done")
 	return d != 0, err
@@ -196,6 +199,7 @@ func (e *Engine) Done(t Ticket) (bool, error) {
 
 // Collect waits for the batch and returns its records ordered by (segment, end); the ticket is released.
 func (e *Engine) Collect(t Ticket) ([]ChunkInfo, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	var n C.uint64_t
 	if err := check(C.pbsgpu_wait(e.h, C.uint64_t(t), &n), "wait"); err != nil {
 		return nil, err
@@ -215,6 +219,7 @@ type DedupStats struct{ Records, Unique, TotalBytes, UniqueBytes uint64 }
 // Dedup flags every record whose digest already occurred at a lower index (device sort + compare): the digest-set
 // reduce of cross-file duplicate detection, run on the all-gathered records of all GPUs.
 func (e *Engine) Dedup(recs []ChunkInfo) ([]bool, DedupStats, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	if len(recs) == 0 {
 		return nil, DedupStats{}, nil
 	}
@@ -234,6 +239,7 @@ func (e *Engine) Dedup(recs []ChunkInfo) ([]bool, DedupStats, error) {
 // EncodeDynamicIndex is datastore.NewDynamicIndexWriter(ctime).Add(end, digest)...Finish()
 // (internal/pxarmount/commit_bottleneck_test.go:773-793): the .didx image of one stream's records.
 func (e *Engine) EncodeDynamicIndex(recs []ChunkInfo, uuid [16]byte, ctime int64) ([]byte, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	var nb C.uint64_t
 	C.pbsgpu_didx_size(C.uint64_t(len(recs)), &nb)
 	out := make([]byte, int(nb))
@@ -327,6 +333,7 @@ type Stream struct {
 }
 
 func (e *Engine) NewStream(windowBytes uint64) (*Stream, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	s := &Stream{eng: e}
 	if err := check(C.pbsgpu_stream_create(e.h, C.uint64_t(windowBytes), &s.h), "stream_create"); err != nil {
 		return nil, err
@@ -338,6 +345,7 @@ func (e *Engine) NewStream(windowBytes uint64) (*Stream, error) {
 // Write implements io.Writer. The Go slice is not retained: the library copies it into its own
 // pinned staging before returning (cgo pointer rule).
 func (s *Stream) Write(p []byte) (int, error) {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	if len(p) == 0 {
 		return 0, nil
 	}
@@ -352,6 +360,7 @@ func (s *Stream) Write(p []byte) (int, error) {
 // ReadFrom implements io.ReaderFrom without the extra copy of Write: the reader fills the
 // library's pinned staging memory directly (zero-copy feed of WriteEntryReader's io.Reader).
 func (s *Stream) ReadFrom(r io.Reader) (int64, error) {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	var total int64
 	for {
 		var buf unsafe.Pointer
@@ -382,6 +391,7 @@ func (s *Stream) ReadFrom(r io.Reader) (int64, error) {
 // WriteEntryRef value, commit_walk.go:455) and the file index under which PollFiles reports the hash — what
 // writeBackedFile keeps in backedHashes[path] (commit_reuse.go:450-461).
 func (s *Stream) WriteEntryReader(r io.Reader, size uint64) (payloadOffset, fileIndex uint64, err error) {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	var off, idx C.uint64_t
 	if err = check(C.pbsgpu_stream_begin_entry(s.h, nil, C.uint64_t(size), &off), "stream_begin_entry"); err != nil {
 		return 0, 0, err
@@ -398,8 +408,12 @@ func (s *Stream) WriteEntryReader(r io.Reader, size uint64) (payloadOffset, file
 }
 
 // BeginFile / EndFile bracket a file body for the XXH3 tee when the caller writes the bytes itself.
-func (s *Stream) BeginFile() error { return check(C.pbsgpu_stream_begin_file(s.h), "stream_begin_file") }
+func (s *Stream) BeginFile() error {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
+	return check(C.pbsgpu_stream_begin_file(s.h), "stream_begin_file")
+}
 func (s *Stream) EndFile() (uint64, error) {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	var idx C.uint64_t
 	err := check(C.pbsgpu_stream_end_file(s.h, &idx), "stream_end_file")
 	return uint64(idx), err
@@ -409,6 +423,7 @@ func (s *Stream) EndFile() (uint64, error) {
 type FileHash struct{ Index, Size, XXH3 uint64 }
 
 func (s *Stream) PollFiles(max int) ([]FileHash, error) {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	if max <= 0 {
 		return nil, errors.New("pbsgpu: PollFiles(max <= 0)")
 	}
@@ -426,6 +441,7 @@ func (s *Stream) PollFiles(max int) ([]FileHash, error) {
 
 // WriteMarker appends the payload start (tail = false) or tail marker.
 func (s *Stream) WriteMarker(tail bool) error {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	t := C.int(0)
 	if tail {
 		t = 1
@@ -435,11 +451,13 @@ func (s *Stream) WriteMarker(tail bool) error {
 
 // Inject mirrors InjectChunks: forced cut, the payload position advances by the injected sizes.
 func (s *Stream) Inject(injectedBytes uint64) error {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	return check(C.pbsgpu_stream_cut(s.h, C.uint64_t(injectedBytes)), "stream_cut")
 }
 
 // PayloadPosition is Encoder().PayloadPosition() (commit_reuse.go:265): written + injected bytes.
 func (s *Stream) PayloadPosition() uint64 {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	var n C.uint64_t
 	C.pbsgpu_stream_position(s.h, &n)
 	return uint64(n)
@@ -447,12 +465,17 @@ func (s *Stream) PayloadPosition() uint64 {
 
 // SuggestBoundary suggests a chunk boundary at the current position (payload chunker; a file starts here).
 func (s *Stream) SuggestBoundary() error {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	return check(C.pbsgpu_stream_suggest(s.h, C.uint64_t(s.PayloadPosition())), "stream_suggest")
 }
 
-func (s *Stream) Finish() error { return check(C.pbsgpu_stream_finish(s.h), "stream_finish") }
+func (s *Stream) Finish() error {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
+	return check(C.pbsgpu_stream_finish(s.h), "stream_finish")
+}
 
 func (s *Stream) Poll(max int) ([]ChunkInfo, error) {
+	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	if max <= 0 {
 		return nil, errors.New("pbsgpu: Poll(max <= 0)")
 	}
@@ -465,6 +488,7 @@ func (s *Stream) Poll(max int) ([]ChunkInfo, error) {
 }
 
 func (s *Stream) Close() {
+	runtime.SetFinalizer(s, nil)
 	if s.h != nil {
 		C.pbsgpu_stream_destroy(s.h)
 		s.h = nil
@@ -480,6 +504,7 @@ type Chunker struct {
 }
 
 func (e *Engine) NewChunker() (*Chunker, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	c := &Chunker{eng: e}
 	if err := check(C.pbsgpu_chunker_create(e.h, &c.h), "chunker_create"); err != nil {
 		return nil, err
@@ -489,6 +514,7 @@ func (e *Engine) NewChunker() (*Chunker, error) {
 }
 
 func (c *Chunker) Scan(data []byte) (int, error) {
+	defer runtime.KeepAlive(c) // the finalizer must not run Close while the C call is executing
 	if len(data) == 0 {
 		return 0, nil
 	}
@@ -498,9 +524,13 @@ func (c *Chunker) Scan(data []byte) (int, error) {
 	return int(pos), err
 }
 
-func (c *Chunker) Reset() error { return check(C.pbsgpu_chunker_reset(c.h), "chunker_reset") }
+func (c *Chunker) Reset() error {
+	defer runtime.KeepAlive(c) // the finalizer must not run Close while the C call is executing
+	return check(C.pbsgpu_chunker_reset(c.h), "chunker_reset")
+}
 
 func (c *Chunker) Close() {
+	runtime.SetFinalizer(c, nil)
 	if c.h != nil {
 		C.pbsgpu_chunker_destroy(c.h)
 		c.h = nil
@@ -513,7 +543,38 @@ func (c *Chunker) Close() {
 // HashFiles is verification.HashFile (internal/agent/verification/handler.go:36-68) for many
 // files of one buffer: digests[i] = SHA-256(buf[offsets[i] : offsets[i]+lengths[i]]). One GPU lane per file:
 // worth it for MANY files per call (see DESIGN.md, crossover), not for a handful of huge ones.
+//
+// POLICY: SHA-256 is serial inside a file (one GPU lane per file, 0.036 GiB/s each), so a batch only beats the host's
+// SHA-NI cores with more than ~55 files per core in flight. The reference's verify job keeps FOUR files in flight
+// (internal/server/verification/job.go:493) — routed here it would be ~50x slower than sha256-simd. HashFiles therefore
+// returns ErrHostFaster (and hashes nothing) when pbsgpu_sha256_many_pays says the host wins for this batch size on
+// runtime.NumCPU() cores; HashFilesForced skips the question.
 func (e *Engine) HashFiles(buf []byte, offsets, lengths []uint64) ([][32]byte, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
+	var pays C.int
+	if err := check(C.pbsgpu_sha256_many_pays(e.h, C.uint32_t(len(offsets)), C.uint32_t(runtime.NumCPU()), &pays), "sha256_many_pays"); err != nil {
+		return nil, err
+	}
+	if pays == 0 {
+		return nil, ErrHostFaster
+	}
+	return e.HashFilesForced(buf, offsets, lengths)
+}
+
+// ErrHostFaster: the batch is too small for the GPU to beat the host's SHA-NI cores; hash on the host.
+var ErrHostFaster = errors.New("pbsgpu: too few files in flight for the GPU to beat host SHA-256; hash on the host")
+
+// Trim releases device memory the engine only keeps for re-use (window buffers of closed streams).
+func (e *Engine) Trim() (uint64, error) {
+	defer runtime.KeepAlive(e)
+	var n C.uint64_t
+	err := check(C.pbsgpu_engine_trim(e.h, &n), "engine_trim")
+	return uint64(n), err
+}
+
+// HashFilesForced hashes on the GPU whatever the batch size.
+func (e *Engine) HashFilesForced(buf []byte, offsets, lengths []uint64) ([][32]byte, error) {
+	defer runtime.KeepAlive(e)
 	segs, err := toSegments(offsets, lengths)
 	if err != nil || len(segs) == 0 {
 		return nil, errors.New("pbsgpu: HashFiles needs matching, non-empty offsets/lengths")
@@ -531,6 +592,7 @@ func (e *Engine) HashFiles(buf []byte, offsets, lengths []uint64) ([][32]byte, e
 
 // XXH3Files is the per-file XXH3-64 of verifyBackedFileHashes (internal/pxarmount/commit_orchestrate.go:485-562).
 func (e *Engine) XXH3Files(buf []byte, offsets, lengths []uint64) ([]uint64, error) {
+	defer runtime.KeepAlive(e) // the finalizer must not run Close while the C call is executing
 	segs, err := toSegments(offsets, lengths)
 	if err != nil || len(segs) == 0 {
 		return nil, errors.New("pbsgpu: XXH3Files needs matching, non-empty offsets/lengths")

@@ -114,6 +114,9 @@ typedef struct pbsgpu_engine pbsgpu_engine;
 int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight, pbsgpu_engine **out);
 void pbsgpu_engine_destroy(pbsgpu_engine *eng);
 int pbsgpu_engine_config(const pbsgpu_engine *eng, pbsgpu_config *out);
+/* Release device memory the engine only holds for re-use (window buffers of destroyed payload streams, bounded by
+ * PBSGPU_STREAM_POOL_GIB, default 16). Waits for the device to go idle: call it between jobs. */
+int pbsgpu_engine_trim(pbsgpu_engine *eng, uint64_t *freed_bytes);
 
 /* Batch path (the data-parallel form of WriteEntryReader's chunk loop —
  * internal/pxarmount/commit_reuse.go:457, commit_walk.go:475,
@@ -256,6 +259,13 @@ int pbsgpu_sha256_many_device(pbsgpu_engine *eng, const void *dptr, uint64_t nby
                               const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests /* 32*nseg */);
 int pbsgpu_sha256_many_host(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes,
                             const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests);
+/* POLICY for the two calls above. SHA-256 is serial inside a file: the GPU hashes ONE file per lane at 0.036 GiB/s
+ * whatever its size, a SHA-NI host core does ~2 GiB/s, so a batch only wins with more than ~55 files in flight per
+ * host core that would otherwise hash (measured). The reference's verify job keeps FOUR files in
+ * flight (internal/server/verification/job.go:493): routed to the GPU it would run ~50x slower than sha256-simd.
+ * *pays = 1 when a batch of `nfiles` beats `host_cores` (0 = 1) host cores, else 0 — a binding keeps the host hash
+ * when it says 0 (go/pbsgpu: Engine.HashFiles returns ErrHostFaster). The hash calls themselves never refuse. */
+int pbsgpu_sha256_many_pays(const pbsgpu_engine *eng, uint32_t nfiles, uint32_t host_cores, int *pays);
 
 /* ---- whole-stream XXH3-64 batch ---------------------------------------------------
  * The per-file hash the commit path tees new file bodies through and re-checks afterwards:

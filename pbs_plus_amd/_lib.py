@@ -104,6 +104,8 @@ SYMBOLS = {
     "pbsgpu_engine_create": (C.c_int, [C.c_int, C.POINTER(Config), C.c_uint32, C.POINTER(_P)]),
     "pbsgpu_engine_destroy": (None, [_P]),
     "pbsgpu_engine_config": (C.c_int, [_P, C.POINTER(Config)]),
+    "pbsgpu_engine_trim": (C.c_int, [_P, _U64P]),
+    "pbsgpu_sha256_many_pays": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
     "pbsgpu_submit_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
     "pbsgpu_submit_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
     "pbsgpu_submit_device_suggested": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P, _P, _U64P]),

@@ -101,8 +101,10 @@ static void free_engine(pbsgpu_engine *e) {
         (void)hipStreamDestroy(cs);
     }
     for (auto &b : e->win_pool) b.release();
-    for (auto &s : e->slots) s->destroy();
-    for (auto &s : e->aux) s->destroy();
+    for (auto &s : e->slots)
+        if (s) s->destroy();  // a failed create leaves a null entry behind (new(nothrow) Slot)
+    for (auto &s : e->aux)
+        if (s) s->destroy();
     if (e->d_table_rot) (void)hipFree(e->d_table_rot);
     delete e;
 }
@@ -288,11 +290,15 @@ static Slot *acquire_pool_slot(pbsgpu_engine *e) {
     return nullptr;
 }
 
-static void release_pool_slot(pbsgpu_engine *e, Slot *s) {
+// `ticket` != 0: release only if the slot still belongs to that ticket. A second collect of the same ticket that got
+// past with_ticket's lookup before the first one finished must not free a slot that a NEW submit has acquired meanwhile.
+static void release_pool_slot(pbsgpu_engine *e, Slot *s, uint64_t ticket = 0) {
     std::lock_guard<std::mutex> lk(e->mu);
+    if (ticket && s->ticket != ticket) return;
     if (s->busy) e->tickets_out.fetch_sub(1, std::memory_order_relaxed);
     s->busy = false;
     s->ready = false;
+    s->ticket = 0;
 }
 
 // run fn on the slot that owns `ticket`, serialised against other calls on the same ticket
@@ -671,6 +677,40 @@ void pbsgpu_engine_destroy(pbsgpu_engine *e) {
     engine_unref(e);
 }
 
+// Give back what the engine only keeps for re-use: window buffers parked by destroyed streams (hipFree waits for the
+// device to go idle, so this is for quiet moments — between backup jobs, or when another allocation has failed).
+int pbsgpu_engine_trim(pbsgpu_engine *e, uint64_t *freed_bytes) {
+    if (!e) return PBSGPU_E_INVALID;
+    CHK(set_device(e));
+    uint64_t freed = 0;
+    {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        for (auto &b : e->win_pool) {
+            freed += b.cap;
+            b.release();
+        }
+        e->win_pool.clear();
+    }
+    if (freed_bytes) *freed_bytes = freed;
+    return PBSGPU_OK;
+}
+
+// SHA-256 is serial inside a file: one GPU lane hashes one file at 64 B per ~1.66 us = 0.036 GiB/s whatever its size,
+// a SHA-NI host core does ~2 GiB/s. A whole-file batch therefore only beats `host_cores` cores with more than
+// ~55 files per core in flight (measured: profiles/r02_verify_workload.log). The reference's verify
+// job keeps 4 files in flight (internal/server/verification/job.go:493): a drop-in that sent those to the GPU would
+// be ~50x slower than the code it replaces, so bindings ask first.
+int pbsgpu_sha256_many_pays(const pbsgpu_engine *e, uint32_t nfiles, uint32_t host_cores, int *pays) {
+    if (!e || !pays) return PBSGPU_E_INVALID;
+    static const uint32_t per_core = []() -> uint32_t {
+        const char *v = getenv("PBSGPU_SHA_MANY_FILES_PER_CORE");
+        return (uint32_t)std::max(1, v ? atoi(v) : 55);
+    }();
+    if (host_cores == 0) host_cores = 1;
+    *pays = (uint64_t)nfiles > (uint64_t)per_core * host_cores ? 1 : 0;
+    return PBSGPU_OK;
+}
+
 int pbsgpu_engine_config(const pbsgpu_engine *e, pbsgpu_config *out) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = e->cfg;
@@ -747,9 +787,11 @@ int pbsgpu_ticket_done(pbsgpu_engine *e, uint64_t ticket, int *done) {
 
 int pbsgpu_collect(pbsgpu_engine *e, uint64_t ticket, pbsgpu_record *out, uint64_t cap, uint64_t *nrecords) {
     if (!e) return PBSGPU_E_INVALID;
-    Slot *owner = nullptr;
+    // The ticket is released on success and on every hard error (E_CAPACITY keeps it valid for a retry) — INSIDE the
+    // ticket's critical section (Slot::op held by with_ticket): a concurrent collect / wait of the same ticket is either
+    // serialised in front of this one or finds the ticket gone (E_TICKET), never a half-released slot.
     int st = with_ticket(e, ticket, [&](Slot &s) -> int {
-        owner = &s;
+        const int r = [&]() -> int {
         CHK(sync_slot(e, s));
         if (nrecords) *nrecords = s.nrec;
         if (s.nrec > cap || (!out && s.nrec)) return PBSGPU_E_CAPACITY;
@@ -774,9 +816,10 @@ int pbsgpu_collect(pbsgpu_engine *e, uint64_t ticket, pbsgpu_record *out, uint64
             }
         }
         return PBSGPU_OK;
+        }();
+        if (r != PBSGPU_E_CAPACITY) release_pool_slot(e, &s, ticket);
+        return r;
     });
-    // the ticket is released on success and on every hard error; E_CAPACITY keeps it valid for a retry
-    if (owner && st != PBSGPU_E_CAPACITY && st != PBSGPU_E_TICKET) release_pool_slot(e, owner);
     return st;
 }
 

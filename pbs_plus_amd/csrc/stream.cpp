@@ -349,11 +349,40 @@ int stream_buffer_ensure(pbsgpu_stream *s, DevBuf &b) {
 // a window buffer that is neither current nor held; grows the ring up to max_bufs, then waits for the oldest window
 int stream_free_buffer(pbsgpu_stream *s, int *out) {
     for (;;) {
-        for (size_t i = 0; i < s->dev.size(); ++i)
+        bool retry = false;
+        for (size_t i = 0; i < s->dev.size() && !retry; ++i)
             if (!s->dev_busy[i] && (int)i != s->cur) {
-                *out = (int)i;
-                return stream_buffer_ensure(s, s->dev[i]);
+                const int st = stream_buffer_ensure(s, s->dev[i]);
+                if (st == PBSGPU_OK) {
+                    *out = (int)i;
+                    return PBSGPU_OK;
+                }
+                // HBM is full (other streams' rings, resident batches): that is back-pressure, not a write error, as long
+                // as this stream has windows in flight whose buffers come back. Drop the empty ring entry, stop growing,
+                // and wait for the oldest window instead. Only a ring that cannot reach its minimum (current + one
+                // more buffer) fails.
+                if (st != PBSGPU_E_NOMEM || s->dev[i].p) return st;
+                {   // buffers parked by destroyed streams are the first thing to give back
+                    std::lock_guard<std::mutex> lk(s->eng->pool_mu);
+                    if (!s->eng->win_pool.empty()) {
+                        for (auto &b : s->eng->win_pool) b.release();
+                        s->eng->win_pool.clear();
+                        retry = true;
+                        continue;
+                    }
+                }
+                if (s->inflight.empty()) return PBSGPU_E_NOMEM;
+                if ((int)i < s->cur) s->cur--;
+                for (auto &w : s->inflight)
+                    if (w.buf > (int)i) w.buf--;
+                if (s->pend.active && s->pend.buf > (int)i) s->pend.buf--;
+                s->dev.erase(s->dev.begin() + (long)i);
+                s->dev_busy.erase(s->dev_busy.begin() + (long)i);
+                s->max_bufs = std::max<size_t>(s->dev.size(), 2);
+                CHK(stream_complete_oldest(s, true));
+                retry = true;
             }
+        if (retry) continue;
         if (s->dev.size() < s->max_bufs) {
             s->dev.emplace_back();
             s->dev_busy.push_back(0);
@@ -689,10 +718,22 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
         if (s->hs) (void)hipStreamSynchronize(s->hs);
         s->cut[1].destroy();
         s->cut[0].destroy();
-        {   // window buffers go back to the engine (freed with it); the pool is capped at what one ring holds
+        {   // window buffers go back to the engine for the next stream (hipFree waits for the whole device, i.e. for other
+            // streams' running hash jobs). The pool is bounded in BYTES (one default ring, PBSGPU_STREAM_POOL_GIB): a
+            // long-lived engine that opens one stream per backup job must not pin tens of GiB of HBM; what does not fit
+            // is freed below. pbsgpu_engine_trim() empties the pool on request.
+            static const uint64_t pool_limit = []() -> uint64_t {
+                const char *v = getenv("PBSGPU_STREAM_POOL_GIB");
+                return (uint64_t)(v ? std::max(0L, atol(v)) : 16L) << 30;
+            }();
             std::lock_guard<std::mutex> lk(e->pool_mu);
+            uint64_t held = 0;
+            for (auto &b : e->win_pool) held += b.cap;
             for (auto &b : s->dev)
-                if (b.p && e->win_pool.size() < 256) e->win_pool.push_back(std::move(b));
+                if (b.p && held + b.cap <= pool_limit) {
+                    held += b.cap;
+                    e->win_pool.push_back(std::move(b));
+                }
         }
         for (auto &b : s->dev) b.release();
         for (auto &b : s->stage) b.release();

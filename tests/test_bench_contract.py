@@ -28,6 +28,10 @@ class _FakeBuf:
     def free(self):
         self.freed = True
 
+    def download(self, offset=0, nbytes=None):
+        n = self.nbytes - offset if nbytes is None else nbytes
+        return self.host[offset:offset + n].copy()
+
 
 class _FakeEngine:
     """Same surface as pbs_plus_amd.Engine as far as bench.py uses it; bytes live in host arrays."""
@@ -160,6 +164,10 @@ def _check_common(d, steps, warmup):
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0
     assert c["records_match_gpu"] is True and c["records_checked"] > 0
+    # parity is checked across every resident slot (restart points), not only at the front of batch 0
+    sp = c["whole_batch_restart_points"]
+    assert sp["ok"] is True and sp["slots"] == d["config"]["resident_batches"] and sp["records_checked"] > 0
+    assert sp["max_offset"] >= 0.9 * d["config"]["bytes_per_batch"]   # the tail of a slot was part of a span
 
 
 @pytest.mark.parametrize("slots,steps,collect", [(4, 9, "any"), (1, 2, "fifo"), (3, 7, "fifo")])
@@ -172,6 +180,25 @@ def test_bench_default_workload_contract(monkeypatch, slots, steps, collect):
     assert d["config"]["resident_batches"] == slots and d["config"]["inflight_batches"] == slots
     assert d["config"]["distinct_data_per_slot"] is True and d["config"]["collect"] == collect
     assert d["config"]["resident_bytes_per_gpu"] == slots * d["config"]["bytes_per_batch"]
+
+
+def test_bench_default_line_carries_the_other_configs(monkeypatch):
+    """configs[2..4] ride in the default line as short legs, each with its own oracle check (here at reduced shapes; the
+    host-fed legs need the real stream writer and are covered by the -m gpu suite)"""
+    _patch(monkeypatch)
+    d = _run(monkeypatch, ["--gib", str(16 / 1024), "--avg", "65536", "--steps", "4", "--warmup", "1", "--cpu-sample-gib",
+                           str(8 / 1024), "--extras-gib", str(32 / 1024), "--extras-file-mib", "1",
+                           "--extras", "manyfiles,corpus_dup,rechunk"])
+    _check_common(d, 4, 1)
+    w = d["workloads"]
+    assert set(w) == {"manyfiles", "corpus_dup", "rechunk", "total_seconds"}
+    for name in ("manyfiles", "corpus_dup", "rechunk"):
+        leg = w[name]
+        assert "error" not in leg, leg
+        assert leg["value"] > 0 and leg["steps"] == 4 and leg["records_match_gpu"] is True and leg["records_checked"] > 0
+    dd = w["corpus_dup"]["results"]["dedup"]
+    assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 0.02
+    assert w["rechunk"]["results"]["reused_chunk_bytes_frac"] > 0.3
 
 
 def test_bench_reread_protocol_is_labelled(monkeypatch):

@@ -354,6 +354,18 @@ def test_full_size_config2_properties(engines, O):
         start = int(ends[i] - sizes[i])
         data = buf.download(start, int(sizes[i]))
         assert bytes(recs["digest"][i]) == hashlib.sha256(data.tobytes()).digest(), i
+    # oracle parity ACROSS the stream (restart points: a cut resets the chunker, so the records behind any cut depend
+    # only on the bytes behind it): 48 points spread over the 64 GiB incl. the first cuts beyond 2^32 and 2^35 and the
+    # span that reaches the final chunk in the last scan tile — cuts AND digests vs the oracle on downloaded bytes
+    from oracle import restart_check as RC
+    r = RC.check_batch(lambda off, m: buf.download(off, m), None, recs, 4 << 20, nbytes=n, k=48, span=64 << 20, threads=16)
+    assert r["ok"], r
+    assert r["records_checked"] > 400 and r["max_offset"] == n and r["points"] >= 48
+    # raw candidates of a window that lies beyond 60 GiB, vs the oracle's candidate list of the downloaded bytes
+    woff, wlen = (61 << 30) + 4096 + 17, (96 << 20) + 5
+    got_c = eng.candidates(buf.ptr + woff, wlen)
+    want_c = O.candidates(O.new_config(4 << 20), buf.download(woff, wlen))
+    assert np.array_equal(got_c, want_c) and want_c.size >= 5, (got_c.size, want_c.size)
     buf.free()
 
 

@@ -651,6 +651,8 @@ def test_bench_workloads_at_full_scale_check_against_the_oracle(gpu_lib, workloa
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["cpu_baseline"]["records_match_gpu"] is True and d["cpu_baseline"]["records_checked"] > 50
+    sp = d["cpu_baseline"]["whole_batch_restart_points"]   # every resident slot, spread over its bytes
+    assert sp["ok"] is True and sp["slots"] == d["config"]["resident_batches"] and sp["records_checked"] > 300, sp
     assert d["config"]["resident_bytes_per_gpu"] >= 120 * (1 << 30)
     if workload == "manyfiles":
         assert d["config"]["files_per_batch"] == 2048 and d["config"]["chunks_per_batch"] > 20_000
