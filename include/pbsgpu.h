@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSGPU_ABI_VERSION 2
+#define PBSGPU_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------- */
 #define PBSGPU_OK 0
@@ -250,6 +250,62 @@ int pbsgpu_stream_begin_entry(pbsgpu_stream *s, const struct pbsgpu_payload_form
                               uint64_t *payload_offset);
 int pbsgpu_stream_end_entry(pbsgpu_stream *s, uint64_t *file_index);
 int pbsgpu_stream_write_marker(pbsgpu_stream *s, const struct pbsgpu_payload_format *fmt, int tail);
+
+/* ---- page ring: many payload streams, page-granular memory release, persistent SHA-256 service ------------------
+ * The data-parallel form of the chunk loop behind WriteEntryReader for SEVERAL archives at once (one writer per
+ * archive: internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836) when the bytes are (or arrive)
+ * in device memory. A batch submitted with pbsgpu_submit_device stays resident until its LONGEST chunk is hashed
+ * (SHA-256 is serial inside a chunk: up to ~0.45 s for 16 MiB); the ring gives memory back PAGE by page:
+ *   - the arena is cut into pages (>= max chunk size); a stream = pages in logical order, anywhere in the arena;
+ *   - reserve / commit (or fill, the synthetic producer) hand the stream's next page to the ring; pump cuts the newly
+ *     committed pages of all streams in one round on the device and feeds every cut chunk to the SHA-256 service, a
+ *     persistent kernel whose lanes take the next chunk the moment they finish one;
+ *   - a page is free again as soon as every chunk touching it has been READ by the service (not when a batch ends);
+ *   - poll returns the stream's finished (end, digest) records in stream order; `end` is the absolute stream offset.
+ * Results are bit-identical to one pbsgpu_submit_* / pbsgpu_stream_* pass over the same bytes.
+ * One thread drives a ring. While the service runs, hipDeviceSynchronize / hipFree block: call quiesce first. */
+typedef struct pbsgpu_ring pbsgpu_ring;
+typedef struct pbsgpu_ring_options {
+    uint64_t arena_bytes;  /* device memory for pages; 0 = what is free minus 8 GiB */
+    uint64_t page_bytes;   /* 0 = default: max chunk rounded up to whole scan tiles (16.2 MiB at avg 4 MiB) */
+    uint32_t max_streams;  /* streams open at once; 0 = 64 */
+    uint32_t sha_cus;      /* CUs of the SHA-256 service; 0 = all but 48 (the rest runs the cut rounds) */
+    uint32_t round_pages;  /* most pages one round cuts; 0 = 256 */
+    uint32_t reserved;
+} pbsgpu_ring_options;
+typedef struct pbsgpu_ring_stats {
+    uint64_t page_bytes, bytes_enqueued, chunks, candidates, pages_enqueued, pages_recycled, service_bytes_last;
+    uint32_t pages_total, pages_free, sha_cus, rounds, rounds_done, rounds_in_flight, streams_opened, service_launches;
+    double service_ms_last;  /* duration of the most recent service launch (HIP events on its stream), set by quiesce */
+    double service_ms_total;
+} pbsgpu_ring_stats;
+int pbsgpu_ring_create(pbsgpu_engine *eng, const pbsgpu_ring_options *opt /* NULL = defaults */, pbsgpu_ring **out);
+void pbsgpu_ring_destroy(pbsgpu_ring *ring);
+/* A new stream (fresh chunker state). PBSGPU_E_BUSY when max_streams are open. */
+int pbsgpu_ring_open(pbsgpu_ring *ring, uint32_t *stream);
+/* The stream's next page: a device pointer to write up to *cap (= page size) bytes to — by a kernel, a DMA, a peer.
+ * PBSGPU_E_BUSY when no page is free right now (pump / poll and retry). */
+int pbsgpu_ring_reserve(pbsgpu_ring *ring, uint32_t stream, void **dptr, uint64_t *cap);
+/* The first nbytes of the reserved page are the stream's next bytes and are VISIBLE to the device (the producer has
+ * finished). Every page but the stream's last must be full; final != 0 ends the stream (nbytes may then be 0, also
+ * without a reservation). */
+int pbsgpu_ring_commit(pbsgpu_ring *ring, uint32_t stream, uint64_t nbytes, int final);
+/* Synthetic producer (benchmarks, parity tests): the stream's next nbytes come from the generator of
+ * pbsgpu_fill_device (seed, kind) at the stream's current offset, written by the round itself. Takes as many whole
+ * pages as are free: *taken bytes were accepted, call again with the rest after a pump. */
+int pbsgpu_ring_fill(pbsgpu_ring *ring, uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, int final,
+                     uint64_t *taken);
+/* Enqueue the committed pages as cut rounds, collect finished rounds and freed pages. Never blocks. */
+int pbsgpu_ring_pump(pbsgpu_ring *ring);
+/* Up to cap finished records of the stream, in stream order; *finished = 1 once the stream has ended and every record
+ * has been handed out. */
+int pbsgpu_ring_poll(pbsgpu_ring *ring, uint32_t stream, pbsgpu_record *out, uint64_t cap, uint64_t *n, int *finished);
+/* Release a finished, fully polled stream's slot. */
+int pbsgpu_ring_close(pbsgpu_ring *ring, uint32_t stream);
+/* Wait until everything enqueued is hashed and stop the service kernel (the device is then idle as far as the ring is
+ * concerned); the next pump starts it again. */
+int pbsgpu_ring_quiesce(pbsgpu_ring *ring);
+int pbsgpu_ring_get_stats(pbsgpu_ring *ring, pbsgpu_ring_stats *out);
 
 /* ---- whole-stream SHA-256 batch ---------------------------------------------
  * verification.HashFile (internal/agent/verification/handler.go:36-68) and

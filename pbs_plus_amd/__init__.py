@@ -7,6 +7,7 @@ pbs-plus reference uses for its pxar stream path:
   (reference internal/pxarmount/commit_orchestrate.go:143-149, internal/tapeio/converter.go:248)
 * ``Engine`` — batch cut + digest (the chunk loop behind ``WriteEntryReader``)
 * ``PayloadStream`` — the payload-stream writer seam (``transfer.ArchiveWriter``)
+* ``PageRing`` — many streams, page-granular memory release, persistent SHA-256 service
 * ``Chunker`` — upstream-style ``scan`` compatibility
 * ``didx`` / ``dedup`` — dynamic index records and the cross-GPU digest-set reduce
 
@@ -22,6 +23,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from . import buzhash  # noqa: F401,E402
 from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401,E402
-from .engine import Chunker, Engine, PayloadStream  # noqa: F401,E402
+from .engine import Chunker, Engine, PageRing, PayloadStream  # noqa: F401,E402
 
-__all__ = ["buzhash", "Engine", "PayloadStream", "Chunker", "RECORD_DTYPE", "PbsGpuError"]
+__all__ = ["buzhash", "Engine", "PayloadStream", "PageRing", "Chunker", "RECORD_DTYPE", "PbsGpuError"]

@@ -78,6 +78,19 @@ class FileHash(C.Structure):
     _fields_ = [("index", C.c_uint64), ("size", C.c_uint64), ("xxh3", C.c_uint64)]
 
 
+class RingOptions(C.Structure):
+    _fields_ = [("arena_bytes", C.c_uint64), ("page_bytes", C.c_uint64), ("max_streams", C.c_uint32),
+                ("sha_cus", C.c_uint32), ("round_pages", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class RingStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("page_bytes", "bytes_enqueued", "chunks", "candidates", "pages_enqueued",
+                                          "pages_recycled", "service_bytes_last")] + \
+               [(k, C.c_uint32) for k in ("pages_total", "pages_free", "sha_cus", "rounds", "rounds_done",
+                                          "rounds_in_flight", "streams_opened", "service_launches")] + \
+               [("service_ms_last", C.c_double), ("service_ms_total", C.c_double)]
+
+
 class DedupStats(C.Structure):
     _fields_ = [
         ("nrecords", C.c_uint64),
@@ -137,6 +150,17 @@ SYMBOLS = {
     "pbsgpu_stream_begin_entry": (C.c_int, [_P, _P, C.c_uint64, _U64P]),
     "pbsgpu_stream_end_entry": (C.c_int, [_P, _U64P]),
     "pbsgpu_stream_write_marker": (C.c_int, [_P, _P, C.c_int]),
+    "pbsgpu_ring_create": (C.c_int, [_P, C.POINTER(RingOptions), C.POINTER(_P)]),
+    "pbsgpu_ring_destroy": (None, [_P]),
+    "pbsgpu_ring_open": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "pbsgpu_ring_reserve": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), _U64P]),
+    "pbsgpu_ring_commit": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_int]),
+    "pbsgpu_ring_fill": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, _U64P]),
+    "pbsgpu_ring_pump": (C.c_int, [_P]),
+    "pbsgpu_ring_poll": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _U64P, C.POINTER(C.c_int)]),
+    "pbsgpu_ring_close": (C.c_int, [_P, C.c_uint32]),
+    "pbsgpu_ring_quiesce": (C.c_int, [_P]),
+    "pbsgpu_ring_get_stats": (C.c_int, [_P, C.POINTER(RingStats)]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),

@@ -31,6 +31,11 @@ struct ScanParams {
     unsigned long long *tile_queue;  // device counter, zero at launch: next tile to hand out
     uint32_t tiles_per_wave;         // k_scan3: 0 = persistent workgroups, else a wave retires after this many tiles
     uint32_t shared_chip;            // other batches of the engine are in flight (their SHA chains are running)
+    // page-ring rounds (k_scan3 only): tile t lies in page entry t / ring_tpp at tile index t % ring_tpp of that page;
+    // data_al = arena base. Null for flat byte ranges.
+    const struct RingPage *ring_pages;
+    uint32_t ring_tpp;
+    uint32_t max_blocks;             // 0 = no extra limit on the launch's workgroups
 };
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st);
@@ -46,7 +51,8 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 // dense, ascending candidate END offsets (caller coordinates) from the per-tile slots
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
-                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st);
+                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st,
+                          const struct RingPage *ring_pages = nullptr, uint32_t ring_tpp = 0);
 
 // one long stream without suggested boundaries: the cut chain followed by pointer doubling (kernels.hip); `scratch` holds
 // resolve_par_scratch_bytes(node_cap, levels); falls back to the serial walk when there are more candidates than node_cap - 1
@@ -138,6 +144,115 @@ hipError_t launch_publish_records(pbsgpu_record *dst_host_mapped, const pbsgpu_r
 
 hipError_t launch_fill(void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed, uint32_t kind,
                        hipStream_t st);
+
+// ---- page ring (ring.cpp): persistent SHA-256 service + cut rounds over non-adjacent pages ----------------------
+struct alignas(64) RingCtl {   // device memory, one 64-byte line
+    union {
+        struct {
+            uint32_t tail;     // positions < tail are published
+            uint32_t stop;     // nothing will be published beyond tail
+        };
+        unsigned long long tail_stop;  // ... read together as one 64-bit word by the service's lanes
+    };
+    uint32_t head;         // next queue position to hand out
+    uint32_t free_count;   // pages reported free so far
+    uint32_t error;        // sticky: a cut round overflowed a capacity (ring.cpp reports PBSGPU_E_DENSITY)
+    uint32_t pad[11];
+};
+struct RingSource {
+    static constexpr bool kRing = true;
+    const uint4 *desc;         // ring of positions, 2 x uint4 each: {p1.lo, p1.hi, len, len1} {p2v.lo, p2v.hi, cell, pages}
+    uint32_t qmask;            // positions - 1 (power of two)
+    RingCtl *ctl;
+    uint8_t *cells;            // mapped pinned: 64-byte record cells {end, digest[32], segment, size, flag, pad}
+    uint32_t *pending;         // per physical page: chunks not yet loaded + holds of open chunks
+    unsigned long long *free_fifo;  // mapped pinned: (sequence << 32) | page
+    uint32_t free_mask;
+    unsigned long long idle_ticks;  // wall-clock ticks (100 MHz) an idle wave waits for work before it gives up
+};
+
+
+// scalar slots of a round (same numbering as engine_internal.h's SC_*)
+enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsTileq = 6 /* u64 */, kRsCount = 10 };
+
+// One physical page of a round (host-written, mapped pinned memory; read by the round's kernels).
+struct RingPage {
+    uint64_t phys_off;     // byte offset of the page BODY from the arena base (a 128-byte pad precedes and follows it)
+    uint64_t logical;      // (stream slot << 40) | offset of the page's first byte within its stream
+    uint32_t valid;        // bytes of the page that belong to the stream (== page size except a stream's last page)
+    uint32_t slot;         // stream slot
+    uint32_t phys;         // physical page index
+    uint32_t seg;          // index of the stream's segment entry in this round
+    uint64_t fill_seed;    // synthetic producer (bench / tests): generator seed, kind and stream offset
+    uint64_t fill_off;
+    uint32_t fill_kind;
+    uint32_t do_fill;
+};
+// One stream of a round.
+struct RingSeg {
+    uint32_t slot;         // stream slot
+    uint32_t first_page;   // first entry of the stream's new pages in the round's page table (ascending logical order)
+    uint32_t npages;       // may be 0 (a stream that is only being finished)
+    uint32_t final;        // the stream ends with this round: its tail becomes the final chunk
+    uint64_t new_end;      // logical length of the stream after this round
+    uint32_t reset;        // first round of a new stream in this slot: state starts from zero
+    uint32_t pad;
+};
+// Device-resident state of a stream slot.
+constexpr uint64_t kRingMaxStream = 1ull << 40;  // logical coordinates are (stream slot << 40) | offset
+constexpr uint32_t kRingPT = 32;       // page-table window per stream (open chunk <= 2 pages + new pages of one round)
+struct RingStreamState {
+    uint64_t c;            // start of the open chunk (logical offset in the stream)
+    uint64_t end;          // bytes received so far
+    uint32_t pt[kRingPT];  // logical page k -> physical page, at [k % kRingPT]
+};
+struct RingRoundStatus {   // mapped pinned: written last by a round
+    uint32_t seq;          // round number + 1
+    uint32_t nrec;         // record cells written (open chunks included as void cells)
+    uint32_t ncand;
+    uint32_t error;        // 1 = a scan tile overflowed its candidate capacity, 2 = record capacity
+    uint32_t tail;         // queue tail after this round
+    uint32_t pad[3];
+};
+struct RingRound {
+    // geometry / constants
+    uint8_t *arena;            // device: [pad | page 0 | pad][pad | page 1 | pad] ...
+    uint32_t page_bytes, stride, tile_bytes, tpp;
+    uint32_t effmin, cmin, maxsz, cap;
+    uint32_t thr;
+    const uint32_t *table_rot;
+    // this round's inputs (mapped pinned)
+    const RingPage *pages;
+    uint32_t npages;
+    const RingSeg *segs_in;
+    uint32_t nseg;
+    uint32_t seq;              // round number + 1
+    uint32_t cell_base, cell_cap, cell_mask;
+    uint32_t scan_blocks;      // workgroups the scan may use (the CUs the SHA service leaves free)
+    RingRoundStatus *status;   // mapped pinned
+    // persistent device state
+    RingStreamState *streams;
+    RingSource q;
+    uint4 *desc_w;             // writable view of q.desc
+    // work buffers (one set: rounds run in order on one HIP stream)
+    uint32_t *scalars;         // SC_* layout of engine_internal.h
+    uint32_t *tile_cnt, *tile_off, *tile_slots, *scan_tmp;
+    uint64_t *dense;
+    uint64_t dense_cap;
+    pbsgpu_segment *segs;
+    uint32_t *seg_cnt, *seg_off;
+    pbsgpu_record *recs;
+    uint64_t rec_cap;
+    uint64_t *seg_newc;        // per segment: the open chunk's start after this round
+    uint32_t *seg_open;        // per segment: 1 = the round left an open chunk
+};
+// enqueue one cut round on `st` (fill -> pads/segments -> scan -> compaction -> resolve -> descriptors -> publish)
+hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st);
+// the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
+hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st);
+// raise `stop` behind everything enqueued so far on `st`
+hipError_t launch_ring_stop(RingCtl *ctl, hipStream_t st);
+hipError_t launch_ring_reset(RingCtl *ctl, hipStream_t st);
 
 // digest-set: sort keys/index pairs by the first 8 digest bytes (big-endian) and flag duplicates
 hipError_t launch_dedup(const pbsgpu_record *recs, uint64_t n, uint64_t *keys, uint32_t *idx,

@@ -385,13 +385,11 @@ static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st)
 // one tile of k_scan3. INTERIOR = the whole tile and its 64-byte warm-up lie inside the buffer (wave-uniform by
 // construction): the check-free instantiation
 template <int LINES, int D, bool INTERIOR>
-__device__ __forceinline__ void scan3_tile(const ScanParams &p, const uint64_t t_idx, const uint64_t A, const int lane,
-                                           const uint8_t *lds0, uint8_t *stage, uint32_t *wcnt) {
+__device__ __forceinline__ void scan3_tile(const ScanParams &p, const uint64_t t_idx, const uint64_t wbase, const uint64_t A,
+                                           const int lane, const uint8_t *lds0, uint8_t *stage, uint32_t *wcnt) {
     constexpr uint32_t SL = LINES * 128;
-    constexpr uint64_t TILE = 64ull * SL;
     constexpr int PITCH = 80;
     constexpr int HALVES = LINES * 2;
-    const uint64_t wbase = t_idx * TILE;
     const uint64_t sbase = wbase + (uint64_t)lane * SL;
     const uint32_t thr = p.thr;
     const uint32_t lane4 = (uint32_t)lane << 2;
@@ -544,13 +542,23 @@ __global__ __launch_bounds__(512, 2) void k_scan3(ScanParams p) {
         if (lane == 0) g0 = atomicAdd(p.tile_queue, 1ull);
         const uint64_t t_idx = __shfl(g0, 0, 64);
         if (t_idx >= p.ntiles) break;
-        const uint64_t wbase = t_idx * TILE;
+        // flat range: tile t starts at t * TILE. Page ring: the tile's page comes from the round's page table — the
+        // page's body is preceded by a 128-byte pad that holds the last bytes of the stream's previous page (the
+        // window warm-up of the page's first strip), and only its `valid` bytes take part
+        uint64_t wbase = t_idx * TILE, At = A;
+        if (p.ring_pages) {
+            const RingPage &pe = p.ring_pages[t_idx / p.ring_tpp];
+            wbase = pe.phys_off + (t_idx % p.ring_tpp) * TILE;
+            At = pe.phys_off + pe.valid;
+        }
         if (lane == 0) *wcnt = 0;
         wave_sync();
-        if ((wbase >= 64) && (wbase + TILE <= A))
-            scan3_tile<LINES, D, true>(p, t_idx, A, lane, lds0, stage, wcnt);
-        else
-            scan3_tile<LINES, D, false>(p, t_idx, A, lane, lds0, stage, wcnt);
+        if (wbase < At) {
+            if ((wbase >= 64) && (wbase + TILE <= At))
+                scan3_tile<LINES, D, true>(p, t_idx, wbase, At, lane, lds0, stage, wcnt);
+            else
+                scan3_tile<LINES, D, false>(p, t_idx, wbase, At, lane, lds0, stage, wcnt);
+        }
         wave_sync();
         if (lane == 0) p.tile_cnt[t_idx] = *wcnt;
         wave_sync();
@@ -611,6 +619,7 @@ static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st)
         if (p.shared_chip && scan_cus_shared() > 0) usable = std::min<uint64_t>(usable, (uint64_t)scan_cus_shared());
         if (blocks > usable) blocks = usable;
     }
+    if (p.max_blocks && blocks > p.max_blocks) blocks = p.max_blocks;
     hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, q);
     return hipGetLastError();
 }
@@ -782,14 +791,16 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const uint32_t *tile_off,
                                                  const uint32_t *tile_slots, uint32_t cap, uint64_t ntiles,
                                                  uint32_t lead, uint64_t *dense, uint64_t dense_cap,
-                                                 uint32_t tile_bytes) {
+                                                 uint32_t tile_bytes, const RingPage *ring_pages, uint32_t ring_tpp) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint32_t c = min(tile_cnt[t], cap);
     if (c == 0) return;
     const uint32_t *sl = tile_slots + t * cap;
     const uint64_t base = tile_off[t];
-    const uint64_t tbase = t * (uint64_t)tile_bytes;
+    // page ring: candidates are reported in LOGICAL stream coordinates ((slot << 40) | offset), pages ascending
+    const uint64_t tbase = ring_pages ? ring_pages[t / ring_tpp].logical + (t % ring_tpp) * (uint64_t)tile_bytes
+                                      : t * (uint64_t)tile_bytes;
     if (c <= 48) {  // the normal case (a handful of candidates per tile): rank by comparison
         for (uint32_t j = 0; j < c; ++j) {
             const uint32_t vj = sl[j];
@@ -821,12 +832,13 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const
 
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
-                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st) {
+                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st, const RingPage *ring_pages,
+                          uint32_t ring_tpp) {
     (void)nbytes;
     if (ntiles == 0) return hipSuccess;
     const uint64_t nb = (ntiles + 255) / 256;
     hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
-                       lead, dense, dense_cap, tile_bytes);
+                       lead, dense, dense_cap, tile_bytes, ring_pages, ring_tpp);
     return hipGetLastError();
 }
 
@@ -1349,6 +1361,7 @@ __device__ __forceinline__ void sha256_tail_words(const uint8_t *base, uint64_t 
 
 // Work source for the SHA kernel: item i -> (byte pointer, length, digest destination)
 struct RecordSource {
+    static constexpr bool kRing = false;
     pbsgpu_record *recs;
     // queue position -> {chunk address lo, hi, size, record index}, longest chunks first (k_order). ONE 16-byte load
     // per chunk a lane takes from the queue: the chain order[i] -> record -> segment offset was three dependent round
@@ -1363,6 +1376,7 @@ struct RecordSource {
     }
 };
 struct SegmentSource {
+    static constexpr bool kRing = false;
     const uint8_t *data;
     const pbsgpu_segment *segs;
     uint8_t *digests;
@@ -1376,6 +1390,7 @@ struct SegmentSource {
 // explicit (pointer, length) descriptors: the shared hash jobs of the streaming writers (chunks of many windows and
 // many streams in one launch); digest i lands at digests + 32 * i
 struct DescSource {
+    static constexpr bool kRing = false;
     const HashDesc *d;
     uint8_t *digests;
     const uint32_t *order;  // queue position -> descriptor index (longest first), may be null
@@ -1386,6 +1401,21 @@ struct DescSource {
         dst = digests + (uint64_t)i * 32;
     }
 };
+
+// The page ring's SHA-256 SERVICE (ring.cpp): one persistent launch whose lanes pull chunk descriptors from a
+// device-resident FIFO that the cut rounds of ALL streams append to (k_ring_order / k_ring_publish), so a chunk starts
+// hashing the moment it has been cut, whichever round, stream or page it came from, and every lane that finishes a chunk
+// takes the next one — no batch-granular makespan, no batch-granular buffer release.
+//   * a lane CLAIMS queue positions with one wave-level atomicAdd on `head` and then waits for `tail` to pass its
+//     position (positions are unique and every position is eventually published, or `stop` is raised);
+//   * a chunk may cross from one physical page into another (pages of a stream are not adjacent): the descriptor
+//     carries both piece addresses; a block that starts in the first piece reads on into the page's 128-byte tail pad,
+//     which mirrors the first bytes of the stream's next page;
+//   * when a lane has LOADED the last block of a chunk it drops the chunk's reference on its page(s); the lane that
+//     brings a page to zero reports it to the host through a FIFO in mapped pinned memory — the page can take new
+//     bytes while the consumer wave is still compressing the chunk's last blocks;
+//   * the consumer writes the digest straight into the host-visible record cell and raises the cell's flag.
+// (RingCtl / RingSource: kernels.h)
 
 // Each lane streams one byte range through SHA-256. Per loop trip every busy lane consumes
 // one 64-byte block: the raw dwords of the NEXT block are requested before the current
@@ -1554,12 +1584,20 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         uint64_t len = 0, blk = 0, nblk = 0;  // blk = next block to fetch
         uint8_t *dst = nullptr;
         bool have = false, exhausted = false;
+        // ring service only: second piece of a chunk that crosses into another physical page (virtual base: the byte at
+        // chunk offset `off >= len1` lives at base2 + off), the chunk's page references, the lane's claimed queue position
+        [[maybe_unused]] const uint8_t *base2 = nullptr;
+        [[maybe_unused]] uint32_t len1 = 0, pages = 0xffffffffu, claim = 0;
+        [[maybe_unused]] uint32_t claimed = 0;  // (a word, not a bool: two bool flags set in sibling branches get their stores
+                                                // merged through a selected pointer by the optimiser, which puts both in scratch)
+        [[maybe_unused]] unsigned long long idle_since = 0;
         // FIFO of raw blocks in flight: a block is requested D iterations before it is expanded, so
         // HBM/TLB latency of the lane-private streams stays off the serial chain
         constexpr int D = 2;  // even (buffer parity is derived from the slot index)
         uint32_t R[D][17];
         uint32_t selv[D], cflag[D];
         uint8_t *dstv[D];
+        [[maybe_unused]] uint32_t pagesv[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
 #pragma unroll
@@ -1567,6 +1605,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             selv[s] = 0x00010203u;
             cflag[s] = 0;
             dstv[s] = nullptr;
+            pagesv[s] = 0xffffffffu;
         }
 
         // Dense form: a wave RESERVES kReserve extra queue positions with every atomic and serves its lanes from that
@@ -1576,6 +1615,51 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         constexpr uint32_t kReserve = 16;
         uint32_t res_next = 0, res_end = 0;  // the wave's reserved positions [res_next, res_end): same value in every lane
         auto acquire = [&](bool need) {
+            if constexpr (Source::kRing) {
+                // (1) lanes without a position claim one: ONE atomic per wave
+                const bool want = need && !claimed;
+                const unsigned long long mw = __ballot(want);
+                if (mw) {
+                    uint32_t first = 0;
+                    const int leader = __ffsll((long long)mw) - 1;
+                    if (lane == leader) first = atomicAdd(&src.ctl->head, (uint32_t)__popcll(mw));
+                    first = __shfl(first, leader, 64);
+                    if (want) {
+                        claim = first + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+                        claimed = 1u;
+                    }
+                }
+                // (2) has the queue reached the lane's position? A relaxed device-scope load of {tail, stop} (no cache
+                // invalidate per poll); only a lane that really takes a descriptor pays the acquire fence behind which
+                // the descriptor and the chunk's bytes (written by other kernels while this one runs) are read.
+                if (__ballot(need) == 0) return;
+                const unsigned long long ts = __hip_atomic_load(&src.ctl->tail_stop,
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t tail = (uint32_t)ts, stop = (uint32_t)(ts >> 32);
+                const bool ready = need && (int32_t)(tail - claim) > 0;
+                if (__ballot(ready)) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+                if (ready) {
+                    d0 = src.desc[2u * (claim & src.qmask)];
+                    d1 = src.desc[2u * (claim & src.qmask) + 1u];
+                }
+                // size 0 = a void position (the open chunk of a round): the lane takes another one next time.
+                // (selects and or-updates, no conditional stores: two flags set in sibling branches get their stores merged
+                // through a selected pointer by the optimiser, which moves both flags into scratch memory)
+                const bool got = ready && d0.z != 0u;
+                claimed = ready ? 0u : claimed;
+                base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)d0.y << 32) | d0.x) : base;
+                base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)d1.y << 32) | d1.x) : base2;
+                len = got ? (uint64_t)d0.z : len;
+                len1 = got ? d0.w : len1;
+                dst = got ? src.cells + (uint64_t)d1.z * 64u + 8u : dst;
+                pages = got ? d1.w : pages;
+                blk = got ? 0ull : blk;
+                nblk = got ? ((uint64_t)d0.z + 8u) / 64u + 1u : nblk;
+                have = have | got;
+                exhausted = exhausted | (need && !ready && stop != 0u);  // stop: nothing will ever be published at this position
+                return;
+            }
             const unsigned long long m = __ballot(need);
             if (m == 0) return;
             uint32_t first = 0;
@@ -1599,7 +1683,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     i = r < avail ? res_next + r : first + (r - avail);
                 }
                 if (i < nitems) {
-                    src.get(i, base, len, dst);
+                    if constexpr (!Source::kRing) src.get(i, base, len, dst);
                     blk = 0;
                     nblk = (len + 8) / 64 + 1;
                     have = true;
@@ -1624,8 +1708,10 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             uint32_t c = 0;
             if (have) {
                 const uint64_t off = blk * 64;
+                const uint8_t *bb = base;
+                if constexpr (Source::kRing) bb = (off < len1) ? base : base2;  // which physical page holds this block
                 if (off + 64 <= len) {  // pure data block: 4-byte aligned vector loads + funnel selector
-                    const uint8_t *p = base + off;
+                    const uint8_t *p = bb + off;
                     const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
                     const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
                     const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
@@ -1636,11 +1722,12 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     R[s][16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
                     selv[s] = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
                 } else {  // tail / padding block (<= 2 per range)
-                    sha256_tail_words(base, len, off, blk + 1 == nblk, R[s]);
+                    sha256_tail_words(bb, len, off, blk + 1 == nblk, R[s]);
                     selv[s] = 0x00010203u;
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
                 dstv[s] = dst;
+                if constexpr (Source::kRing) pagesv[s] = pages;
                 if (++blk == nblk) have = false;
             }
             cflag[s] = c;
@@ -1660,6 +1747,28 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
                     const uint32_t c = cflag[s];
                     uint8_t *cur_dst = dstv[s];
+                    if constexpr (Source::kRing) {
+                        // The chunk's LAST block has arrived in registers: nothing of the chunk will be read from HBM
+                        // again. Drop its page references (release: all earlier loads of this lane have completed);
+                        // whoever brings a page to zero hands it back to the host, which may refill it at once.
+                        if (c & 2u) {
+                            const uint32_t pg = pagesv[s];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
+                                if (pi != 0xffffu) {
+                                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
+                                                                                __HIP_MEMORY_SCOPE_AGENT);
+                                    if (old == 1u) {
+                                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
+                                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask],
+                                                           ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                }
+                            }
+                        }
+                    }
                     prep(s);  // refill the slot: the block D iterations ahead
                     const bool any_cur = __any(c & 1u);
                     if (any_cur) {
@@ -1676,7 +1785,23 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     }
                     ctrl[pb][lane] = c;
                     dstp[pb][lane] = cur_dst;
-                    if (lane == 0) alive[pr][pb] = any_cur ? 1u : 0u;
+                    bool live = any_cur;
+                    if constexpr (Source::kRing) {
+                        // a service wave stays until `stop` has reached every lane and its block FIFO has drained; with
+                        // nothing to do it naps instead of spinning through barriers, and a wave that has seen no work for
+                        // idle_ticks gives up (a host that died must not leave a kernel behind that never ends)
+                        const bool wave_done = __ballot(!exhausted) == 0ull;
+                        live = any_cur || !wave_done;
+                        if (!any_cur && !wave_done) {
+                            const unsigned long long now = wall_clock64();
+                            if (idle_since == 0) idle_since = now;
+                            if (now - idle_since > src.idle_ticks) exhausted = true;
+                            __builtin_amdgcn_s_sleep(48);
+                        } else {
+                            idle_since = 0;
+                        }
+                    }
+                    if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
                     if (!any_alive(pb)) running = false;  // every pair drained
                 }
@@ -1720,6 +1845,10 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     uint32_t *o = reinterpret_cast<uint32_t *>(x.d);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(H[j]);
+                    if constexpr (Source::kRing) {  // record cell in mapped pinned memory: digest first, then its flag
+                        __threadfence_system();
+                        __hip_atomic_store(o + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     sha256_iv(H);
                 }
             }
@@ -2567,5 +2696,7 @@ hipError_t launch_xxh3_items(const XxhItem *items, uint32_t nitems, uint64_t tot
                        queue);
     return hipGetLastError();
 }
+
+#include "ring_kernels.inc"
 
 }  // namespace pbsk

@@ -1,0 +1,662 @@
+// libpbsgpu host side, part 3: the PAGE RING — many payload streams through one device arena with page-granular
+// memory release and a persistent cross-stream SHA-256 service.
+//
+// Why it exists. SHA-256 is serial inside a chunk (a 16 MiB chunk = 262 144 dependent compressions ~ 0.43 s on one
+// lane), so a batch submitted with pbsgpu_submit_device keeps ALL its bytes resident until its longest chunk is done:
+// throughput <= resident bytes / 0.45 s whatever the chip could hash. The ring removes the batch as the unit of
+// residency. It stands where the chunk loop behind WriteEntryReader runs for every archive of a multi-archive ingest
+// (internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836):
+//   * device memory is an arena of fixed PAGES (>= max chunk, a whole number of scan tiles). A stream is a sequence
+//     of pages in logical order; physically they lie wherever a page was free;
+//   * newly filled pages of all streams are cut in ROUNDS (ring_kernels.inc): scan of the new pages only, multi-stream
+//     resolve continuing from each stream's open chunk (device-resident state: no host round trip between rounds);
+//   * every cut chunk goes into ONE device-resident FIFO that the SHA-256 SERVICE — a persistent kernel on a fixed set
+//     of CUs — drains: a lane takes the next chunk the moment it finishes one, across rounds and streams;
+//   * each page counts the chunks that still have to be read from it (plus a hold while the stream's open chunk
+//     reaches into it). The lane that loads a chunk's last block drops the reference; a page that reaches zero is
+//     reported to the host through mapped pinned memory and can take new bytes at once — residency per page is the
+//     hash time of the longest chunk that touches THAT page, not of the longest chunk of a 64 GiB batch;
+//   * digests and record fields land in host-visible record cells; pbsgpu_ring_poll hands them out per stream, in order.
+// One thread drives a ring (like one goroutine owns a writer, internal/tapeio/converter.go:672-680).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <thread>
+
+#include "engine_internal.h"
+
+using namespace pbse;
+
+namespace {
+
+constexpr uint32_t kInputs = 16;          // rounds whose host-written tables may be in flight
+constexpr uint32_t kPagesPerStreamRound = 12;  // < kRingPT - 2 (open chunk) with room to spare
+
+struct PageReq {                          // a committed page waiting for its round
+    uint32_t phys = 0;
+    uint64_t k = 0;                       // logical page index in its stream
+    uint32_t valid = 0;
+    bool final = false;
+    bool do_fill = false;
+    uint64_t seed = 0, fill_off = 0;
+    uint32_t kind = 0;
+};
+
+struct CellRef {
+    uint32_t cell;
+    uint32_t round_idx;                   // index into live rounds' accounting (seq)
+};
+
+struct StreamSlot {
+    bool open = false;
+    bool fresh = true;                    // no round has carried this stream yet (device state starts from zero)
+    uint64_t next_k = 0;                  // next logical page
+    uint64_t bytes_committed = 0;
+    uint64_t bytes_enqueued = 0;          // stream length after the rounds enqueued so far
+    bool final_committed = false, final_enqueued = false, final_done = false;
+    bool zero_final = false;              // final commit of 0 bytes still to be carried by a round
+    uint32_t final_seq = 0;
+    int64_t reserved = -1;                // physical page handed out by reserve
+    std::deque<PageReq> ready;
+    std::deque<CellRef> cells;            // record cells in stream order (round results reaped)
+    uint64_t records_out = 0;
+};
+
+struct RoundInfo {
+    uint32_t seq = 0;                     // round number + 1
+    uint32_t input = 0;
+    uint64_t cell_base = 0;               // monotonic
+    uint32_t cell_cap = 0;
+    uint32_t live_cells = 0;              // cells handed to streams and not yet polled
+    bool reaped = false;
+    std::vector<uint32_t> finals;         // slots whose stream ended with this round
+    std::vector<uint32_t> phys;           // pages carried (diagnostics)
+};
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct pbsgpu_ring {
+    pbsgpu_engine *eng = nullptr;
+    // geometry
+    uint64_t page_bytes = 0, stride = 0;
+    uint32_t tile_bytes = 0, tpp = 0, npages = 0, max_streams = 0, sha_cus = 0, round_pages = 0, cap = 0;
+    uint64_t rec_cap = 0, dense_cap = 0;
+    uint32_t qslots = 0, ncells = 0, nfree = 0;
+    // device
+    DevBuf arena, ctl, streams, pending, desc;
+    DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
+    // mapped pinned
+    PinnedBuf cells, free_fifo, inputs;
+    size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_status_off = 0;
+    hipStream_t cs = nullptr, ss = nullptr;
+    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr;
+    bool service_running = false;
+    // host bookkeeping
+    std::vector<uint32_t> free_pages;
+    uint32_t free_read = 0;               // entries of the free FIFO consumed
+    std::vector<StreamSlot> slots;
+    std::deque<RoundInfo> rounds;         // enqueued, oldest first; popped when reaped AND all their cells were polled
+    bool input_busy[kInputs] = {};
+    uint32_t next_seq = 1;
+    uint64_t cell_cursor = 0;
+    int error = PBSGPU_OK;
+    pbsgpu_ring_stats st{};
+    double svc_t0 = 0;
+    uint64_t svc_bytes0 = 0;
+
+    uint8_t *in(uint32_t i) const { return inputs.as<uint8_t>() + (size_t)i * input_stride; }
+    pbsk::RingPage *in_pages(uint32_t i) const { return reinterpret_cast<pbsk::RingPage *>(in(i) + in_pages_off); }
+    pbsk::RingSeg *in_segs(uint32_t i) const { return reinterpret_cast<pbsk::RingSeg *>(in(i) + in_segs_off); }
+    pbsk::RingRoundStatus *in_status(uint32_t i) const {
+        return reinterpret_cast<pbsk::RingRoundStatus *>(in(i) + in_status_off);
+    }
+    pbsk::RingSource source() const {
+        pbsk::RingSource q{};
+        q.desc = desc.as<uint4>();
+        q.qmask = qslots - 1;
+        q.ctl = ctl.as<pbsk::RingCtl>();
+        q.cells = cells.as<uint8_t>();
+        q.pending = pending.as<uint32_t>();
+        q.free_fifo = free_fifo.as<unsigned long long>();
+        q.free_mask = nfree - 1;
+        double idle_s = 20.0;
+        if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.5, atof(v));
+        q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
+        return q;
+    }
+};
+
+namespace {
+
+uint32_t pow2_at_least(uint64_t v) {
+    uint32_t p = 1;
+    while (p < v && p < (1u << 31)) p <<= 1;
+    return p;
+}
+
+// pages the service has handed back since the last call
+void ring_reap_free(pbsgpu_ring *r) {
+    volatile unsigned long long *f = r->free_fifo.as<volatile unsigned long long>();
+    for (;;) {
+        const unsigned long long e = f[r->free_read & (r->nfree - 1)];
+        if ((uint32_t)(e >> 32) != r->free_read + 1u) break;
+        r->free_pages.push_back((uint32_t)e);
+        r->free_read++;
+        r->st.pages_recycled++;
+    }
+}
+
+// round results in order: record cells to their streams, finished streams, input tables reusable
+void ring_reap_rounds(pbsgpu_ring *r) {
+    for (auto &ri : r->rounds) {
+        if (ri.reaped) continue;
+        volatile pbsk::RingRoundStatus *hs = r->in_status(ri.input);
+        if (hs->seq != ri.seq) break;  // rounds complete in order
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (hs->error) {
+            r->error = PBSGPU_E_DENSITY;
+        } else {
+            const uint32_t n = hs->nrec;
+            const uint8_t *cells = r->cells.as<uint8_t>();
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t c = (uint32_t)((ri.cell_base + i) & (r->ncells - 1));
+                const uint32_t *cw = reinterpret_cast<const uint32_t *>(cells + (size_t)c * 64);
+                if (cw[11] == 0) continue;  // the round's open chunk: no record
+                const uint32_t slot = cw[10];
+                if (slot >= r->slots.size()) continue;
+                r->slots[slot].cells.push_back(CellRef{c, ri.seq});
+                ri.live_cells++;
+                r->st.chunks++;
+            }
+            r->st.candidates += hs->ncand;
+        }
+        for (uint32_t s : ri.finals) r->slots[s].final_done = true;
+        ri.reaped = true;
+        r->input_busy[ri.input] = false;
+        r->st.rounds_done++;
+    }
+    while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
+}
+
+int ring_start_service(pbsgpu_ring *r) {
+    if (r->service_running) return PBSGPU_OK;
+    // head := tail, stop := 0 behind everything on the control stream; the service starts behind that
+    HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));
+    HIPCHK(hipEventRecord(r->ev_reset, r->cs));
+    HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));
+    HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
+    HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
+    HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
+    r->service_running = true;
+    r->svc_t0 = now_ms();
+    r->svc_bytes0 = r->st.bytes_enqueued;
+    r->st.service_launches++;
+    return PBSGPU_OK;
+}
+
+// build + enqueue one round from the committed pages; *did = false when there is nothing to do or no room
+int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
+    *did = false;
+    pbsgpu_engine *e = r->eng;
+    if (r->error != PBSGPU_OK) return r->error;
+    bool any = false;
+    for (auto &s : r->slots) any |= s.open && (!s.ready.empty() || s.zero_final);
+    if (!any) return PBSGPU_OK;
+    int in = -1;
+    for (uint32_t i = 0; i < kInputs; ++i)
+        if (!r->input_busy[i]) { in = (int)i; break; }
+    if (in < 0) return PBSGPU_OK;
+    // record cells: a round takes a contiguous (modulo the ring) range; wait while older rounds still own what the
+    // largest possible round would overwrite (only a caller that never polls gets here)
+    {
+        const uint64_t oldest = r->rounds.empty() ? r->cell_cursor : r->rounds.front().cell_base;
+        if (r->cell_cursor + r->rec_cap - oldest > r->ncells) return PBSGPU_OK;
+    }
+    pbsk::RingPage *pg = r->in_pages((uint32_t)in);
+    pbsk::RingSeg *sg = r->in_segs((uint32_t)in);
+    uint32_t np = 0, ns = 0;
+    uint64_t cells_needed = 0, new_bytes = 0;
+    RoundInfo ri;
+    const uint32_t minsz = std::min(e->effmin, e->cfg.min);
+    for (uint32_t si = 0; si < r->slots.size() && np < r->round_pages; ++si) {
+        StreamSlot &s = r->slots[si];
+        if (!s.open || (s.ready.empty() && !s.zero_final)) continue;
+        pbsk::RingSeg g{};
+        g.slot = si;
+        g.first_page = np;
+        g.reset = s.fresh ? 1u : 0u;
+        uint64_t end = s.bytes_enqueued;
+        uint32_t take = 0;
+        while (!s.ready.empty() && take < kPagesPerStreamRound && np < r->round_pages) {
+            const PageReq &q = s.ready.front();
+            pbsk::RingPage p{};
+            p.phys = q.phys;
+            p.phys_off = (uint64_t)q.phys * r->stride + 128u;
+            p.logical = ((uint64_t)si << 40) | (q.k * r->page_bytes);
+            p.valid = q.valid;
+            p.slot = si;
+            p.seg = ns;
+            p.do_fill = q.do_fill ? 1u : 0u;
+            p.fill_seed = q.seed;
+            p.fill_off = q.fill_off;
+            p.fill_kind = q.kind;
+            pg[np++] = p;
+            ri.phys.push_back(q.phys);
+            end += q.valid;
+            new_bytes += q.valid;
+            if (q.final) g.final = 1;
+            s.ready.pop_front();
+            ++take;
+        }
+        if (s.zero_final && s.ready.empty()) {
+            g.final = 1;
+            s.zero_final = false;
+        }
+        g.npages = take;
+        g.new_end = end;
+        s.bytes_enqueued = end;
+        s.fresh = false;
+        if (g.final) {
+            s.final_enqueued = true;
+            ri.finals.push_back(si);
+        }
+        cells_needed += ((uint64_t)take * r->page_bytes + e->cfg.max) / minsz + 2;
+        sg[ns++] = g;
+    }
+    if (ns == 0) return PBSGPU_OK;
+    if (cells_needed > r->rec_cap) cells_needed = r->rec_cap;  // (the bound above is never larger: rec_cap is the same formula for a full round)
+    ri.cell_base = r->cell_cursor;
+    ri.cell_cap = (uint32_t)cells_needed;
+    r->cell_cursor += cells_needed;
+    uint8_t *cells = r->cells.as<uint8_t>();
+    for (uint64_t i = 0; i < cells_needed; ++i)
+        std::memset(cells + (size_t)((ri.cell_base + i) & (r->ncells - 1)) * 64, 0, 64);
+    ri.seq = r->next_seq++;
+    ri.input = (uint32_t)in;
+    pbsk::RingRoundStatus *hs = r->in_status((uint32_t)in);
+    hs->seq = 0;
+    std::atomic_thread_fence(std::memory_order_release);
+
+    pbsk::RingRound rr{};
+    rr.arena = r->arena.as<uint8_t>();
+    rr.page_bytes = (uint32_t)r->page_bytes;
+    rr.stride = (uint32_t)r->stride;
+    rr.tile_bytes = r->tile_bytes;
+    rr.tpp = r->tpp;
+    rr.effmin = e->effmin;
+    rr.cmin = e->cfg.min;
+    rr.maxsz = e->cfg.max;
+    rr.cap = r->cap;
+    rr.thr = e->thr;
+    rr.table_rot = e->d_table_rot;
+    rr.pages = pg;
+    rr.npages = np;
+    rr.segs_in = sg;
+    rr.nseg = ns;
+    rr.seq = ri.seq;
+    rr.cell_base = (uint32_t)(ri.cell_base & (r->ncells - 1));
+    rr.cell_cap = ri.cell_cap;
+    rr.cell_mask = r->ncells - 1;
+    rr.scan_blocks = (uint32_t)std::max(1, e->num_cus - (int)r->sha_cus);
+    rr.status = hs;
+    rr.streams = r->streams.as<pbsk::RingStreamState>();
+    rr.q = r->source();
+    rr.desc_w = r->desc.as<uint4>();
+    rr.scalars = r->scalars.as<uint32_t>();
+    rr.tile_cnt = r->tile_cnt.as<uint32_t>();
+    rr.tile_off = r->tile_off.as<uint32_t>();
+    rr.tile_slots = r->tile_slots.as<uint32_t>();
+    rr.scan_tmp = r->scan_tmp.as<uint32_t>();
+    rr.dense = r->dense.as<uint64_t>();
+    rr.dense_cap = r->dense_cap;
+    rr.segs = r->segs.as<pbsgpu_segment>();
+    rr.seg_cnt = r->seg_cnt.as<uint32_t>();
+    rr.seg_off = r->seg_off.as<uint32_t>();
+    rr.recs = r->recs.as<pbsgpu_record>();
+    rr.rec_cap = r->rec_cap;
+    rr.seg_newc = r->seg_newc.as<uint64_t>();
+    rr.seg_open = r->seg_open.as<uint32_t>();
+    CHK(ring_start_service(r));
+    HIPCHK(pbsk::launch_ring_round(rr, e->num_cus, r->cs));
+    r->input_busy[in] = true;
+    r->rounds.push_back(std::move(ri));
+    r->st.rounds++;
+    r->st.bytes_enqueued += new_bytes;
+    r->st.pages_enqueued += np;
+    *did = true;
+    return PBSGPU_OK;
+}
+
+int ring_take_page(pbsgpu_ring *r, uint32_t *phys) {
+    if (r->free_pages.empty()) ring_reap_free(r);
+    if (r->free_pages.empty()) return PBSGPU_E_BUSY;
+    *phys = r->free_pages.back();
+    r->free_pages.pop_back();
+    return PBSGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_ring **out) {
+    if (!e || !out) return PBSGPU_E_INVALID;
+    *out = nullptr;
+    CHK(set_device(e));
+    pbsgpu_ring_options o{};
+    if (opt) o = *opt;
+    pbsgpu_ring *r = new (std::nothrow) pbsgpu_ring();
+    if (!r) return PBSGPU_E_NOMEM;
+    engine_ref(e);
+    r->eng = e;
+    int st = [&]() -> int {
+        // page geometry: a whole number of scan tiles, >= the largest chunk (so a chunk touches at most two pages)
+        const uint32_t big = 64u * 34u * 128u, small = 64u * 4u * 128u;
+        uint64_t page = o.page_bytes;
+        if (page == 0) {
+            const uint32_t tile = e->cfg.max >= (1u << 20) ? big : small;
+            page = ((uint64_t)e->cfg.max + tile - 1) / tile * tile;
+            if (page < 2ull * tile && tile == small) page = 2ull * tile;
+        }
+        if (page % big == 0) r->tile_bytes = big;
+        else if (page % small == 0) r->tile_bytes = small;
+        else return PBSGPU_E_INVALID;
+        if (page < e->cfg.max || page >= (1ull << 31)) return PBSGPU_E_INVALID;
+        r->page_bytes = page;
+        r->tpp = (uint32_t)(page / r->tile_bytes);
+        r->stride = page + 256;
+        uint64_t arena_bytes = o.arena_bytes;
+        if (arena_bytes == 0) {
+            size_t fr = 0, tot = 0;
+            HIPCHK(hipMemGetInfo(&fr, &tot));
+            arena_bytes = fr > (12ull << 30) ? fr - (8ull << 30) : fr / 2;
+        }
+        r->npages = (uint32_t)std::min<uint64_t>(arena_bytes / r->stride, 65534);
+        if (r->npages < 4) return PBSGPU_E_INVALID;
+        r->max_streams = o.max_streams ? o.max_streams : 64;
+        if (r->max_streams > 4096) return PBSGPU_E_INVALID;
+        int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - 48);
+        if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
+        r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1));
+        r->round_pages = o.round_pages ? o.round_pages : 256;
+        if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
+        r->round_pages = std::min(r->round_pages, r->npages);
+        // candidate slots per scan tile: twice the batch path's default for this tile size
+        const double lambda = 3.0 * r->tile_bytes / ((double)e->cfg.mask + 1.0);
+        uint32_t capv = 8;
+        while (capv < 4.0 * lambda + 16.0) capv <<= 1;
+        r->cap = std::min<uint32_t>(capv * 2, r->tile_bytes);
+        const uint64_t ntiles = (uint64_t)r->round_pages * r->tpp;
+        if (ntiles * r->cap >= (1ull << 32)) return PBSGPU_E_DENSITY;
+        const uint32_t minsz = std::min(e->effmin, e->cfg.min);
+        r->dense_cap = ntiles * r->cap;
+        r->rec_cap = ((uint64_t)r->round_pages * r->page_bytes + (uint64_t)r->max_streams * e->cfg.max) / minsz +
+                     4ull * r->max_streams + 64;
+        const uint64_t resident_chunks = (uint64_t)r->npages * r->page_bytes / minsz + 2ull * r->npages + r->rec_cap;
+        r->qslots = pow2_at_least(2 * resident_chunks + 4096);
+        r->ncells = pow2_at_least(4 * resident_chunks + 4 * r->rec_cap);
+        r->nfree = pow2_at_least(4ull * r->npages + 64);
+
+        CHK(r->arena.ensure((size_t)r->npages * r->stride + 512));
+        CHK(r->ctl.ensure(256));
+        CHK(r->streams.ensure((size_t)r->max_streams * sizeof(pbsk::RingStreamState)));
+        CHK(r->pending.ensure((size_t)r->npages * 4 + 64));
+        CHK(r->desc.ensure((size_t)r->qslots * 32));
+        CHK(r->scalars.ensure(pbsk::kRsCount * 4 + 64));
+        CHK(r->tile_cnt.ensure((size_t)ntiles * 4 + 16));
+        CHK(r->tile_off.ensure((size_t)ntiles * 4 + 16));
+        CHK(r->tile_slots.ensure((size_t)ntiles * r->cap * 4 + 16));
+        CHK(r->dense.ensure((size_t)r->dense_cap * 8 + 16));
+        CHK(r->scan_tmp.ensure(pbsk::scan_tmp_words(std::max<uint64_t>(ntiles, r->max_streams)) * 4 + 64));
+        CHK(r->segs.ensure((size_t)r->max_streams * sizeof(pbsgpu_segment)));
+        CHK(r->seg_cnt.ensure((size_t)r->max_streams * 4 + 16));
+        CHK(r->seg_off.ensure((size_t)r->max_streams * 4 + 16));
+        CHK(r->seg_newc.ensure((size_t)r->max_streams * 8 + 16));
+        CHK(r->seg_open.ensure((size_t)r->max_streams * 4 + 16));
+        CHK(r->recs.ensure((size_t)r->rec_cap * sizeof(pbsgpu_record) + 64));
+        HIPCHK(hipMemset(r->ctl.p, 0, 256));
+        HIPCHK(hipMemset(r->streams.p, 0, (size_t)r->max_streams * sizeof(pbsk::RingStreamState)));
+        HIPCHK(hipMemset(r->pending.p, 0, (size_t)r->npages * 4 + 64));
+        HIPCHK(hipMemset(r->scalars.p, 0, pbsk::kRsCount * 4 + 64));
+        CHK(r->cells.ensure((size_t)r->ncells * 64));
+        CHK(r->free_fifo.ensure((size_t)r->nfree * 8));
+        std::memset(r->free_fifo.p, 0, (size_t)r->nfree * 8);
+        r->in_pages_off = 0;
+        r->in_segs_off = ((size_t)r->round_pages * sizeof(pbsk::RingPage) + 63) & ~(size_t)63;
+        r->in_status_off = (r->in_segs_off + (size_t)r->max_streams * sizeof(pbsk::RingSeg) + 63) & ~(size_t)63;
+        r->input_stride = r->in_status_off + 64;
+        CHK(r->inputs.ensure(r->input_stride * kInputs));
+        std::memset(r->inputs.p, 0, r->input_stride * kInputs);
+        HIPCHK(hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking));
+        // the service must never share a hardware queue with a stream that enqueues behind it (packets of one queue
+        // run in order: work queued behind a kernel that only ends on request would never start). HIP keeps one queue
+        // pool per priority: the service gets the highest priority to itself.
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&r->ss, hipStreamNonBlocking, hi));
+        HIPCHK(hipEventCreateWithFlags(&r->ev_reset, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&r->ev_svc0));
+        HIPCHK(hipEventCreate(&r->ev_svc1));
+        r->slots.resize(r->max_streams);
+        r->free_pages.reserve(r->npages);
+        for (uint32_t p = r->npages; p-- > 0;) r->free_pages.push_back(p);  // page 0 is handed out first
+        r->st.pages_total = r->npages;
+        r->st.page_bytes = r->page_bytes;
+        r->st.sha_cus = r->sha_cus;
+        return PBSGPU_OK;
+    }();
+    if (st != PBSGPU_OK) {
+        pbsgpu_ring_destroy(r);
+        return st;
+    }
+    *out = r;
+    return PBSGPU_OK;
+}
+
+// Stop the SHA service behind everything enqueued so far and wait until the device holds no ring work: every chunk of
+// every enqueued round is hashed, the persistent kernel has ended (hipDeviceSynchronize / hipFree can return again).
+// The next pump starts the service again.
+int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
+    if (!r) return PBSGPU_E_INVALID;
+    CHK(set_device(r->eng));
+    if (r->service_running) {
+        HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
+        HIPCHK(hipStreamSynchronize(r->cs));
+        HIPCHK(hipStreamSynchronize(r->ss));
+        r->service_running = false;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r->ev_svc0, r->ev_svc1) == hipSuccess) {
+            r->st.service_ms_last = ms;
+            r->st.service_ms_total += ms;
+        } else {
+            (void)hipGetLastError();
+        }
+        r->st.service_bytes_last = r->st.bytes_enqueued - r->svc_bytes0;
+    } else {
+        HIPCHK(hipStreamSynchronize(r->cs));
+    }
+    ring_reap_free(r);
+    ring_reap_rounds(r);
+    return r->error;
+}
+
+void pbsgpu_ring_destroy(pbsgpu_ring *r) {
+    if (!r) return;
+    pbsgpu_engine *e = r->eng;
+    if (e) {
+        (void)hipSetDevice(e->device);
+        if (r->cs && r->ss) (void)pbsgpu_ring_quiesce(r);
+        if (r->ss) (void)hipStreamDestroy(r->ss);
+        if (r->cs) (void)hipStreamDestroy(r->cs);
+        for (hipEvent_t ev : {r->ev_reset, r->ev_svc0, r->ev_svc1})
+            if (ev) (void)hipEventDestroy(ev);
+        for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->scalars, &r->tile_cnt, &r->tile_off,
+                          &r->tile_slots, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
+                          &r->seg_open})
+            b->release();
+        r->cells.release();
+        r->free_fifo.release();
+        r->inputs.release();
+    }
+    delete r;
+    if (e) engine_unref(e);
+}
+
+int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
+    if (!r || !stream) return PBSGPU_E_INVALID;
+    for (uint32_t i = 0; i < r->slots.size(); ++i)
+        if (!r->slots[i].open) {
+            r->slots[i] = StreamSlot{};
+            r->slots[i].open = true;
+            *stream = i;
+            r->st.streams_opened++;
+            return PBSGPU_OK;
+        }
+    return PBSGPU_E_BUSY;
+}
+
+int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
+    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    StreamSlot &s = r->slots[stream];
+    if (!s.final_done || !s.cells.empty()) return PBSGPU_E_STATE;  // finish it and poll its records first
+    s.open = false;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_ring_reserve(pbsgpu_ring *r, uint32_t stream, void **dptr, uint64_t *cap) {
+    if (!r || !dptr || !cap || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    StreamSlot &s = r->slots[stream];
+    if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
+    if (r->error != PBSGPU_OK) return r->error;
+    uint32_t phys = 0;
+    CHK(ring_take_page(r, &phys));
+    s.reserved = phys;
+    *dptr = r->arena.as<uint8_t>() + (uint64_t)phys * r->stride + 128u;
+    *cap = r->page_bytes;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_ring_commit(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final) {
+    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    StreamSlot &s = r->slots[stream];
+    if (s.final_committed) return PBSGPU_E_STATE;
+    if (nbytes > r->page_bytes || (nbytes != r->page_bytes && !final)) return PBSGPU_E_INVALID;  // only a stream's last page is short
+    if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;
+    if (nbytes == 0) {
+        if (s.reserved >= 0) {  // nothing written: the page goes back
+            r->free_pages.push_back((uint32_t)s.reserved);
+            s.reserved = -1;
+        }
+        s.zero_final = true;
+        s.final_committed = true;
+        return PBSGPU_OK;
+    }
+    if (s.reserved < 0) return PBSGPU_E_STATE;
+    PageReq q;
+    q.phys = (uint32_t)s.reserved;
+    q.k = s.next_k++;
+    q.valid = (uint32_t)nbytes;
+    q.final = final != 0;
+    s.ready.push_back(q);
+    s.reserved = -1;
+    s.bytes_committed += nbytes;
+    if (final) s.final_committed = true;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, int final,
+                     uint64_t *taken) {
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open || kind > 3) return PBSGPU_E_INVALID;
+    StreamSlot &s = r->slots[stream];
+    *taken = 0;
+    if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
+    if (r->error != PBSGPU_OK) return r->error;
+    if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;
+    if (nbytes == 0) {
+        if (final) {
+            s.zero_final = true;
+            s.final_committed = true;
+        }
+        return PBSGPU_OK;
+    }
+    while (*taken < nbytes) {
+        const uint64_t n = std::min<uint64_t>(r->page_bytes, nbytes - *taken);
+        const bool last = (*taken + n == nbytes);
+        if (n < r->page_bytes && !(last && final)) break;  // a short page only as the stream's last one
+        uint32_t phys = 0;
+        if (ring_take_page(r, &phys) != PBSGPU_OK) break;   // no page free right now: the caller pumps and retries
+        PageReq q;
+        q.phys = phys;
+        q.k = s.next_k++;
+        q.valid = (uint32_t)n;
+        q.final = last && final;
+        q.do_fill = true;
+        q.seed = seed;
+        q.kind = kind;
+        q.fill_off = s.bytes_committed;  // the generator's stream offset = the page's offset in its stream
+        s.ready.push_back(q);
+        s.bytes_committed += n;
+        *taken += n;
+        if (q.final) s.final_committed = true;
+    }
+    return PBSGPU_OK;
+}
+
+int pbsgpu_ring_pump(pbsgpu_ring *r) {
+    if (!r) return PBSGPU_E_INVALID;
+    CHK(set_device(r->eng));
+    ring_reap_free(r);
+    ring_reap_rounds(r);
+    for (int i = 0; i < 4; ++i) {
+        bool did = false;
+        CHK(ring_enqueue_round(r, &did));
+        if (!did) break;
+    }
+    return r->error;
+}
+
+int pbsgpu_ring_poll(pbsgpu_ring *r, uint32_t stream, pbsgpu_record *out, uint64_t cap, uint64_t *n, int *finished) {
+    if (!r || !n || stream >= r->slots.size() || !r->slots[stream].open || (!out && cap)) return PBSGPU_E_INVALID;
+    StreamSlot &s = r->slots[stream];
+    ring_reap_rounds(r);
+    *n = 0;
+    const uint8_t *cells = r->cells.as<uint8_t>();
+    while (*n < cap && !s.cells.empty()) {
+        const CellRef cr = s.cells.front();
+        const uint8_t *c = cells + (size_t)cr.cell * 64;
+        const volatile uint32_t *flag = reinterpret_cast<const volatile uint32_t *>(c + 48);
+        if (*flag != 1u) break;  // its chunk is still being hashed: records come out in stream order
+        std::atomic_thread_fence(std::memory_order_acquire);
+        pbsgpu_record rec;
+        std::memcpy(&rec, c, sizeof(rec));
+        rec.segment = stream;
+        out[(*n)++] = rec;
+        s.cells.pop_front();
+        s.records_out++;
+        for (auto &ri : r->rounds)
+            if (ri.seq == cr.round_idx) {
+                ri.live_cells--;
+                break;
+            }
+    }
+    while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
+    if (finished) *finished = (s.final_done && s.cells.empty()) ? 1 : 0;
+    return r->error;
+}
+
+int pbsgpu_ring_get_stats(pbsgpu_ring *r, pbsgpu_ring_stats *out) {
+    if (!r || !out) return PBSGPU_E_INVALID;
+    ring_reap_free(r);
+    r->st.pages_free = (uint32_t)r->free_pages.size();
+    r->st.rounds_in_flight = 0;
+    for (auto &ri : r->rounds) r->st.rounds_in_flight += ri.reaped ? 0 : 1;
+    *out = r->st;
+    return PBSGPU_OK;
+}
+
+}  // extern "C"

@@ -425,3 +425,114 @@ class Chunker:
             self.close()
         except Exception:
             pass
+
+
+class PageRing:
+    """Many payload streams through one device arena with page-granular memory release and the persistent SHA-256
+    service (pbsgpu_ring_*, include/pbsgpu.h): the chunk loop behind ``WriteEntryReader`` for several archives at once
+    (internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836) when bytes are in device memory."""
+
+    def __init__(self, eng: Engine, arena_bytes: int = 0, page_bytes: int = 0, max_streams: int = 0, sha_cus: int = 0,
+                 round_pages: int = 0):
+        self._eng = eng
+        self._L = eng._L
+        opt = _lib.RingOptions(int(arena_bytes), int(page_bytes), int(max_streams), int(sha_cus), int(round_pages), 0)
+        h = C.c_void_p()
+        check(self._L.pbsgpu_ring_create(eng._h, C.byref(opt), C.byref(h)), "ring_create")
+        self._h = h
+        self.page_bytes = self.stats()["page_bytes"]
+
+    def open(self) -> int:
+        s = C.c_uint32()
+        check(self._L.pbsgpu_ring_open(self._h, C.byref(s)), "ring_open")
+        return s.value
+
+    def reserve(self, stream: int):
+        """(device pointer, capacity) of the stream's next page, or None when no page is free right now."""
+        p, cap = C.c_void_p(), C.c_uint64()
+        st = self._L.pbsgpu_ring_reserve(self._h, stream, C.byref(p), C.byref(cap))
+        if st == _lib.E_BUSY:
+            return None
+        check(st, "ring_reserve")
+        return p.value, cap.value
+
+    def commit(self, stream: int, nbytes: int, final: bool = False) -> None:
+        check(self._L.pbsgpu_ring_commit(self._h, stream, int(nbytes), int(final)), "ring_commit")
+
+    def fill(self, stream: int, seed: int, kind: int, nbytes: int, final: bool = False) -> int:
+        """Synthetic producer: bytes accepted (whole pages that were free); call again with the rest after pump()."""
+        t = C.c_uint64()
+        check(self._L.pbsgpu_ring_fill(self._h, stream, int(seed), int(kind), int(nbytes), int(final), C.byref(t)),
+              "ring_fill")
+        return t.value
+
+    def pump(self) -> None:
+        check(self._L.pbsgpu_ring_pump(self._h), "ring_pump")
+
+    def poll(self, stream: int, cap: int = 4096):
+        """(records, finished) — records in stream order, `end` = absolute stream offset."""
+        out = np.zeros(cap, dtype=RECORD_DTYPE)
+        n, fin = C.c_uint64(), C.c_int()
+        check(self._L.pbsgpu_ring_poll(self._h, stream, out.ctypes.data, cap, C.byref(n), C.byref(fin)), "ring_poll")
+        return out[: n.value], bool(fin.value)
+
+    def close_stream(self, stream: int) -> None:
+        check(self._L.pbsgpu_ring_close(self._h, stream), "ring_close")
+
+    def quiesce(self) -> None:
+        check(self._L.pbsgpu_ring_quiesce(self._h), "ring_quiesce")
+
+    def stats(self) -> dict:
+        st = _lib.RingStats()
+        check(self._L.pbsgpu_ring_get_stats(self._h, C.byref(st)), "ring_get_stats")
+        return {k: getattr(st, k) for k, _ in _lib.RingStats._fields_}
+
+    def ingest_synthetic(self, jobs, timeout_s: float = 120.0, concurrent: int | None = None):
+        """Drive whole synthetic streams through the ring: jobs = [(seed, kind, nbytes)]; returns one record array per
+        job. At most `concurrent` (default: all slots) streams are open at a time."""
+        import time
+
+        res = [[] for _ in jobs]
+        todo = list(range(len(jobs)))
+        active = {}                                   # stream id -> [job index, bytes left]
+        limit = concurrent or len(jobs)
+        t0 = time.perf_counter()
+        while todo or active:
+            while todo and len(active) < limit:
+                try:
+                    sid = self.open()
+                except _lib.PbsGpuError as exc:
+                    if exc.status != _lib.E_BUSY:
+                        raise
+                    break
+                j = todo.pop(0)
+                active[sid] = [j, int(jobs[j][2]), False]
+            for sid, a in active.items():
+                j, left, sent_final = a
+                if not sent_final:
+                    got = self.fill(sid, jobs[j][0], jobs[j][1], left, final=True)
+                    a[1] -= got
+                    if a[1] == 0:
+                        a[2] = True
+            self.pump()
+            for sid in list(active):
+                recs, fin = self.poll(sid)
+                if recs.size:
+                    res[active[sid][0]].append(recs.copy())
+                if fin:
+                    self.close_stream(sid)
+                    del active[sid]
+            if time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError(f"ring ingest did not finish in {timeout_s} s: {self.stats()}")
+        return [np.concatenate(r) if r else np.zeros(0, dtype=RECORD_DTYPE) for r in res]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pbsgpu_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
