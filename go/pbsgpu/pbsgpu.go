@@ -607,3 +607,158 @@ func (e *Engine) XXH3Files(buf []byte, offsets, lengths []uint64) ([]uint64, err
 	runtime.KeepAlive(buf)
 	return out, err
 }
+
+// ---- page ring: several archives at once, page-granular memory release ---------------------------------------------
+
+// Ring runs the chunk loop for SEVERAL payload streams through one device arena (pbsgpu_ring_*): memory is given
+// back page by page as soon as the chunks touching a page have been read by the persistent SHA-256 service, not when a
+// whole batch has been hashed. One goroutine drives a Ring (like one goroutine owns a writer,
+// internal/tapeio/converter.go:672-680); bytes reach a stream's pages through Reserve/Commit (a device pointer for
+// a DMA, a peer GPU or a kernel) or WriteHost.
+type Ring struct {
+	h   *C.pbsgpu_ring
+	eng *Engine
+}
+
+// RingOptions mirrors pbsgpu_ring_options; zero values select the library defaults.
+type RingOptions struct {
+	ArenaBytes, PageBytes         uint64
+	MaxStreams, ShaCUs, RoundPages uint32
+}
+
+func (e *Engine) NewRing(o RingOptions) (*Ring, error) {
+	defer runtime.KeepAlive(e)
+	co := C.pbsgpu_ring_options{arena_bytes: C.uint64_t(o.ArenaBytes), page_bytes: C.uint64_t(o.PageBytes),
+		max_streams: C.uint32_t(o.MaxStreams), sha_cus: C.uint32_t(o.ShaCUs), round_pages: C.uint32_t(o.RoundPages)}
+	r := &Ring{eng: e}
+	if err := check(C.pbsgpu_ring_create(e.h, &co, &r.h), "ring_create"); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(r, func(r *Ring) { r.Close() })
+	return r, nil
+}
+
+// Open starts a new stream (fresh chunker state); ErrBusy when MaxStreams are open.
+func (r *Ring) Open() (uint32, error) {
+	defer runtime.KeepAlive(r)
+	var s C.uint32_t
+	st := C.pbsgpu_ring_open(r.h, &s)
+	if st == C.PBSGPU_E_BUSY {
+		return 0, ErrBusy
+	}
+	return uint32(s), check(st, "ring_open")
+}
+
+// Reserve returns the device address and capacity of the stream's next page; ErrBusy when no page is free right now.
+func (r *Ring) Reserve(stream uint32) (dptr uintptr, capacity uint64, err error) {
+	defer runtime.KeepAlive(r)
+	var p unsafe.Pointer
+	var c C.uint64_t
+	st := C.pbsgpu_ring_reserve(r.h, C.uint32_t(stream), &p, &c)
+	if st == C.PBSGPU_E_BUSY {
+		return 0, 0, ErrBusy
+	}
+	return uintptr(p), uint64(c), check(st, "ring_reserve")
+}
+
+// Commit hands the first nbytes of the reserved page to the ring; final ends the stream.
+func (r *Ring) Commit(stream uint32, nbytes uint64, final bool) error {
+	defer runtime.KeepAlive(r)
+	f := C.int(0)
+	if final {
+		f = 1
+	}
+	return check(C.pbsgpu_ring_commit(r.h, C.uint32_t(stream), C.uint64_t(nbytes), f), "ring_commit")
+}
+
+// FillSynthetic is the benchmark producer (pbsgpu_ring_fill); returns the bytes accepted.
+func (r *Ring) FillSynthetic(stream uint32, seed uint64, kind uint32, nbytes uint64, final bool) (uint64, error) {
+	defer runtime.KeepAlive(r)
+	f := C.int(0)
+	if final {
+		f = 1
+	}
+	var taken C.uint64_t
+	err := check(C.pbsgpu_ring_fill(r.h, C.uint32_t(stream), C.uint64_t(seed), C.uint32_t(kind), C.uint64_t(nbytes), f, &taken),
+		"ring_fill")
+	return uint64(taken), err
+}
+
+// Pump enqueues the committed pages as cut rounds and collects finished rounds and freed pages; never blocks.
+func (r *Ring) Pump() error {
+	defer runtime.KeepAlive(r)
+	return check(C.pbsgpu_ring_pump(r.h), "ring_pump")
+}
+
+// Poll returns up to max finished (end, digest) entries of the stream in stream order; done once the stream has ended
+// and every entry has been handed out.
+func (r *Ring) Poll(stream uint32, max int) (recs []ChunkInfo, done bool, err error) {
+	defer runtime.KeepAlive(r)
+	if max <= 0 {
+		return nil, false, errors.New("pbsgpu: Poll(max <= 0)")
+	}
+	buf := make([]C.pbsgpu_record, max)
+	var n C.uint64_t
+	var fin C.int
+	if err = check(C.pbsgpu_ring_poll(r.h, C.uint32_t(stream), &buf[0], C.uint64_t(max), &n, &fin), "ring_poll"); err != nil {
+		return nil, false, err
+	}
+	return fromRecords(buf, int(n)), fin != 0, nil
+}
+
+// CloseStream releases a finished, fully polled stream's slot.
+func (r *Ring) CloseStream(stream uint32) error {
+	defer runtime.KeepAlive(r)
+	return check(C.pbsgpu_ring_close(r.h, C.uint32_t(stream)), "ring_close")
+}
+
+// Quiesce waits until everything enqueued is hashed and stops the service kernel; the next Pump restarts it.
+func (r *Ring) Quiesce() error {
+	defer runtime.KeepAlive(r)
+	return check(C.pbsgpu_ring_quiesce(r.h), "ring_quiesce")
+}
+
+// RingStats mirrors the counters of pbsgpu_ring_stats a caller sizes its feed with.
+type RingStats struct {
+	PageBytes, BytesEnqueued, Chunks uint64
+	PagesTotal, PagesFree, Rounds    uint32
+	ServiceMsLast                    float64
+}
+
+func (r *Ring) Stats() (RingStats, error) {
+	defer runtime.KeepAlive(r)
+	var st C.pbsgpu_ring_stats
+	if err := check(C.pbsgpu_ring_get_stats(r.h, &st), "ring_get_stats"); err != nil {
+		return RingStats{}, err
+	}
+	return RingStats{uint64(st.page_bytes), uint64(st.bytes_enqueued), uint64(st.chunks), uint32(st.pages_total),
+		uint32(st.pages_free), uint32(st.rounds), float64(st.service_ms_last)}, nil
+}
+
+func (r *Ring) Close() {
+	runtime.SetFinalizer(r, nil)
+	if r.h != nil {
+		C.pbsgpu_ring_destroy(r.h)
+		r.h = nil
+	}
+	r.eng = nil
+}
+
+// DedupDevice flags duplicates among n records that already are in device memory (the receive buffer of an RCCL
+// all-gather): the digest-set reduce without a host round trip of the set.
+func (e *Engine) DedupDevice(drecs uintptr, n uint64) ([]bool, DedupStats, error) {
+	defer runtime.KeepAlive(e)
+	if n == 0 {
+		return nil, DedupStats{}, nil
+	}
+	dup := make([]C.uint8_t, n)
+	var st C.pbsgpu_dedup_stats
+	if err := check(C.pbsgpu_dedup_device(e.h, unsafe.Pointer(drecs), C.uint64_t(n), &dup[0], &st), "dedup_device"); err != nil {
+		return nil, DedupStats{}, err
+	}
+	out := make([]bool, n)
+	for i := range out {
+		out[i] = dup[i] != 0
+	}
+	return out, DedupStats{uint64(st.nrecords), uint64(st.nunique), uint64(st.total_bytes), uint64(st.unique_bytes)}, nil
+}

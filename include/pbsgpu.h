@@ -142,6 +142,16 @@ int pbsgpu_submit_device_suggested(pbsgpu_engine *eng, const void *dptr, uint64_
 int pbsgpu_submit_host_suggested(pbsgpu_engine *eng, const void *hptr, uint64_t nbytes, const pbsgpu_segment *segs,
                                  uint32_t nseg, const uint64_t *suggested, const uint32_t *suggested_index,
                                  uint64_t *ticket);
+/* Which READER the suggested-boundary rule emulates. Upstream's payload chunker looks at its pending boundary once per
+ * `scan` call, before the hash scan of the bytes that call brings: a boundary inside the call's buffer is cut at even
+ * if a hash boundary lies EARLIER in the same buffer, while a hash boundary found by an earlier call wins. The result
+ * therefore depends on how many bytes one call sees. feed_bytes = 1 (the default): byte-serial feed, the
+ * feed-independent limit (the earlier position wins); N > 1: every call sees N bytes; 0: one call sees everything
+ * that is left. absolute_grid = 0: the buffer grid restarts at every cut (oracle_chunk_stream_suggested's feeding
+ * loop); 1: buffers end at multiples of feed_bytes from the stream start (a reader appending fixed-size reads, as a
+ * Go io.Reader loop with a fixed buffer does: internal/agent/verification/handler.go:15-20 uses 256 KiB). Applies to
+ * everything enqueued afterwards. Whether github.com/pbs-plus/pxar cuts at suggested boundaries at all is open. */
+int pbsgpu_engine_set_suggested_feed(pbsgpu_engine *eng, uint64_t feed_bytes, int absolute_grid);
 /* Block until the ticket's work is done; report its record count. */
 int pbsgpu_wait(pbsgpu_engine *eng, uint64_t ticket, uint64_t *nrecords);
 /* Non-blocking: *done = 1 when everything enqueued for the ticket has finished on the device (collect will not
@@ -269,7 +279,7 @@ typedef struct pbsgpu_ring_options {
     uint64_t arena_bytes;  /* device memory for pages; 0 = what is free minus 8 GiB */
     uint64_t page_bytes;   /* 0 = default: max chunk rounded up to whole scan tiles (16.2 MiB at avg 4 MiB) */
     uint32_t max_streams;  /* streams open at once; 0 = 64 */
-    uint32_t sha_cus;      /* CUs of the SHA-256 service; 0 = all but 48 (the rest runs the cut rounds) */
+    uint32_t sha_cus;      /* CUs of the SHA-256 service; 0 = three quarters of the chip (the rest runs the cut rounds) */
     uint32_t round_pages;  /* most pages one round cuts; 0 = 256 */
     uint32_t reserved;
 } pbsgpu_ring_options;
@@ -344,6 +354,10 @@ typedef struct pbsgpu_dedup_stats {
 } pbsgpu_dedup_stats;
 int pbsgpu_dedup_host(pbsgpu_engine *eng, const pbsgpu_record *recs, uint64_t n, uint8_t *dup /* n, may be NULL */,
                       pbsgpu_dedup_stats *stats);
+/* The same on records that already are in device memory (the receive buffer of the RCCL all-gather): the gathered set
+ * never takes a host round trip. `dup` (host, may be NULL) and `stats` as above. */
+int pbsgpu_dedup_device(pbsgpu_engine *eng, const void *drecs, uint64_t n, uint8_t *dup /* n, may be NULL */,
+                        pbsgpu_dedup_stats *stats);
 
 /* ---- dynamic index (.didx) encoding ------------------------------------------
  * On-disk form of the record list: datastore.NewDynamicIndexWriter(ctime)
@@ -404,7 +418,8 @@ int pbsgpu_reuse_should(const pbsgpu_record *idx, uint64_t n, uint64_t range_sta
 /* ---- synthetic corpus generator ----------------------------------------------
  * Fills device memory with the deterministic byte stream the benchmarks and
  * parity tests use (the oracle has the CPU twin). kind: 0 random, 1 zeros,
- * 2 repeating 4 KiB block, 3 random with ~30 % zero extents. `stream_off`
+ * 2 repeating 4 KiB block, 3 random with ~30 % zero extents, 4 random from a cheap ARX generator
+ * (two ChaCha quarter-rounds per 16-byte block; the page ring's refill). `stream_off`
  * and `dptr` must be 8-byte aligned. */
 int pbsgpu_fill_device(pbsgpu_engine *eng, void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed,
                        uint32_t kind);

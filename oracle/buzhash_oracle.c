@@ -227,12 +227,24 @@ size_t oracle_payload_chunker_scan(oracle_payload_chunker *p, const uint8_t *dat
  * an earlier hash cut wins over a later suggested boundary). */
 size_t oracle_chunk_stream_suggested(const oracle_config *cfg, const uint8_t *data, size_t len, const uint64_t *sugg,
                                      size_t nsugg, size_t feed, uint64_t *ends, size_t cap) {
+    return oracle_chunk_stream_suggested_grid(cfg, data, len, sugg, nsugg, feed, 0, ends, cap);
+}
+
+/* absolute != 0: the reader appends fixed reads of `feed` bytes to its buffer, so a scan call ends at the next multiple
+ * of `feed` from the STREAM start (after a cut the rest of the buffered read is scanned first) — the shape of a Go
+ * io.Reader loop with a fixed buffer; absolute == 0: `feed` bytes per call counted from the last cut. */
+size_t oracle_chunk_stream_suggested_grid(const oracle_config *cfg, const uint8_t *data, size_t len, const uint64_t *sugg,
+                                          size_t nsugg, size_t feed, int absolute, uint64_t *ends, size_t cap) {
     oracle_payload_chunker p;
     oracle_payload_chunker_init(&p, cfg, sugg, nsugg);
     size_t n = 0;
     uint64_t base = 0, pos = 0;
     while (pos < len) {
         size_t take = (feed == 0 || feed > len - pos) ? (size_t)(len - pos) : feed;
+        if (absolute && feed) {
+            const size_t to_grid = feed - (size_t)(pos % feed);
+            take = to_grid > len - pos ? (size_t)(len - pos) : to_grid;
+        }
         size_t k = oracle_payload_chunker_scan(&p, data + pos, take, base, (pos - base) + take);
         if (k == 0) {
             pos += take;
@@ -308,9 +320,28 @@ static inline uint64_t splitmix64(uint64_t seed, uint64_t idx) {
     return z ^ (z >> 31);
 }
 
+/* kind 4: 16-byte blocks from two ChaCha quarter-rounds over {block index, seed} — adds, xors and rotates only, ~1/3
+ * of splitmix64's issue slots on the GPU (64-bit multiplies run at quarter rate there). Statistically sound for this
+ * purpose: byte histogram chi^2 238 over 64 MiB, candidate and chunk counts at the nominal density (measured against
+ * splitmix64 data). Used where the generator runs inside a timed region (the page ring's refill). */
+static inline uint32_t rotl32g(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+static inline uint64_t chacha2_word(uint64_t widx, uint64_t seed) {
+    uint64_t q = widx >> 1;
+    uint32_t x0 = (uint32_t)q ^ 0x61707865u, x1 = (uint32_t)(q >> 32) ^ 0x3320646eu;
+    uint32_t x2 = (uint32_t)seed ^ 0x79622d32u, x3 = (uint32_t)(seed >> 32) ^ 0x6b206574u;
+    for (int r = 0; r < 2; ++r) {
+        x0 += x1; x3 = rotl32g(x3 ^ x0, 16);
+        x2 += x3; x1 = rotl32g(x1 ^ x2, 12);
+        x0 += x1; x3 = rotl32g(x3 ^ x0, 8);
+        x2 += x3; x1 = rotl32g(x1 ^ x2, 7);
+    }
+    return (widx & 1u) ? ((uint64_t)x3 << 32) | x2 : ((uint64_t)x1 << 32) | x0;
+}
+
 static inline uint64_t fill_word(uint64_t widx, uint64_t seed, uint32_t kind) {
     switch (kind) {
     case 0: return splitmix64(seed, widx);
+    case 4: return chacha2_word(widx, seed);
     case 1: return 0;
     case 2: return splitmix64(seed, widx & 511u); /* 4 KiB period */
     default: {

@@ -93,6 +93,8 @@ size_t oracle_payload_chunker_scan(oracle_payload_chunker *p, const uint8_t *dat
 /* one stream, `feed` bytes per scan call (0 = all that is left; 1 = byte-serial = the engine's definition) */
 size_t oracle_chunk_stream_suggested(const oracle_config *cfg, const uint8_t *data, size_t len, const uint64_t *sugg,
                                      size_t nsugg, size_t feed, uint64_t *ends, size_t cap);
+size_t oracle_chunk_stream_suggested_grid(const oracle_config *cfg, const uint8_t *data, size_t len, const uint64_t *sugg,
+                                          size_t nsugg, size_t feed, int absolute, uint64_t *ends, size_t cap);
 
 /* Raw candidates: every END offset e (64 <= e <= len) whose 64-byte window [e-64, e)
  * passes the break test (no min/max, no resets), ascending. Returns the count. */
@@ -142,7 +144,8 @@ size_t oracle_chunk_and_digest_suggested(const oracle_config *cfg, const uint8_t
 /* Deterministic synthetic byte generator shared with the engine's device fill
  * kernel (pbsgpu_fill): 8 bytes per counter via splitmix64(seed, index),
  * shaped by `kind`: 0 random, 1 zeros, 2 repeating 4 KiB block,
- * 3 random with ~30 % zero extents (64 KiB granules). `stream_off` is the
+ * 3 random with ~30 % zero extents (64 KiB granules), 4 random from two ChaCha
+ * quarter-rounds per 16-byte block (the cheap generator of the page ring's refill). `stream_off` is the
  * absolute byte offset of dst[0] in the synthetic stream (multiple of 8). */
 void oracle_fill(uint8_t *dst, uint64_t stream_off, uint64_t len, uint64_t seed, uint32_t kind);
 

@@ -87,6 +87,9 @@ def lib() -> C.CDLL:
         L.oracle_chunk_stream_suggested.argtypes = [C.POINTER(Config), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                     C.c_size_t, C.c_void_p, C.c_size_t]
         L.oracle_chunk_stream_suggested.restype = C.c_size_t
+        L.oracle_chunk_stream_suggested_grid.argtypes = [C.POINTER(Config), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                         C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.oracle_chunk_stream_suggested_grid.restype = C.c_size_t
         L.oracle_chunk_and_digest_suggested.argtypes = [C.POINTER(Config), C.c_void_p, C.POINTER(Segment), C.c_uint32,
                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.oracle_chunk_and_digest_suggested.restype = C.c_size_t
@@ -140,16 +143,17 @@ def chunk_stream(cfg: Config, data) -> np.ndarray:
     return ends[:n].copy()
 
 
-def chunk_stream_suggested(cfg: Config, data, suggested, feed: int = 1) -> np.ndarray:
+def chunk_stream_suggested(cfg: Config, data, suggested, feed: int = 1, absolute: bool = False) -> np.ndarray:
     """Chunk END offsets of `data` cut as one stream by the payload chunker (ChunkerImpl + suggested boundaries,
     absolute offsets in send order). feed = bytes handed to each scan call: 1 = byte-serial (the engine's
-    definition), 0 = the whole remaining buffer at once (upstream's second test loop)."""
+    default), 0 = the whole remaining buffer at once (upstream's second test loop), N = N bytes per call counted from
+    the last cut or — absolute — ending at multiples of N from the stream start."""
     a = _buf(data)
     sg = np.ascontiguousarray(suggested, dtype=np.uint64)
     cap = max(16, a.size // max(1, cfg.min) + 2 + sg.size)
     ends = np.empty(cap, dtype=np.uint64)
-    n = lib().oracle_chunk_stream_suggested(C.byref(cfg), a.ctypes.data, a.size, sg.ctypes.data if sg.size else None,
-                                            sg.size, feed, ends.ctypes.data, cap)
+    n = lib().oracle_chunk_stream_suggested_grid(C.byref(cfg), a.ctypes.data, a.size, sg.ctypes.data if sg.size else None,
+                                                 sg.size, feed, int(absolute), ends.ctypes.data, cap)
     assert n <= cap
     return ends[:n].copy()
 

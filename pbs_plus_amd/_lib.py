@@ -118,6 +118,7 @@ SYMBOLS = {
     "pbsgpu_engine_destroy": (None, [_P]),
     "pbsgpu_engine_config": (C.c_int, [_P, C.POINTER(Config)]),
     "pbsgpu_engine_trim": (C.c_int, [_P, _U64P]),
+    "pbsgpu_engine_set_suggested_feed": (C.c_int, [_P, C.c_uint64, C.c_int]),
     "pbsgpu_sha256_many_pays": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
     "pbsgpu_submit_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
     "pbsgpu_submit_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _U64P]),
@@ -166,6 +167,7 @@ SYMBOLS = {
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_dedup_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(DedupStats)]),
+    "pbsgpu_dedup_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(DedupStats)]),
     "pbsgpu_didx_size": (C.c_int, [C.c_uint64, _U64P]),
     "pbsgpu_didx_encode": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int64, _P, C.c_uint64]),
     "pbsgpu_didx_decode": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P, C.POINTER(C.c_int64), _P]),

@@ -202,6 +202,9 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
             sg.index = s.sugg_idx.as<uint32_t>();
         }
         sg.cmin = e->cfg.min;
+        sg.feed = e->sugg_feed.load(std::memory_order_relaxed);
+        sg.absolute = e->sugg_feed_abs.load(std::memory_order_relaxed);
+        sg.origin = s.sugg_origin;
     }
     // one long stream, no suggested boundaries: follow the cut chain by pointer doubling (one workgroup, ~20 rounds)
     // instead of walking it chunk by chunk on one wave (4.6 ms per 64 GiB, 11 ms next to SHA waves)
@@ -339,6 +342,7 @@ int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32
     }
     s.nseg = nseg;
     s.nsugg = 0;
+    s.sugg_origin = sg ? sg->origin : 0;
     if (sg && sg->offsets && sg->index) {
         if (sg->index[0] != 0) return PBSGPU_E_INVALID;
         for (uint32_t i = 0; i < nseg; ++i) {
@@ -711,6 +715,15 @@ int pbsgpu_sha256_many_pays(const pbsgpu_engine *e, uint32_t nfiles, uint32_t ho
     return PBSGPU_OK;
 }
 
+// Which reader the suggested-boundary rule emulates (see pbsgpu.h). Applies to *_suggested submits and
+// pbsgpu_stream_suggest cuts enqueued after the call.
+int pbsgpu_engine_set_suggested_feed(pbsgpu_engine *e, uint64_t feed_bytes, int absolute_grid) {
+    if (!e) return PBSGPU_E_INVALID;
+    e->sugg_feed.store(feed_bytes == 0 ? ~0ull : feed_bytes, std::memory_order_relaxed);
+    e->sugg_feed_abs.store(absolute_grid ? 1u : 0u, std::memory_order_relaxed);
+    return PBSGPU_OK;
+}
+
 int pbsgpu_engine_config(const pbsgpu_engine *e, pbsgpu_config *out) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = e->cfg;
@@ -996,7 +1009,7 @@ int pbsgpu_xxh3_many_host(pbsgpu_engine *e, const void *hptr, uint64_t nbytes, c
 
 int pbsgpu_fill_device(pbsgpu_engine *e, void *dptr, uint64_t stream_off, uint64_t nbytes, uint64_t seed,
                        uint32_t kind) {
-    if (!e || (!dptr && nbytes) || ((uintptr_t)dptr & 7u) || (stream_off & 7u) || kind > 3) return PBSGPU_E_INVALID;
+    if (!e || (!dptr && nbytes) || ((uintptr_t)dptr & 7u) || (stream_off & 7u) || kind > 4) return PBSGPU_E_INVALID;
     CHK(set_device(e));
     AuxLease lease(e);
     HIPCHK(pbsk::launch_fill(dptr, stream_off, nbytes, seed, kind, lease.s->stream));

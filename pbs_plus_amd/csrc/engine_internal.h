@@ -166,6 +166,7 @@ struct Slot {
     uint32_t cap = 0;
     uint64_t rec_cap = 0;
     uint64_t nsugg = 0;     // suggested offsets staged for this batch (0 = none)
+    uint64_t sugg_origin = 0;
     bool host_submit = false;
     uint32_t retries = 0;
     uint64_t nrec = 0, ncand = 0;
@@ -224,6 +225,9 @@ struct pbsgpu_engine {
     uint32_t bits = 0;     // mask == 2^bits - 1
     uint32_t thr = 0;      // break_min << (32 - bits)
     uint32_t effmin = 0;   // max(min, 65)
+    // reader buffer size the suggested-boundary rule emulates (pbsgpu_engine_set_suggested_feed): 1 = byte-serial
+    std::atomic<uint64_t> sugg_feed{1};
+    std::atomic<uint32_t> sugg_feed_abs{0};
     uint32_t *d_table_rot = nullptr;
     std::vector<std::unique_ptr<pbse::Slot>> slots;  // batch-ticket pool
     std::vector<std::unique_ptr<pbse::Slot>> aux;    // leased to synchronous helper calls
@@ -272,6 +276,7 @@ void engine_unref(pbsgpu_engine *e);  // frees the engine when the last referenc
 struct SuggestedHost {  // caller's suggested boundaries: offsets[index[s] .. index[s+1]) ascending, relative to segment s
     const uint64_t *offsets = nullptr;
     const uint32_t *index = nullptr;
+    uint64_t origin = 0;  // stream offset of the (single) segment's first byte: only the absolute feed grid needs it
 };
 
 int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint32_t cap,

@@ -73,6 +73,19 @@ struct Suggested {
     const uint64_t *offsets = nullptr;  // device
     const uint32_t *index = nullptr;    // device, nseg + 1 entries
     uint32_t cmin = 0;                  // the config's true min (a suggested cut needs chunk_size >= min, not >= 65)
+    // How many bytes one `scan` call of the reference's payload chunker sees (its reader's buffer): a suggested boundary
+    // that lies in the CURRENT buffer is taken without running the hash scan on that buffer, i.e. it pre-empts an earlier
+    // hash cut of the same buffer; a hash cut found in an earlier buffer still wins. feed <= 1 = byte-serial feed (the
+    // feed-independent limit: the earlier position wins); ~0 = the whole rest in one call. `absolute`: buffers end at
+    // multiples of `feed` from the STREAM start (a reader that appends fixed-size reads to its buffer; `origin` = stream
+    // offset of the segment start) instead of restarting at every cut (oracle_chunk_stream_suggested's feeding loop).
+    uint64_t feed = 1;
+    uint64_t origin = 0;
+    uint32_t absolute = 0;
+};
+struct SuggFeed {
+    uint64_t feed, origin;
+    uint32_t absolute;
 };
 
 // min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
@@ -200,7 +213,7 @@ struct RingSeg {
 };
 // Device-resident state of a stream slot.
 constexpr uint64_t kRingMaxStream = 1ull << 40;  // logical coordinates are (stream slot << 40) | offset
-constexpr uint32_t kRingPT = 32;       // page-table window per stream (open chunk <= 2 pages + new pages of one round)
+constexpr uint32_t kRingPT = 64;       // page-table window per stream (open chunk <= 2 pages + new pages of one round)
 struct RingStreamState {
     uint64_t c;            // start of the open chunk (logical offset in the stream)
     uint64_t end;          // bytes received so far
@@ -247,7 +260,9 @@ struct RingRound {
     uint32_t *seg_open;        // per segment: 1 = the round left an open chunk
 };
 // enqueue one cut round on `st` (fill -> pads/segments -> scan -> compaction -> resolve -> descriptors -> publish)
-hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st);
+// (`fill_st` / `fill_ev`: the synthetic producer's own stream and the event the cut waits for; null = same stream)
+hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st, hipStream_t fill_st = nullptr,
+                             hipEvent_t fill_ev = nullptr);
 // the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
 hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st);
 // raise `stop` behind everything enqueued so far on `st`

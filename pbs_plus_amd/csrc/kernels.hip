@@ -859,7 +859,8 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
                                                  const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
                                                  uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
                                                  pbsgpu_record *recs, uint64_t rec_cap, const uint64_t *sugg,
-                                                 const uint32_t *sugg_idx, uint32_t cmin, const uint32_t *gate) {
+                                                 const uint32_t *sugg_idx, uint32_t cmin, const uint32_t *gate,
+                                                 SuggFeed fr) {
     const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (seg >= nseg) return;
@@ -912,7 +913,16 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
                 swb += 64;
                 sv = (swb + lane < send) ? A + sugg[swb + lane] : ~0ull;
             }
-            if (b < e) e = b;  // b >= s + min and b < e <= s + max: a legal chunk
+            if (fr.feed <= 1) {
+                if (b < e) e = b;  // b >= s + min and b < e <= s + max: a legal chunk
+            } else if (b <= B && b - s <= maxsz) {
+                // the reference's payload chunker sees `feed` bytes per scan call: a boundary inside the call's buffer is
+                // taken before the hash scan of that buffer runs, so it also wins over an EARLIER hash cut in the same
+                // buffer; buffers are counted from the last cut, or (absolute) from the stream start
+                const uint64_t ob = fr.absolute ? fr.origin + (b - A) : b - s, oe = fr.absolute ? fr.origin + (e - A) : e - s;
+                const uint64_t jb = (ob - 1) / fr.feed, je = (oe - 1) / fr.feed;
+                if (jb <= je) e = b;
+            }
         }
         if (WRITE) {
             if (lane == 0 && rbase + k < rec_cap) {
@@ -935,7 +945,7 @@ hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, co
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
                        maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0, sg.offsets,
-                       sg.index, sg.cmin, (const uint32_t *)nullptr);
+                       sg.index, sg.cmin, (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute});
     return hipGetLastError();
 }
 
@@ -946,7 +956,7 @@ hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, co
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
     hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
                        maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin,
-                       (const uint32_t *)nullptr);
+                       (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute});
     return hipGetLastError();
 }
 
@@ -1219,7 +1229,8 @@ hipError_t launch_resolve_single_par_grid(const uint64_t *cands, const uint32_t 
                        (const uint32_t *)R, (const uint64_t *)endpos, levels, node_cap, (const uint32_t *)hops, recs, rec_cap);
     // the serial walk, gated: runs only if there were more candidates than nodes (*fallback != 0)
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
-                       rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback);
+                       rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback,
+                       SuggFeed{1, 0, 0});
     return hipGetLastError();
 }
 
@@ -1238,7 +1249,8 @@ hipError_t launch_resolve_single_par(const uint64_t *cands, const uint32_t *ncan
                        endpos, node_cap, levels, fallback);
     // the serial walk, gated: runs only if the parallel kernel handed the job back (*fallback != 0)
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
-                       rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback);
+                       rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback,
+                       SuggFeed{1, 0, 0});
     return hipGetLastError();
 }
 
@@ -1247,7 +1259,8 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
                                  pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec,
-                       zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin, (const uint32_t *)nullptr);
+                       zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin, (const uint32_t *)nullptr,
+                       SuggFeed{sg.feed, sg.origin, sg.absolute});
     return hipGetLastError();
 }
 
@@ -2131,9 +2144,29 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t seed, uint64_t idx) {
     return z ^ (z >> 31);
 }
 
+// kind 4: 16-byte blocks from two ChaCha quarter-rounds over {block index, seed}: adds / xors / rotates only (24 full-rate
+// VALU ops per 16 bytes; splitmix64's two 64-bit multiplies cost ~6 ops per BYTE at quarter rate). The page ring's refill
+// runs inside the timed region on the few CUs the SHA service leaves free, so the generator has to be cheap.
+__device__ __forceinline__ uint4 chacha2_block(uint64_t q, uint64_t seed) {
+    uint32_t x0 = (uint32_t)q ^ 0x61707865u, x1 = (uint32_t)(q >> 32) ^ 0x3320646eu;
+    uint32_t x2 = (uint32_t)seed ^ 0x79622d32u, x3 = (uint32_t)(seed >> 32) ^ 0x6b206574u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        x0 += x1; x3 = __builtin_rotateleft32(x3 ^ x0, 16);
+        x2 += x3; x1 = __builtin_rotateleft32(x1 ^ x2, 12);
+        x0 += x1; x3 = __builtin_rotateleft32(x3 ^ x0, 8);
+        x2 += x3; x1 = __builtin_rotateleft32(x1 ^ x2, 7);
+    }
+    return make_uint4(x0, x1, x2, x3);
+}
+
 __device__ __forceinline__ uint64_t fill_word(uint64_t widx, uint64_t seed, uint32_t kind) {
     switch (kind) {
     case 0: return splitmix64(seed, widx);
+    case 4: {
+        const uint4 b = chacha2_block(widx >> 1, seed);
+        return (widx & 1u) ? ((uint64_t)b.w << 32) | b.z : ((uint64_t)b.y << 32) | b.x;
+    }
     case 1: return 0;
     case 2: return splitmix64(seed, widx & 511u);
     default: {

@@ -31,7 +31,7 @@ using namespace pbse;
 namespace {
 
 constexpr uint32_t kInputs = 16;          // rounds whose host-written tables may be in flight
-constexpr uint32_t kPagesPerStreamRound = 12;  // < kRingPT - 2 (open chunk) with room to spare
+constexpr uint32_t kPagesPerStreamRound = 48;  // < kRingPT - 2 (open chunk) with room to spare
 
 struct PageReq {                          // a committed page waiting for its round
     uint32_t phys = 0;
@@ -84,7 +84,8 @@ struct pbsgpu_ring {
     pbsgpu_engine *eng = nullptr;
     // geometry
     uint64_t page_bytes = 0, stride = 0;
-    uint32_t tile_bytes = 0, tpp = 0, npages = 0, max_streams = 0, sha_cus = 0, round_pages = 0, cap = 0;
+    uint32_t tile_bytes = 0, tpp = 0, npages = 0, max_streams = 0, sha_cus = 0, round_pages = 0, min_round_pages = 0, cap = 0;
+    uint32_t max_inflight = 3;
     uint64_t rec_cap = 0, dense_cap = 0;
     uint32_t qslots = 0, ncells = 0, nfree = 0;
     // device
@@ -93,8 +94,9 @@ struct pbsgpu_ring {
     // mapped pinned
     PinnedBuf cells, free_fifo, inputs;
     size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_status_off = 0;
-    hipStream_t cs = nullptr, ss = nullptr;
+    hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
     hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr;
+    hipEvent_t ev_fill[kInputs] = {};
     bool service_running = false;
     // host bookkeeping
     std::vector<uint32_t> free_pages;
@@ -204,9 +206,26 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     *did = false;
     pbsgpu_engine *e = r->eng;
     if (r->error != PBSGPU_OK) return r->error;
-    bool any = false;
-    for (auto &s : r->slots) any |= s.open && (!s.ready.empty() || s.zero_final);
+    bool any = false, any_final = false;
+    size_t ready = 0;
+    for (auto &s : r->slots) {
+        if (!s.open) continue;
+        any |= !s.ready.empty() || s.zero_final;
+        any_final |= s.zero_final || (!s.ready.empty() && s.ready.back().final);
+        ready += s.ready.size();
+    }
     if (!any) return PBSGPU_OK;
+    // A round costs a dozen dependent launches whatever it holds: while earlier rounds keep the device busy, wait until
+    // a quarter of a full round has gathered (pages come back from the SHA service one by one). A stream's end and an
+    // idle device go at once.
+    {
+        size_t inflight = 0;
+        for (auto &ri : r->rounds) inflight += ri.reaped ? 0 : 1;
+        if (inflight > 0 && !any_final && ready < r->min_round_pages) return PBSGPU_OK;
+        // ... and never queue rounds deep: a page that waits behind several queued rounds is resident without being
+        // worked on (measured: 16 rounds deep = ~80 ms of extra residency per page, a quarter of the whole)
+        if (inflight >= r->max_inflight) return PBSGPU_OK;
+    }
     int in = -1;
     for (uint32_t i = 0; i < kInputs; ++i)
         if (!r->input_busy[i]) { in = (int)i; break; }
@@ -322,7 +341,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.seg_newc = r->seg_newc.as<uint64_t>();
     rr.seg_open = r->seg_open.as<uint32_t>();
     CHK(ring_start_service(r));
-    HIPCHK(pbsk::launch_ring_round(rr, e->num_cus, r->cs));
+    HIPCHK(pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in]));
     r->input_busy[in] = true;
     r->rounds.push_back(std::move(ri));
     r->st.rounds++;
@@ -380,12 +399,18 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         if (r->npages < 4) return PBSGPU_E_INVALID;
         r->max_streams = o.max_streams ? o.max_streams : 64;
         if (r->max_streams > 4096) return PBSGPU_E_INVALID;
-        int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - 48);
+        // 3/4 of the chip hashes, 1/4 cuts: per GiB the cut rounds cost ~70 CU-ms (scan 52 + refill 18), the service
+        // ~233 CU-ms (128 chains per CU at 1.66-1.75 us per 64-byte block) — measured optimum 192 of 256 CUs
+        // (profiles/r03_ring_sweep_*.log: 184 -> 580, 192 -> 597, 200 -> 528, 208 -> 504 GiB/s)
+        int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - e->num_cus / 4);
         if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
         r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1));
         r->round_pages = o.round_pages ? o.round_pages : 256;
         if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
         r->round_pages = std::min(r->round_pages, r->npages);
+        r->min_round_pages = std::max(1u, r->round_pages / 4);
+        if (const char *v = getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = (uint32_t)std::max(1, atoi(v));
+        if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kInputs);
         // candidate slots per scan tile: twice the batch path's default for this tile size
         const double lambda = 3.0 * r->tile_bytes / ((double)e->cfg.mask + 1.0);
         uint32_t capv = 8;
@@ -433,6 +458,8 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         CHK(r->inputs.ensure(r->input_stride * kInputs));
         std::memset(r->inputs.p, 0, r->input_stride * kInputs);
         HIPCHK(hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&r->fs, hipStreamNonBlocking));
+        for (auto &ev : r->ev_fill) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         // the service must never share a hardware queue with a stream that enqueues behind it (packets of one queue
         // run in order: work queued behind a kernel that only ends on request would never start). HIP keeps one queue
         // pool per priority: the service gets the highest priority to itself.
@@ -468,6 +495,7 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
         HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
         HIPCHK(hipStreamSynchronize(r->cs));
         HIPCHK(hipStreamSynchronize(r->ss));
+        HIPCHK(hipStreamSynchronize(r->fs));
         r->service_running = false;
         float ms = 0;
         if (hipEventElapsedTime(&ms, r->ev_svc0, r->ev_svc1) == hipSuccess) {
@@ -493,6 +521,9 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         if (r->cs && r->ss) (void)pbsgpu_ring_quiesce(r);
         if (r->ss) (void)hipStreamDestroy(r->ss);
         if (r->cs) (void)hipStreamDestroy(r->cs);
+        if (r->fs) (void)hipStreamDestroy(r->fs);
+        for (auto ev : r->ev_fill)
+            if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : {r->ev_reset, r->ev_svc0, r->ev_svc1})
             if (ev) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->scalars, &r->tile_cnt, &r->tile_off,
@@ -571,7 +602,7 @@ int pbsgpu_ring_commit(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int fin
 
 int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, int final,
                      uint64_t *taken) {
-    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open || kind > 3) return PBSGPU_E_INVALID;
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open || kind > 4) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     *taken = 0;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;

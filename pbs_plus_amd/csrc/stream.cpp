@@ -544,7 +544,7 @@ int stream_flush(pbsgpu_stream *s, bool final) {
         pc.sugg_rel.push_back(b - s->base);
     }
     const uint32_t sidx[2] = {0u, (uint32_t)pc.sugg_rel.size()};
-    SuggestedHost sg{pc.sugg_rel.data(), sidx};
+    SuggestedHost sg{pc.sugg_rel.data(), sidx, s->base};
     pbsgpu_segment seg{0, total};
     pc.ctx = s->cut_next;
     s->cut_next ^= 1;
@@ -1108,8 +1108,22 @@ int pbsgpu_gather_device(pbsgpu_engine *e, const void *src, uint64_t src_bytes, 
 }
 
 // ---- digest-set duplicate detection ---------------------------------------------------------
+static int dedup_common(pbsgpu_engine *e, const pbsgpu_record *recs, bool on_device, uint64_t n, uint8_t *dup,
+                        pbsgpu_dedup_stats *stats);
+
 int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, uint8_t *dup,
                       pbsgpu_dedup_stats *stats) {
+    return dedup_common(e, recs, false, n, dup, stats);
+}
+
+// the records are already in device memory (e.g. the output of an RCCL all-gather): no host round trip of the set
+int pbsgpu_dedup_device(pbsgpu_engine *e, const void *drecs, uint64_t n, uint8_t *dup, pbsgpu_dedup_stats *stats) {
+    if (n && !is_device_pointer(drecs)) return PBSGPU_E_INVALID;
+    return dedup_common(e, static_cast<const pbsgpu_record *>(drecs), true, n, dup, stats);
+}
+
+static int dedup_common(pbsgpu_engine *e, const pbsgpu_record *recs, bool on_device, uint64_t n, uint8_t *dup,
+                        pbsgpu_dedup_stats *stats) {
     if (!e || (!recs && n) || !stats) return PBSGPU_E_INVALID;
     if (n >= (1ull << 32)) return PBSGPU_E_INVALID;
     std::memset(stats, 0, sizeof(*stats));
@@ -1119,21 +1133,25 @@ int pbsgpu_dedup_host(pbsgpu_engine *e, const pbsgpu_record *recs, uint64_t n, u
     Slot *s = lease.s;
     const size_t tmp_bytes = pbsk::dedup_tmp_bytes(n);
     // layout inside slot buffers: recs | keys | keys_alt | idx | idx_alt | dup | stats | tmp
-    CHK(s->recs.ensure((size_t)n * sizeof(pbsgpu_record)));
+    if (!on_device) CHK(s->recs.ensure((size_t)n * sizeof(pbsgpu_record)));
     CHK(s->dense.ensure((size_t)n * 16 + 64));
     CHK(s->tile_slots.ensure((size_t)n * 8 + 64));
     CHK(s->tile_cnt.ensure((size_t)n + 64));
     CHK(s->scalars.ensure(SC_COUNT * 4 + 64));
     CHK(s->scan_tmp.ensure(tmp_bytes));
     CHK(s->h_scalars.ensure(64));
-    CHK(staged_h2d(*s, s->recs.p, recs, n * sizeof(pbsgpu_record), s->stream));
+    const pbsgpu_record *drecs = recs;
+    if (!on_device) {
+        CHK(staged_h2d(*s, s->recs.p, recs, n * sizeof(pbsgpu_record), s->stream));
+        drecs = s->recs.as<pbsgpu_record>();
+    }
     uint64_t *keys = s->dense.as<uint64_t>();
     uint64_t *keys_alt = keys + n;
     uint32_t *idx = s->tile_slots.as<uint32_t>();
     uint32_t *idx_alt = idx + n;
     uint8_t *d_dup = s->tile_cnt.as<uint8_t>();
     uint64_t *d_stats = reinterpret_cast<uint64_t *>(s->scalars.as<uint8_t>() + 32);
-    HIPCHK(pbsk::launch_dedup(s->recs.as<pbsgpu_record>(), n, keys, idx, keys_alt, idx_alt, d_dup, d_stats,
+    HIPCHK(pbsk::launch_dedup(drecs, n, keys, idx, keys_alt, idx_alt, d_dup, d_stats,
                               s->scan_tmp.p, tmp_bytes, s->stream));
     HIPCHK(hipMemcpyAsync(s->h_scalars.p, d_stats, 32, hipMemcpyDeviceToHost, s->stream));
     if (dup) HIPCHK(hipMemcpyAsync(dup, d_dup, (size_t)n, hipMemcpyDeviceToHost, s->stream));

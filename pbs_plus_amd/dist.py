@@ -30,18 +30,14 @@ def shard_segments(lengths, world_size: int):
     return [sorted(x) for x in out]
 
 
-def allgather_records(records: np.ndarray, device=None, group=None, cap_records: int | None = None) -> np.ndarray:
-    """All-gather every rank's record array (variable length) -> concatenation in rank order.
-
-    With `cap_records` (an upper bound every rank agrees on, e.g. bytes / min chunk size) this is ONE collective:
-    an all_gather_into_tensor of [count | padded 48-byte records]; without it the counts are exchanged first.
-    `device` = torch device of the communication buffers ("cuda:N" with RCCL, None/"cpu" with gloo)."""
+def _gather_rows(records: np.ndarray, dev, group, cap_records):
+    """ONE all_gather_into_tensor of [count | padded 48-byte records] rows; returns (rows tensor on `dev`, row bytes,
+    world size, capacity). The rows tensor stays on the device with RCCL."""
     import torch
     import torch.distributed as dist
 
     ws = dist.get_world_size(group)
     recs = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
-    dev = torch.device(device) if device is not None else torch.device("cpu")
     isz = RECORD_DTYPE.itemsize
     if cap_records is None:
         cnt = torch.tensor([recs.size], dtype=torch.int64, device=dev)
@@ -51,13 +47,30 @@ def allgather_records(records: np.ndarray, device=None, group=None, cap_records:
     if recs.size > cap_records:
         raise ValueError(f"{recs.size} records exceed the agreed capacity {cap_records}")
     row = 16 + cap_records * isz                       # 16-byte header keeps the records 16-byte aligned
-    payload = np.zeros(row, dtype=np.uint8)
-    payload[:8] = np.frombuffer(np.uint64(recs.size).tobytes(), dtype=np.uint8)
-    payload[16:16 + recs.size * isz] = recs.view(np.uint8).reshape(-1)
-    mine = torch.from_numpy(payload).to(dev)
+    # only the bytes that exist are uploaded: the row is assembled on the device (the padding is never copied H2D)
+    mine = torch.zeros(row, dtype=torch.uint8, device=dev)
+    head = np.zeros(16, dtype=np.uint8)
+    head[:8] = np.frombuffer(np.uint64(recs.size).tobytes(), dtype=np.uint8)
+    mine[:16] = torch.from_numpy(head).to(dev)
+    if recs.size:
+        mine[16:16 + recs.size * isz] = torch.from_numpy(recs.view(np.uint8).reshape(-1)).to(dev)
     out = torch.empty(ws * row, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, mine, group=group)
-    host = out.cpu().numpy().reshape(ws, row)
+    return out.view(ws, row), row, ws, cap_records
+
+
+def allgather_records(records: np.ndarray, device=None, group=None, cap_records: int | None = None) -> np.ndarray:
+    """All-gather every rank's record array (variable length) -> concatenation in rank order, on the HOST.
+
+    With `cap_records` (an upper bound every rank agrees on, e.g. bytes / min chunk size) this is ONE collective:
+    an all_gather_into_tensor of [count | padded 48-byte records]; without it the counts are exchanged first.
+    `device` = torch device of the communication buffers ("cuda:N" with RCCL, None/"cpu" with gloo)."""
+    import torch
+
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    rows, row, ws, _ = _gather_rows(records, dev, group, cap_records)
+    host = rows.cpu().numpy()
+    isz = RECORD_DTYPE.itemsize
     parts = []
     for r in range(ws):
         n = int(host[r, :8].view(np.uint64)[0])
@@ -65,11 +78,35 @@ def allgather_records(records: np.ndarray, device=None, group=None, cap_records:
     return np.concatenate(parts) if parts else np.zeros(0, dtype=RECORD_DTYPE)
 
 
-def global_dedup(engine, local_records: np.ndarray, device=None, group=None, cap_records: int | None = None):
-    """Digest-set reduce: gather all ranks' records (one collective), then duplicate detection on this rank's
-    GPU (radix sort by digest prefix + compare, libpbsgpu). Returns (dup flags, stats, all records)."""
-    allrecs = allgather_records(local_records, device=device, group=group, cap_records=cap_records)
-    dup, stats = engine.dedup(allrecs)
+def global_dedup(engine, local_records: np.ndarray, device=None, group=None, cap_records: int | None = None,
+                 want_records: bool = True):
+    """Digest-set reduce: gather all ranks' records (one collective), then duplicate detection on this rank's GPU
+    (radix sort by digest prefix + compare, libpbsgpu). Returns (dup flags, stats, all records or None).
+
+    With RCCL (`device` = a cuda device) the gathered set never leaves the device: the rows of the all-gather are
+    compacted with one device gather and handed to pbsgpu_dedup_device; only the per-rank counts (8 bytes each), the
+    flags and the four statistics come back to the host. `want_records=False` skips the download of the gathered
+    records (the benchmark only needs the statistics).
+    Every rank runs the (sub-millisecond) dedup over the whole set: with ~10 MB per TiB of corpus the exchange is
+    latency-bound, and a rank-0-only dedup would pay a second collective to broadcast four numbers."""
+    import torch
+
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if dev.type != "cuda" or not hasattr(engine, "dedup_device"):
+        allrecs = allgather_records(local_records, device=device, group=group, cap_records=cap_records)
+        dup, stats = engine.dedup(allrecs)
+        return dup, stats, allrecs
+    rows, row, ws, _ = _gather_rows(local_records, dev, group, cap_records)
+    isz = RECORD_DTYPE.itemsize
+    counts = rows[:, :8].contiguous().cpu().numpy().view(np.uint64).reshape(-1)      # ws x 8 bytes
+    total = int(counts.sum())
+    if total == 0:
+        dup, stats = engine.dedup(np.zeros(0, dtype=RECORD_DTYPE))
+        return dup, stats, (np.zeros(0, dtype=RECORD_DTYPE) if want_records else None)
+    packed = torch.cat([rows[r, 16:16 + int(counts[r]) * isz] for r in range(ws) if counts[r]])
+    torch.cuda.synchronize(dev)               # the engine's own HIP stream reads the tensor next
+    dup, stats = engine.dedup_device(packed.data_ptr(), total)
+    allrecs = packed.cpu().numpy().view(RECORD_DTYPE).copy() if want_records else None
     return dup, stats, allrecs
 
 
@@ -80,7 +117,8 @@ def ingest_corpus(engine, lengths, make_batch, device=None, group=None, max_batc
 
     lengths      byte length of every segment of the corpus (same on every rank)
     make_batch   callback(list of global segment indices) -> (device buffer, [(offset, length)] in that buffer);
-                 the caller owns how bytes reach HBM (generated, read from disk, received from agents)
+                 the caller owns how bytes reach HBM (generated, read from disk, received from agents). Two batches
+                 are in flight: make_batch must NOT reuse the buffer of the previous call (it is still being read)
     Returns (records of this rank with GLOBAL segment ids, dedup stats over the whole corpus, all ranks' records)."""
     import torch.distributed as dist
 
@@ -103,11 +141,17 @@ def ingest_corpus(engine, lengths, make_batch, device=None, group=None, max_batc
     parts, pending = [], []
     for ids in batches:                      # two batches in flight: the next is generated while one hashes
         buf, segs = make_batch(ids)
-        pending.append((ids, engine.submit(buf, segs, None if not isinstance(buf, int) else sum(n for _, n in segs))))
+        # a raw device pointer needs the byte extent of its segments (they need not start at 0 nor be gap-free)
+        nbytes = None if not isinstance(buf, int) else max((int(o) + int(n) for o, n in segs), default=0)
+        # `buf` stays referenced until its ticket has been collected: device pointers are borrowed until then (a torch
+        # tensor dropped here could be handed to the next batch by the caching allocator while this one is still read)
+        pending.append((ids, engine.submit(buf, segs, nbytes), buf))
         if len(pending) == 2:
-            parts.append(_collect_global(engine, *pending.pop(0)))
+            ids0, t0, _keep = pending.pop(0)
+            parts.append(_collect_global(engine, ids0, t0))
     while pending:
-        parts.append(_collect_global(engine, *pending.pop(0)))
+        ids0, t0, _keep = pending.pop(0)
+        parts.append(_collect_global(engine, ids0, t0))
     local = np.concatenate(parts) if parts else np.zeros(0, dtype=RECORD_DTYPE)
     if ws > 1:
         cap = max(int(sum(int(lengths[g]) for g in p) // max(1, engine.config.MinSize)) + 2 * len(p) + 16 for p in plan)

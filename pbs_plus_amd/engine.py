@@ -93,6 +93,10 @@ class Engine:
     def __exit__(self, *a):
         self.close()
 
+    def set_suggested_feed(self, feed_bytes: int = 1, absolute_grid: bool = False) -> None:
+        """Reader buffer size the suggested-boundary rule emulates (1 = byte-serial, 0 = everything at once)."""
+        check(self._L.pbsgpu_engine_set_suggested_feed(self._h, int(feed_bytes), int(absolute_grid)), "set_suggested_feed")
+
     # ---- device memory helpers -------------------------------------------------------------
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
@@ -261,6 +265,14 @@ class Engine:
         check(self._L.pbsgpu_dedup_host(self._h, recs.ctypes.data if recs.size else None, recs.size, dup.ctypes.data,
                                         C.byref(st)), "dedup_host")
         return dup[: recs.size], {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
+
+    def dedup_device(self, dptr: int, n: int, want_flags: bool = True):
+        """dedup() on n records that already are in device memory (e.g. an RCCL all-gather's output)."""
+        dup = np.zeros(max(n, 1), dtype=np.uint8) if want_flags else None
+        st = _lib.DedupStats()
+        check(self._L.pbsgpu_dedup_device(self._h, dptr, n, dup.ctypes.data if want_flags else None, C.byref(st)),
+              "dedup_device")
+        return (dup[:n] if want_flags else None), {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
 
     # ---- dynamic index ------------------------------------------------------------------------------
     def didx_encode(self, records: np.ndarray, uuid: bytes = b"\0" * 16, ctime: int = 0) -> bytes:
@@ -498,7 +510,8 @@ class PageRing:
         limit = concurrent or len(jobs)
         t0 = time.perf_counter()
         while todo or active:
-            while todo and len(active) < limit:
+            # `limit` streams are FED at a time; a stream whose bytes are all in only waits for its last chunks
+            while todo and sum(1 for v in active.values() if not v[2]) < limit:
                 try:
                     sid = self.open()
                 except _lib.PbsGpuError as exc:
@@ -507,12 +520,14 @@ class PageRing:
                     break
                 j = todo.pop(0)
                 active[sid] = [j, int(jobs[j][2]), False]
+            quota = 16 * self.page_bytes            # pages are dealt out evenly among the open streams
             for sid, a in active.items():
                 j, left, sent_final = a
                 if not sent_final:
-                    got = self.fill(sid, jobs[j][0], jobs[j][1], left, final=True)
+                    want = min(left, quota)
+                    got = self.fill(sid, jobs[j][0], jobs[j][1], want, final=(want == left))
                     a[1] -= got
-                    if a[1] == 0:
+                    if a[1] == 0 and (got == want):
                         a[2] = True
             self.pump()
             for sid in list(active):

@@ -124,8 +124,79 @@ def _patch(monkeypatch, engine_cls=_FakeEngine):
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     monkeypatch.setattr(pbs_plus_amd, "Engine", engine_cls)
+    monkeypatch.setattr(pbs_plus_amd, "PageRing", _FakeRing)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
+
+
+class _FakeRing:
+    """Stand-in for pbs_plus_amd.PageRing as far as bench.py drives it: a stream's bytes are generated on the host by the
+    oracle's twin of the device generator, a fraction per fill() call (pages trickle in), and cut + hashed by the oracle
+    when the stream ends. Records come out in two instalments so that bench.py's poll loop is exercised."""
+    PAGE = 1 << 16
+
+    def __init__(self, eng, arena_bytes=0, page_bytes=0, max_streams=0, sha_cus=0, round_pages=0):
+        self.eng, self.streams, self.next, self.rounds, self.launches = eng, {}, 0, 0, 0
+        self.page_bytes = self.PAGE
+        self.running, self.bytes = False, 0
+        self.svc_bytes0 = 0
+
+    def open(self):
+        self.next += 1
+        self.streams[self.next] = {"parts": [], "final": False, "recs": None, "given": 0}
+        return self.next
+
+    def fill(self, sid, seed, kind, nbytes, final=False):
+        st = self.streams[sid]
+        take = min(nbytes, 3 * self.PAGE)          # a few pages per call: the bench has to come back
+        if take < nbytes:
+            take -= take % self.PAGE
+        off = sum(p.size for p in st["parts"])
+        st["parts"].append(self.eng.O.fill(take, seed, kind, stream_off=off))
+        if take == nbytes and final:
+            st["final"] = True
+        self.bytes += take
+        return take
+
+    def pump(self):
+        if not self.running:
+            self.running = True
+            self.launches += 1
+        self.rounds += 1
+        for st in self.streams.values():
+            if st["final"] and st["recs"] is None:
+                data = np.concatenate(st["parts"]) if st["parts"] else np.zeros(0, np.uint8)
+                st["recs"] = self.eng.O.chunk_and_digest(self.eng.O.new_config(self.eng.avg), data, [(0, data.size)])
+                st["parts"] = []
+
+    def poll(self, sid, cap=4096):
+        st = self.streams[sid]
+        if st["recs"] is None:
+            return np.zeros(0, dtype=st_dtype()), False
+        lo = st["given"]
+        hi = min(st["recs"].size, lo + max(1, st["recs"].size // 2 + 1), lo + cap)
+        st["given"] = hi
+        return st["recs"][lo:hi].copy(), hi == st["recs"].size
+
+    def close_stream(self, sid):
+        assert self.streams[sid]["given"] == self.streams[sid]["recs"].size
+        del self.streams[sid]
+
+    def quiesce(self):
+        self.running = False
+        self.svc_last, self.svc_bytes0 = self.bytes - self.svc_bytes0, self.bytes
+
+    def stats(self):
+        return {"page_bytes": self.PAGE, "pages_total": 64, "sha_cus": 208, "rounds": self.rounds, "service_launches": self.launches,
+                "service_ms_last": 5.0, "service_bytes_last": getattr(self, "svc_last", 0), "chunks": 0}
+
+    def close(self):
+        pass
+
+
+def st_dtype():
+    from pbs_plus_amd import RECORD_DTYPE
+    return RECORD_DTYPE
 
 
 def _run(monkeypatch, argv):
@@ -173,7 +244,7 @@ def _check_common(d, steps, warmup):
 @pytest.mark.parametrize("slots,steps,collect", [(4, 9, "any"), (1, 2, "fifo"), (3, 7, "fifo")])
 def test_bench_default_workload_contract(monkeypatch, slots, steps, collect):
     _patch(monkeypatch)
-    d = _run(monkeypatch, ["--gib", str(16 / 1024), "--avg", "65536", "--steps", str(steps), "--warmup", "1",
+    d = _run(monkeypatch, ["--workload", "stream64g", "--gib", str(16 / 1024), "--avg", "65536", "--steps", str(steps), "--warmup", "1",
                            "--slots", str(slots), "--cpu-sample-gib", str(8 / 1024), "--collect", collect])
     _check_common(d, steps, 1)
     assert d["scaling"] == "weak"
@@ -186,7 +257,7 @@ def test_bench_default_line_carries_the_other_configs(monkeypatch):
     """configs[2..4] ride in the default line as short legs, each with its own oracle check (here at reduced shapes; the
     host-fed legs need the real stream writer and are covered by the -m gpu suite)"""
     _patch(monkeypatch)
-    d = _run(monkeypatch, ["--gib", str(16 / 1024), "--avg", "65536", "--steps", "4", "--warmup", "1", "--cpu-sample-gib",
+    d = _run(monkeypatch, ["--workload", "stream64g", "--gib", str(16 / 1024), "--avg", "65536", "--steps", "4", "--warmup", "1", "--cpu-sample-gib",
                            str(8 / 1024), "--extras-gib", str(32 / 1024), "--extras-file-mib", "1",
                            "--extras", "manyfiles,corpus_dup,rechunk"])
     _check_common(d, 4, 1)
@@ -201,9 +272,37 @@ def test_bench_default_line_carries_the_other_configs(monkeypatch):
     assert w["rechunk"]["results"]["reused_chunk_bytes_frac"] > 0.3
 
 
+def test_bench_ring_workload_is_the_default_and_keeps_the_contract(monkeypatch):
+    """The default line = configs[1] through the page ring: a step is one whole file, every file new data, the roofline
+    entry is the persistent service launch, parity = prefix + restart points over EVERY timed file on regenerated bytes;
+    the batch path rides along in `workloads`."""
+    _patch(monkeypatch)
+    d = _run(monkeypatch, ["--gib", str(24 / 1024), "--avg", "65536", "--steps", "5", "--warmup", "2", "--cpu-sample-gib",
+                           str(8 / 1024), "--ring-streams", "3", "--extras-gib", str(16 / 1024), "--extras-file-mib", "1",
+                           "--extras", "batch,manyfiles"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["unit"] == "GiB/s" and d["value"] > 0
+    assert "page ring" in d["config"]["path"] and d["config"]["files_in_flight"] == 3
+    assert d["config"]["bytes_per_step"] == 24 << 20 and d["config"]["distinct_data_per_step"] is True
+    r = d["roofline"]
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "path", "single_file"):
+        assert key in r, key
+    assert "RingSource" in r["kernel"] and r["service_launch_bytes"] == 5 * (24 << 20)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["records_match_gpu"] is True and c["kind"] == "port" and c["cores"] == 1
+    sp = c["whole_file_restart_points"]
+    assert sp["ok"] is True and sp["files"] == 6 and sp["max_offset"] == 24 << 20   # 5 timed files + the single-file pass
+    w = d["workloads"]
+    assert "error" not in w["batch_path_stream64g"] and w["batch_path_stream64g"]["value"] > 0
+    assert w["batch_path_stream64g"]["records_match_gpu"] is True and w["manyfiles"]["records_match_gpu"] is True
+
+
 def test_bench_reread_protocol_is_labelled(monkeypatch):
     _patch(monkeypatch, _RereadEngine)
-    d = _run(monkeypatch, ["--gib", str(16 / 1024), "--avg", "65536", "--steps", "6", "--warmup", "1", "--reread", "3",
+    d = _run(monkeypatch, ["--workload", "stream64g", "--gib", str(16 / 1024), "--avg", "65536", "--steps", "6", "--warmup", "1", "--reread", "3",
                            "--cpu-sample-gib", str(8 / 1024)])
     _check_common(d, 6, 1)
     assert d["config"]["distinct_data_per_slot"] is False and d["config"]["inflight_batches"] == 3
@@ -283,7 +382,7 @@ def _two_ranks(args):
 def test_bench_two_ranks_gloo_prints_one_aggregate_line():
     """The N>1 branch of bench.py (barrier, per-step digest-set all-gather, MAX-over-ranks timing, rank 0 prints)
     with world_size 2 over gloo on CPU — the launch shape the driver uses with RCCL on the GPU node."""
-    d = _two_ranks(["--gpus", "2", "--gib", str(16 / 1024), "--avg", "65536", "--steps", "4", "--warmup", "1",
+    d = _two_ranks(["--gpus", "2", "--workload", "stream64g", "--gib", str(16 / 1024), "--avg", "65536", "--steps", "4", "--warmup", "1",
                     "--slots", "3", "--no-cpu-baseline"])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
     one_rank_bytes = d["config"]["bytes_per_batch"]

@@ -107,3 +107,25 @@ def test_python_binding_declares_every_function_it_calls():
         assert len(fn.argtypes) == n, f"{name}: ctypes argtypes has {len(fn.argtypes)} entries, header declares {n}"
         checked += 1
     assert checked >= 50, checked
+
+
+def _go_exports(src: str):
+    src = _strip_comments(src)
+    funcs = set(re.findall(r"^func\s+([A-Z]\w*)\s*\(", src, flags=re.M))
+    meths = set((m.group(1), m.group(2)) for m in re.finditer(r"^func\s+\(\w+\s+\*?(\w+)\)\s+([A-Z]\w*)\s*\(", src, flags=re.M))
+    types = (set(re.findall(r"^type\s+([A-Z]\w*)\b", src, flags=re.M)) | set(re.findall(r"^\t([A-Z]\w*)\s+struct\b", src, flags=re.M))
+             | set(re.findall(r"^\t(Ticket)\s+uint64\b", src, flags=re.M)))
+    vars_ = set(re.findall(r"^(?:var\s+|\t)(Err[A-Z]\w*)\s*=", src, flags=re.M))
+    return funcs, meths, types, vars_
+
+
+def test_go_fallback_mirrors_the_whole_exported_surface():
+    """CGO_ENABLED=0 builds (the project's default) must compile code written against the GPU binding: every exported
+    function, method, type and error value of pbsgpu.go exists in fallback.go."""
+    gf, gm, gt, gv = _go_exports(open(os.path.join(ROOT, "go", "pbsgpu", "pbsgpu.go")).read())
+    ff, fm, ft, fv = _go_exports(open(os.path.join(ROOT, "go", "pbsgpu", "fallback.go")).read())
+    assert len(gm) >= 40 and len(gf) >= 4, (len(gm), len(gf))
+    assert gf <= ff, sorted(gf - ff)
+    assert gm <= fm, sorted(gm - fm)
+    assert gt <= ft, sorted(gt - ft)
+    assert gv <= fv | {"ErrNotBuilt"}, sorted(gv - fv)

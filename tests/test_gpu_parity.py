@@ -52,7 +52,7 @@ def host_twin(O, segs, table, total):
 
 def test_device_fill_matches_oracle_fill(engines, O):
     eng = engines(4096)
-    for kind in range(4):
+    for kind in range(5):
         n = (1 << 20) + 13
         buf = eng.alloc(n + 8)
         eng.fill(buf.ptr, n, 42 + kind, kind, stream_off=4096)

@@ -1,0 +1,232 @@
+"""The page ring (pbsgpu_ring_*: page-granular memory release + persistent cross-stream SHA-256 service) against the
+CPU oracle, through the C ABI. Every stream's records (end, size, digest) must be bit-identical to the serial
+chunker + SHA-256 over the same bytes — whatever pages the stream's bytes landed in, however its chunks were spread
+over rounds, and however often the service kernel was stopped and started. Mirrors the shapes the reference's writers
+produce: many archives at once (internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836), empty and
+tiny files (commit_walk_test.go:21-147), zero runs."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GiB = 1 << 30
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _short_idle_timeout(monkeypatch):
+    # a service wave that sees no work gives up after this long: a bug must fail a test, not hang the box
+    monkeypatch.setenv("PBSGPU_RING_IDLE_TIMEOUT_S", "5")
+
+
+def _engine(avg):
+    from pbs_plus_amd import Engine, buzhash
+
+    return Engine(buzhash.NewConfig(avg), device=0, inflight=1)
+
+
+def _oracle_records(O, avg, jobs):
+    cfg = O.new_config(avg)
+    out = [None] * len(jobs)
+
+    def one(i):
+        seed, kind, n = jobs[i]
+        out[i] = O.chunk_and_digest(cfg, O.fill(n, seed, kind), [(0, n)]) if n else np.zeros(0, dtype=O.RECORD_DTYPE)
+
+    ths = [threading.Thread(target=one, args=(i,)) for i in range(len(jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return out
+
+
+def _assert_same(got, want, what):
+    assert got.size == want.size, (what, got.size, want.size)
+    assert np.array_equal(got["end"], want["end"]), what
+    assert np.array_equal(got["size"], want["size"]), what
+    assert np.array_equal(got["digest"], want["digest"]), what
+
+
+SMALL = dict(page_bytes=65536, max_streams=8, sha_cus=4, round_pages=6)
+
+
+@pytest.mark.parametrize("name,avg,opt,jobs,conc", [
+    ("one stream", 4096, dict(arena_bytes=24 * (65536 + 256), **SMALL), [(11, 0, 200 * 1024 + 17)], None),
+    ("mixed, empty, tiny, page-exact", 4096, dict(arena_bytes=24 * (65536 + 256), **SMALL),
+     [(21, 0, (1 << 20) + 5), (22, 1, 300 * 1024), (23, 3, 700 * 1024 + 3), (24, 0, 0), (25, 0, 63), (26, 2, 65536),
+      (27, 0, 65536 * 3), (28, 4, 65536 * 2 + 1), (29, 0, 1)], None),
+    ("two at a time through 10 pages", 4096, dict(arena_bytes=10 * (65536 + 256), page_bytes=65536, max_streams=2, sha_cus=2,
+                                                  round_pages=3),
+     [(31, 0, (1 << 20) + 5), (32, 1, 300 * 1024), (33, 3, 700 * 1024 + 3), (34, 0, 64), (35, 0, 65), (36, 4, 131072)], 2),
+    ("avg 64 KiB", 65536, dict(arena_bytes=96 * (262144 + 256), page_bytes=262144, max_streams=8, sha_cus=16, round_pages=16),
+     [(41 + i, i % 5, (8 << 20) + 4099 * i) for i in range(6)], None),
+])
+def test_ring_streams_match_the_oracle(gpu_lib, O, name, avg, opt, jobs, conc):
+    from pbs_plus_amd import PageRing
+
+    eng = _engine(avg)
+    ring = PageRing(eng, **opt)
+    got = ring.ingest_synthetic(jobs, timeout_s=60.0, concurrent=conc)
+    ring.quiesce()
+    st = ring.stats()
+    want = _oracle_records(O, avg, jobs)
+    for i, (g, w) in enumerate(zip(got, want)):
+        _assert_same(g, w, (name, i, jobs[i]))
+    # every page came back, exactly once per use
+    assert st["pages_free"] == st["pages_total"] and st["pages_recycled"] == st["pages_enqueued"], st
+    assert st["service_launches"] == 1
+    ring.close()
+    eng.close()
+
+
+def test_ring_production_chunker_three_streams(gpu_lib, O):
+    """avg 4 MiB (buzhash.NewConfig(4 << 20), commit_orchestrate.go:144): default page size (61 scan tiles, 16.2 MiB),
+    random / 30 % zero extents / all-zero streams of 0.5-1.5 GiB through 3 GiB of pages — the arena turns over"""
+    from pbs_plus_amd import PageRing
+
+    avg = 4 << 20
+    eng = _engine(avg)
+    ring = PageRing(eng, arena_bytes=3 * GiB, max_streams=4, sha_cus=64, round_pages=64)
+    jobs = [(51, 0, 3 * GiB // 2 + 56), (52, 3, 3 * GiB // 2), (53, 1, GiB // 2 + 4096), (54, 4, GiB + 24)]
+    got = ring.ingest_synthetic(jobs, timeout_s=120.0)
+    ring.quiesce()
+    st = ring.stats()
+    want = _oracle_records(O, avg, jobs)
+    for i, (g, w) in enumerate(zip(got, want)):
+        _assert_same(g, w, (i, jobs[i]))
+    assert st["page_bytes"] == 61 * 64 * 34 * 128 and st["pages_free"] == st["pages_total"]
+    assert st["pages_enqueued"] > st["pages_total"]          # the arena turned over
+    assert (got[2]["size"][:-1] == 16 << 20).all()           # a zero run is cut at max size only
+    ring.close()
+    eng.close()
+
+
+def test_ring_reserve_commit_external_producer_and_service_restart(gpu_lib, O):
+    """The caller's own producer writes the pages (here: pbsgpu_fill_device / an H2D copy into the reserved pointer),
+    commit hands them over; between two groups of streams the ring is quiesced (service kernel stopped: the device is
+    idle, hipDeviceSynchronize returns) and started again by the next pump."""
+    from pbs_plus_amd import PageRing
+
+    avg = 65536
+    eng = _engine(avg)
+    ring = PageRing(eng, arena_bytes=40 * (262144 + 256), page_bytes=262144, max_streams=4, sha_cus=8, round_pages=8)
+    page = ring.page_bytes
+    L = eng._L
+
+    def feed(jobs):
+        res = {}
+        streams = {ring.open(): [j, 0] for j in range(len(jobs))}
+        import time
+        t0 = time.time()
+        while streams:
+            for sid in list(streams):
+                j, off = streams[sid]
+                seed, kind, n, host = jobs[j]
+                if off < n or (n == 0 and off == 0):
+                    if n == 0:
+                        ring.commit(sid, 0, final=True)
+                        streams[sid][1] = 1
+                        continue
+                    r = ring.reserve(sid)
+                    if r is not None:
+                        ptr, cap = r
+                        m = min(cap, n - off)
+                        if host is None:
+                            eng.fill(ptr, (m + 7) & ~7, seed, kind, stream_off=off)   # the page has room for the rounding
+                        else:
+                            assert L.pbsgpu_memcpy_h2d(eng._h, ptr, host[off:off + m].ctypes.data, m) == 0
+                        ring.commit(sid, m, final=(off + m == n))
+                        streams[sid][1] = off + m
+            ring.pump()
+            for sid in list(streams):
+                recs, fin = ring.poll(sid)
+                if recs.size:
+                    res.setdefault(streams[sid][0], []).append(recs.copy())
+                if fin:
+                    ring.close_stream(sid)
+                    del streams[sid]
+            assert time.time() - t0 < 60, ring.stats()
+        return [np.concatenate(res[j]) if j in res else np.zeros(0, dtype=O.RECORD_DTYPE) for j in range(len(jobs))]
+
+    rng = np.random.default_rng(3)
+    host_bytes = rng.integers(0, 256, 3 * page + 77, dtype=np.uint8)
+    host_bytes[page - 40:page + 40] = 0                     # a constant run across a page boundary
+    groups = [[(61, 0, 5 * page + 1234, None), (62, 3, 2 * page, None), (0, 0, host_bytes.size, host_bytes), (63, 0, 0, None)],
+              [(64, 4, 7 * page + 9, None), (65, 1, page + 1, None)]]
+    for gi, jobs in enumerate(groups):
+        got = feed(jobs)
+        ring.quiesce()
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipDeviceSynchronize() == 0               # returns: the persistent kernel has really ended
+        for j, (seed, kind, n, host) in enumerate(jobs):
+            data = host if host is not None else O.fill(n, seed, kind)
+            want = O.chunk_and_digest(O.new_config(avg), data, [(0, n)]) if n else np.zeros(0, dtype=O.RECORD_DTYPE)
+            _assert_same(got[j], want, (gi, j))
+        assert ring.stats()["service_launches"] == gi + 1
+    ring.close()
+    eng.close()
+
+
+def test_ring_dense_candidates_fail_loudly_not_silently(gpu_lib, O):
+    """64-byte periodic bytes make every position of a scan tile a candidate: more than the ring's per-tile capacity.
+    The batch path re-runs such a batch with a larger capacity; a ring round cannot be re-run (later rounds already
+    depend on its result), so the ring must report PBSGPU_E_DENSITY — never hand out a wrong or partial record list."""
+    from pbs_plus_amd import PageRing, PbsGpuError, _lib
+
+    avg = 4096
+    eng = _engine(avg)
+    ring = PageRing(eng, arena_bytes=24 * (65536 + 256), **SMALL)
+    cfg = O.new_config(avg)
+    pat = None
+    rng = np.random.default_rng(5)
+    for _ in range(20000):                                   # a 64-byte pattern whose (periodic) window hash passes the break test
+        p = rng.integers(0, 256, 64, dtype=np.uint8)
+        if O.candidates(cfg, np.tile(p, 8)).size >= 6:     # one candidate per 64-byte period = 43x the nominal density
+            pat = p
+            break
+    if pat is None:
+        pytest.skip("no dense pattern found")
+    data = np.tile(pat, 2 * 65536 // 64)
+    sid = ring.open()
+    L = eng._L
+    with pytest.raises(PbsGpuError) as ei:
+        import time
+        t0 = time.time()
+        off = 0
+        while time.time() - t0 < 30:
+            if off < data.size:
+                r = ring.reserve(sid)
+                if r is not None:
+                    assert L.pbsgpu_memcpy_h2d(eng._h, r[0], data[off:off + 65536].ctypes.data, 65536) == 0
+                    off += 65536
+                    ring.commit(sid, 65536, final=(off == data.size))
+            ring.pump()
+            recs, fin = ring.poll(sid)
+            assert not fin, "a stream whose round overflowed must not complete"
+    assert ei.value.status == _lib.E_DENSITY
+    ring.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("extra", [[], ["--ring-kind", "0", "--ring-streams", "2"]])
+def test_bench_ring_workload_small_scale(gpu_lib, extra):
+    """bench.py's default workload (the ring) end to end at a size the oracle re-checks completely enough: 1.5 GiB files
+    through a 6 GiB arena, prefix + restart points over every timed file."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gib", "1.5", "--arena-gib", "6", "--steps", "5",
+                          "--warmup", "2", "--cpu-sample-gib", "0.5", "--no-extras", "--ring-sha-cus", "128"] + extra,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    c = d["cpu_baseline"]
+    assert c["records_match_gpu"] is True and c["whole_file_restart_points"]["files"] == 6, c
+    assert c["whole_file_restart_points"]["max_offset"] == d["config"]["bytes_per_step"]
+    assert d["roofline"]["service_launch_bytes"] == 5 * d["config"]["bytes_per_step"]
+    assert d["value"] > 20 and d["config"]["distinct_data_per_step"] is True

@@ -496,7 +496,9 @@ def test_stream_tee_large_files_at_production_window(engines, O):
 
 
 @pytest.mark.parametrize("workload,extra", [("stream64g", ["--slots", "2"]), ("corpus_dup", ["--file-mib", "8", "--scaling", "strong"]),
-                                             ("corpus_dup", ["--file-mib", "8"])])
+                                             ("corpus_dup", ["--file-mib", "8"]),
+                                             # two rings on ONE GPU: each service gets 64 CUs (a real job has one rank per GPU)
+                                             ("ring", ["--ring-streams", "2", "--arena-gib", "1.5", "--ring-sha-cus", "64"])])
 def test_bench_two_ranks_share_the_gpu(gpu_lib, workload, extra):
     """bench.py's N > 1 branch with the REAL engine: two ranks over gloo on the one GPU of the test box (the driver
     runs the same code with RCCL, one rank per GPU). Rank 0 prints the aggregate line; the digest-set reduce ran."""
@@ -801,7 +803,7 @@ def test_dense_sha_form_stays_bit_exact(gpu_lib):
         assert "dense-ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("workload", ["stream64g", "corpus_dup"])
+@pytest.mark.parametrize("workload", ["stream64g", "corpus_dup", "ring"])
 def test_bench_rccl_code_path_with_one_rank(gpu_lib, workload):
     """The "nccl" (= RCCL) branch of bench.py on real hardware: process-group init with device_id, barrier, all_reduce
     (MAX / SUM), all_gather_into_tensor of the uint8 record payload, destroy — forced on with ONE rank
@@ -818,7 +820,8 @@ def test_bench_rccl_code_path_with_one_rank(gpu_lib, workload):
         port = so.getsockname()[1]
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                PBS_BENCH_FORCE_DIST="1", PBS_BENCH_BACKEND="nccl")
-    extra = ["--slots", "2"] if workload == "stream64g" else ["--file-mib", "8"]
+    extra = {"stream64g": ["--slots", "2"], "corpus_dup": ["--file-mib", "8"],
+             "ring": ["--ring-streams", "2", "--arena-gib", "2"]}[workload]
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", workload, "--gib", "0.25",
                           "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--avg", str(1 << 20)] + extra,
                          env=env, capture_output=True, text=True, timeout=600)

@@ -204,3 +204,61 @@ def test_ingest_corpus_two_ranks_finds_the_planted_duplicates():
     assert stats["total_bytes"] - stats["unique_bytes"] >= dup_bytes > 0
     frac = 1 - stats["unique_bytes"] / stats["total_bytes"]
     assert 0.2 < frac < 0.6
+
+
+def _ingest_worker_uneven(rank, ws, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from pbs_plus_amd.dist import ingest_corpus
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        eng = _OracleEngine(65536)
+        # three segments over four ranks: one rank gets nothing (an empty shard must not break the collective), the
+        # others get very different byte counts
+        lens = [3 << 20, (1 << 20) + 77, 70000]
+        root = [0, 1, 1]
+        calls = []
+
+        def make_batch(ids):
+            calls.append(list(ids))
+            parts, segs, off = [], [], 0
+            for g in ids:
+                parts.append(eng.O.fill(lens[g], 500 + root[g], 0)[: lens[g]])
+                segs.append((off, lens[g]))
+                off += lens[g]
+            return np.concatenate(parts), segs
+
+        local, stats, allrecs = ingest_corpus(eng, lens, make_batch, max_batch_bytes=2 << 20)
+        q.put((rank, int(local.size), {k: int(v) for k, v in stats.items()}, allrecs.tobytes(), calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ws", [4, 8])
+def test_ingest_corpus_more_ranks_than_segments(ws):
+    """world size 4 and 8 over gloo with 3 segments: empty ranks, uneven shards, one segment larger than the batch limit.
+    Every rank ends with the same global record set and statistics; segment 2's content is a prefix of segment 1's."""
+    import torch.multiprocessing as mp
+
+    from pbs_plus_amd import RECORD_DTYPE
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ingest_worker_uneven, args=(r, ws, port, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(ws))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(1 for g in got if g[1] == 0) == ws - 3          # the ranks without a segment hold no records
+    assert all(g[2] == got[0][2] and g[3] == got[0][3] for g in got)
+    allr = np.frombuffer(got[0][3], dtype=RECORD_DTYPE)
+    assert sorted(set(int(x) for x in allr["segment"])) == [0, 1, 2]
+    st = got[0][2]
+    assert st["total_bytes"] == (3 << 20) + (1 << 20) + 77 + 70000 and st["nrecords"] == allr.size
+    assert st["total_bytes"] - st["unique_bytes"] > 0          # the shared prefix of segments 1 and 2 dedups
