@@ -601,7 +601,7 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
                          "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
         except BaseException as exc:  # noqa: BLE001
             res["batch_path_stream64g" if name == "stream64g" else name] = {"error": repr(exc)}
-    for label, key, producers, gib_steps in (("hostfeed_1_writer", "hostfeed1", 1, 16), ("hostfeed_8_writers", "hostfeed8", 8, 12)):
+    for label, key, producers, gib_steps in (("hostfeed_1_writer", "hostfeed1", 1, 96), ("hostfeed_8_writers", "hostfeed8", 8, 16)):
         if key not in legs:
             continue
         b = copy.copy(a)
@@ -1013,7 +1013,7 @@ def run_batch(a, rank, local_rank, world, ctx):
 
 def load_traffic():
     """HBM bytes per launch / algorithmic bytes, from the committed PMC passes (FETCH_SIZE, gfx950 x2 correction)."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tj = json.load(f)

@@ -298,6 +298,12 @@ int cut_finish(pbsgpu_engine *e, Slot &s, uint64_t *nrec);
 // size every buffer a single-segment cut of up to max_bytes can touch, so that steady-state windows never reallocate
 int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes);
 
+// Caller bytes -> pinned staging. One thread copies ~12 GB/s, the H2D engine moves 57 GB/s: a single writer (the
+// reference drives ONE goroutine per archive, internal/tapeio/converter.go:672-680) was memcpy-bound at 24-28 GiB/s.
+// Large copies are therefore split over a few helper threads of a process-wide pool (started at the first large
+// write; PBSGPU_COPY_THREADS, default 4 incl. the caller, 1 = off). Small writes stay on the caller's thread.
+void parallel_memcpy(void *dst, const void *src, size_t n);
+
 // hash dispatcher (stream.cpp)
 int hd_init(pbsgpu_engine *e);
 void hd_destroy(pbsgpu_engine *e);

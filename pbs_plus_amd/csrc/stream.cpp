@@ -11,7 +11,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <thread>
 
 #include "engine_internal.h"
@@ -27,6 +29,86 @@ using namespace pbse;
 // window the number of concurrent kernels would grow with the ingest rate and exhaust the hardware queues; with
 // shared jobs it is bounded by the lane count while every chunk still starts within one lane-turnaround.
 namespace pbse {
+
+namespace {
+struct CopyPool {
+    struct Job { uint8_t *dst; const uint8_t *src; size_t n; };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job> jobs;
+    size_t pending = 0;
+    std::vector<std::thread> threads;
+    bool stop = false;
+    int nthreads = 0;
+
+    void start(int n) {
+        nthreads = n;
+        for (int i = 0; i < n; ++i)
+            threads.emplace_back([this] {
+                for (;;) {
+                    Job j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_work.wait(lk, [this] { return stop || !jobs.empty(); });
+                        if (stop && jobs.empty()) return;
+                        j = jobs.front();
+                        jobs.pop_front();
+                    }
+                    std::memcpy(j.dst, j.src, j.n);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+}  // namespace
+
+void parallel_memcpy(void *dst, const void *src, size_t n) {
+    static const int want = []() {
+        const char *v = getenv("PBSGPU_COPY_THREADS");
+        return std::min(16, std::max(1, v ? atoi(v) : 4));
+    }();
+    constexpr size_t kMin = 4u << 20;  // below this one thread is as fast as the hand-over
+    if (want <= 1 || n < kMin) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    static CopyPool pool;              // helpers only: the caller copies a slice itself
+    static std::once_flag once;
+    std::call_once(once, [] { pool.start(want - 1); });
+    static std::mutex serial;          // one large copy at a time uses the helpers; concurrent writers fall back to their own thread
+    std::unique_lock<std::mutex> only(serial, std::try_to_lock);
+    if (!only.owns_lock()) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    const size_t parts = (size_t)want;
+    const size_t slice = ((n / parts) + 4095) & ~(size_t)4095;
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    const uint8_t *s = static_cast<const uint8_t *>(src);
+    size_t off = std::min(slice, n);   // [0, off) is the caller's own slice
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        for (size_t o = off; o < n; o += slice) {
+            pool.jobs.push_back(CopyPool::Job{d + o, s + o, std::min(slice, n - o)});
+            pool.pending++;
+        }
+    }
+    pool.cv_work.notify_all();
+    std::memcpy(d, s, off);
+    std::unique_lock<std::mutex> lk(pool.mu);
+    pool.cv_done.wait(lk, [] { return pool.pending == 0; });
+}
 
 constexpr int kHashLanes = 6;  // + 2 copy streams + one stream per payload stream: within the 24 hardware queues for 8 writers
 
@@ -768,7 +850,7 @@ int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
         }
         size_t n = std::min(len, kStreamStage - s->stage_fill);
         n = (size_t)std::min<uint64_t>(n, s->window - s->fill - s->stage_fill);
-        std::memcpy(s->stage[k].as<uint8_t>() + s->stage_fill, p, n);
+        parallel_memcpy(s->stage[k].as<uint8_t>() + s->stage_fill, p, n);
         s->stage_fill += n;
         s->written += n;
         if (s->in_entry) s->entry_left -= std::min<uint64_t>(s->entry_left, n);

@@ -15,10 +15,49 @@ import (
 	"crypto/sha256"
 	"encoding/hex"
 	"encoding/json"
+	"fmt"
 	"os"
+	"reflect"
 
 	"github.com/pbs-plus/pxar/buzhash"
 )
+
+// configFields dumps whatever buzhash.Config really contains (SURVEY.md Appendix E.1/E.2: the field set — min, max,
+// window, mask, break minimum, table — is not visible from pbs-plus). Reflection keeps this compiling whatever the names.
+func configFields(cfg interface{}) map[string]interface{} {
+	out := map[string]interface{}{}
+	v := reflect.ValueOf(cfg)
+	if v.Kind() == reflect.Ptr {
+		v = v.Elem()
+	}
+	if v.Kind() != reflect.Struct {
+		out["value"] = fmt.Sprint(cfg)
+		return out
+	}
+	for i := 0; i < v.NumField(); i++ {
+		f := v.Type().Field(i)
+		if f.PkgPath != "" { // unexported: print what fmt can see
+			out[f.Name] = fmt.Sprintf("%v", v.Field(i))
+			continue
+		}
+		out[f.Name] = v.Field(i).Interface()
+	}
+	return out
+}
+
+// suggestedCase: the payload chunker's suggested boundaries (Appendix E.3). `Feed` = bytes handed to each Scan call
+// (0 = everything that is left): upstream's result depends on it, the engine emulates it with
+// pbsgpu_engine_set_suggested_feed. Adjust newPayloadChunker / Scan to the module's real names; if the module has no
+// payload chunker, delete the suggested cases — that itself answers E.3.
+type suggestedCase struct {
+	Name      string   `json:"name"`
+	Avg       int      `json:"avg"`
+	Seed      uint64   `json:"seed"`
+	Length    uint64   `json:"length"`
+	Suggested []uint64 `json:"suggested"`
+	Feed      int      `json:"feed"`
+	Ends      []uint64 `json:"ends"`
+}
 
 type segSpec struct {
 	Seed   uint64 `json:"seed"`
@@ -100,6 +139,57 @@ func main() {
 			}
 		}
 	}
+	// the module's actual Config for the two production / test averages (closes Appendix E.1 and E.2)
+	cfgDump := map[string]interface{}{}
+	for _, avg := range []int{4096, 4 << 20} {
+		cfg, err := buzhash.NewConfig(avg)
+		if err != nil {
+			panic(err)
+		}
+		cfgDump[fmt.Sprint(avg)] = configFields(cfg)
+	}
+	// suggested boundaries: the LE-u32 counter buffer of upstream's test_suggested_boundary (avg 64 KiB; expected sizes
+	// recalled from upstream: 32768, 110609, 229376, 32768, 262144, 262144, 118767) and a random stream, per feed size
+	var sugg []suggestedCase
+	counter := make([]byte, 1<<20)
+	for i := 0; i < len(counter)/4; i++ {
+		counter[4*i], counter[4*i+1], counter[4*i+2], counter[4*i+3] = byte(i), byte(i>>8), byte(i>>16), byte(i>>24)
+	}
+	for _, feed := range []int{1, 4096, 65536, 0} {
+		for _, in := range []struct {
+			name string
+			data []byte
+			seed uint64
+			sg   []uint64
+		}{
+			{"counter_avg64k", counter, 0, []uint64{32 * 1024, 32 * 1024, 372753, 405521}},
+			{"rand_avg64k", fill(4<<20, 61, 0), 61, []uint64{100000, 150000, 700001, 1 << 20, 3000000}},
+		} {
+			cfg, _ := buzhash.NewConfig(65536)
+			pc := buzhash.NewPayloadChunker(cfg, in.sg) // adjust: upstream feeds boundaries through a channel
+			c := suggestedCase{Name: in.name, Avg: 65536, Seed: in.seed, Length: uint64(len(in.data)), Suggested: in.sg, Feed: feed}
+			pos, base := 0, 0
+			for pos < len(in.data) {
+				take := len(in.data) - pos
+				if feed > 0 && feed < take {
+					take = feed
+				}
+				k := pc.Scan(in.data[pos:pos+take], uint64(base), uint64(pos-base+take)) // (data, chunk base, bytes of the chunk so far)
+				if k == 0 {
+					pos += take
+					continue
+				}
+				pos += k
+				base = pos
+				c.Ends = append(c.Ends, uint64(pos))
+			}
+			if base < len(in.data) {
+				c.Ends = append(c.Ends, uint64(len(in.data)))
+			}
+			sugg = append(sugg, c)
+		}
+	}
 	enc := json.NewEncoder(os.Stdout)
-	_ = enc.Encode(map[string]interface{}{"schema": "pbsgpu-golden-v1", "generator": "github.com/pbs-plus/pxar v0.34.0", "cases": cases})
+	_ = enc.Encode(map[string]interface{}{"schema": "pbsgpu-golden-v2", "generator": "github.com/pbs-plus/pxar v0.34.0",
+		"cases": cases, "config": cfgDump, "suggested": sugg})
 }
