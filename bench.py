@@ -65,7 +65,8 @@ def parse():
                     help="timed steps (default 20; hostfeed 48: its final drain is one chunk chain, ~0.6 s, whatever the length)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="ring",
-                    choices=("ring", "stream64g", "manyfiles", "corpus_dup", "rechunk", "hostfeed", "verify"))
+                    choices=("ring", "ring_manyfiles", "ring_corpus_dup", "stream64g", "manyfiles", "corpus_dup", "rechunk",
+                             "hostfeed", "verify"))
     ap.add_argument("--arena-gib", type=float, default=None, help="ring: device memory of the page arena (default: free HBM - 12 GiB)")
     ap.add_argument("--ring-streams", type=int, default=4, help="ring: files in flight at once")
     ap.add_argument("--ring-sha-cus", type=int, default=0, help="ring: CUs of the SHA-256 service (0 = library default)")
@@ -89,7 +90,7 @@ def parse():
     ap.add_argument("--spread-points", type=int, default=40, help="restart points per resident slot")
     ap.add_argument("--no-extras", action="store_true",
                     help="default workload only: skip the short configs[2..4] / host-fed legs folded into the line")
-    ap.add_argument("--extras", default="batch,manyfiles,corpus_dup,rechunk,hostfeed1,hostfeed8",
+    ap.add_argument("--extras", default="batch,manyfiles,corpus_dup,rechunk,ring_manyfiles,ring_corpus_dup,hostfeed1,hostfeed8",
                     help="which short legs the default line carries (they run when --gib is left at its default, or when "
                          "--extras-gib names a reduced shape)")
     ap.add_argument("--extras-gib", type=float, default=None, help="bytes per device batch of the short legs (tests)")
@@ -548,6 +549,10 @@ def main():
             if world == 1 and not a.no_extras and (a.gib is None or a.extras_gib is not None):
                 out["workloads"] = extras(_copy_args(a, workload="stream64g"), rank, local_rank, world, ctx, with_batch=True)
             print(json.dumps(out), flush=True)
+    elif a.workload in ("ring_manyfiles", "ring_corpus_dup"):
+        out = ring_files_run(a, rank, local_rank, world, ctx, a.workload[5:])
+        if rank == 0:
+            print(json.dumps(out), flush=True)
     elif a.workload == "hostfeed":
         outj = hostfeed_run(a, rank, local_rank, world, ctx)
         if rank == 0:
@@ -599,8 +604,26 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
                          "records_match_gpu": o.get("cpu_baseline", {}).get("records_match_gpu"),
                          "records_checked": o.get("cpu_baseline", {}).get("records_checked"),
                          "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
+            if name == "stream64g":   # one 64 GiB file alone through the batch path (scan on the whole chip)
+                res["batch_path_stream64g"]["single_file_ms"] = o.get("serial_step_ms", {}).get("total")
         except BaseException as exc:  # noqa: BLE001
             res["batch_path_stream64g" if name == "stream64g" else name] = {"error": repr(exc)}
+    for name in ("ring_manyfiles", "ring_corpus_dup"):
+        if name not in legs or not with_batch:
+            continue
+        b = copy.copy(a)
+        b.workload, b.steps, b.warmup, b.gib, b.file_mib = name, 6, 1, a.extras_gib, a.extras_file_mib
+        b.cpu_sample_gib, b.brief = (0.25 if a.extras_gib is None else a.extras_gib / 8), True
+        t0 = time.perf_counter()
+        try:
+            o = ring_files_run(b, rank, local_rank, world, ctx, name[5:])
+            res[name] = {"value": o["value"], "unit": o["unit"], "steps": o["steps"], "ms_per_step": o["ms_per_step"],
+                         "workload": o["config"]["workload"], "feed_phase": o["roofline"]["feed_phase"],
+                         "records_match_gpu": o.get("cpu_baseline", {}).get("records_match_gpu"),
+                         "records_checked": o.get("cpu_baseline", {}).get("records_checked"),
+                         "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
+        except BaseException as exc:  # noqa: BLE001
+            res[name] = {"error": repr(exc)}
     for label, key, producers, gib_steps in (("hostfeed_1_writer", "hostfeed1", 1, 96), ("hostfeed_8_writers", "hostfeed8", 8, 16)):
         if key not in legs:
             continue
@@ -703,6 +726,16 @@ def ring_run(a, rank, local_rank, world, ctx):
         rc = torch.tensor([ctx.rec_cap], dtype=torch.int64, device=ctx.comm_dev)
         ctx.dist.all_reduce(rc, op=ctx.dist.ReduceOp.MAX)
         ctx.rec_cap = int(rc.item())
+    if ctx.dist is not None:
+        # first contact of the digest-set reduce BEFORE the persistent service starts: RCCL's lazy channel buffers, torch's
+        # communication tensors and the engine's dedup work buffers all take their final size here (at the agreed record
+        # capacity), so nothing inside the timed region allocates, frees or waits for the whole device
+        from pbs_plus_amd.dist import global_dedup
+        dummy = np.zeros(ctx.rec_cap, dtype=pbs_plus_amd.RECORD_DTYPE)
+        dummy["digest"][:, :8] = np.arange(ctx.rec_cap, dtype=np.uint64).view(np.uint8).reshape(-1, 8)
+        dummy["size"] = 1
+        global_dedup(eng, dummy, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
+        ctx.dist.barrier()
     if a.warmup:
         run_files(a.warmup, False)
     ring.quiesce()
@@ -800,6 +833,156 @@ def ring_run(a, rank, local_rank, world, ctx):
             out["results"] = extra
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = ring_cpu_baseline(a, kept, single, file_bytes, kind, seed_of)
+    ring.close()
+    eng.close()
+    return out
+
+
+def ring_files_run(a, rank, local_rank, world, ctx, mode):
+    """BASELINE.json configs[2] / configs[3] through the PAGE RING: every 64 MiB file (or corpus segment) is its own ring
+    stream — the many-small-stream packing the ring exists for. A step = `files_per_step` files (128 GiB); the files of
+    all timed steps flow through the ring back to back (pages are recycled as they are read), then the ring drains once.
+    mode "manyfiles": entropy class = file % 4; mode "corpus_dup": 40 % of the segments are exact copies of an earlier
+    one (the copy carries the original's generator seed), duplicate bytes found by the device dedup vs planted."""
+    import pbs_plus_amd
+    from pbs_plus_amd import buzhash
+
+    cfg = buzhash.NewConfig(a.avg)
+    eng = pbs_plus_amd.Engine(cfg, device=local_rank, inflight=1)
+    fbytes = int(a.file_mib * MiB) & ~15
+    per_step = max(1, int((128.0 if a.gib is None else a.gib) * GiB) // fbytes)
+    arena = 0 if a.arena_gib is None else int(a.arena_gib * GiB)
+    feeding = max(8, a.ring_streams * 8)
+    ring = pbs_plus_amd.PageRing(eng, arena_bytes=arena, max_streams=4096, sha_cus=a.ring_sha_cus, round_pages=a.ring_round_pages)
+    total_files = per_step * (a.steps + a.warmup)
+    root = dup_roots(per_step * a.steps, a.seed + 4) if mode == "corpus_dup" else None
+
+    def spec(g):
+        """(seed, kind) of global file index g (g < 0: warm-up files)"""
+        if mode == "corpus_dup" and g >= 0:
+            return a.seed + 104729 * int(root[g]) + 5 + 1000003 * rank, 0
+        return a.seed + 7919 * (g + 10 ** 6 * (rank + 1)) + 1, ((g % 4) if mode == "manyfiles" else 0)
+
+    quota = 4 * int(ring.page_bytes)
+    recs_of = {}
+
+    def run(first, count, keep):
+        nxt, done, active, t_last = first, 0, {}, time.perf_counter()
+        marks.clear()
+        while done < count:
+            nfeed = sum(1 for st in active.values() if st[1])
+            while nxt < first + count and nfeed < feeding and len(active) < 4000:
+                sid = ring.open()
+                active[sid] = [nxt, fbytes, []]
+                nxt += 1
+                nfeed += 1
+            for sid, st in active.items():
+                if st[1]:
+                    seed, kind = spec(st[0])
+                    want = min(st[1], quota)
+                    st[1] -= ring.fill(sid, seed, kind, want, final=(want == st[1]))
+            ring.pump()
+            if nxt == first + count and "t_fed" not in marks and not any(st[1] for st in active.values()):
+                marks["t_fed"] = time.perf_counter()
+            recs, fin = ring.poll_any()
+            if recs.size:
+                t_last = time.perf_counter()
+                if keep:
+                    for sid in np.unique(recs["segment"]):
+                        active[int(sid)][2].append(recs[recs["segment"] == sid])
+            for sid in fin:
+                g, _, parts = active.pop(int(sid))
+                ring.close_stream(int(sid))
+                if keep:
+                    r = np.concatenate(parts) if parts else np.zeros(0, dtype=pbs_plus_amd.RECORD_DTYPE)
+                    r["segment"] = 0
+                    recs_of[g] = r
+                done += 1
+            if time.perf_counter() - t_last > 60:
+                raise SystemExit(f"ring made no progress for 60 s: {ring.stats()}")
+
+    marks = {}
+    if a.warmup:
+        run(-per_step * a.warmup, per_step * a.warmup, False)
+    ring.quiesce()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(0, per_step * a.steps, True)
+    t_fed = marks.get("t_fed")
+    ring.quiesce()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st1 = ring.stats()
+    total_bytes = float(per_step * a.steps) * fbytes
+    out = {
+        "metric": "GiB/s ingested through CDC+SHA-256", "value": round(total_bytes / GiB / elapsed, 2), "unit": "GiB/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic (generated on device page by page; one ring stream per file)",
+        "config": {"workload": (f"{per_step} x {fbytes / MiB:g} MiB files per step through the page ring, one stream per file "
+                                + ("(entropy class = file % 4; BASELINE.json configs[2])" if mode == "manyfiles" else
+                                   "(40 % of the segments exact copies of an earlier one, device dedup over the pass; "
+                                   "BASELINE.json configs[3])")),
+                   "files_per_step": per_step, "file_bytes": fbytes, "streams_feeding": feeding,
+                   "resident_bytes_per_gpu": int(st1["pages_total"]) * int(st1["page_bytes"])},
+        "roofline": {"kernel": "k_sha256_pair<RingSource,false>", "bound": "valu",
+                     "achieved": round(float(st1["service_bytes_last"]) / max(float(st1["service_ms_last"]), 1e-9) / 1e6, 1),
+                     "peak": round(SHA_VALU_GBS, 1), "unit": "GB/s",
+                     "frac": round(float(st1["service_bytes_last"]) / max(float(st1["service_ms_last"]), 1e-9) / 1e6 / SHA_VALU_GBS, 4),
+                     "traffic": None,
+                     "feed_phase": None if t_fed is None else {"seconds": round(t_fed - t0, 4),
+                                                               "GiBps": round(total_bytes / GiB / max(t_fed - t0, 1e-9), 1),
+                                                               "drain_seconds": round(elapsed - (t_fed - t0), 4)}},
+    }
+    if mode == "corpus_dup":
+        allr = np.concatenate([recs_of[g] for g in sorted(recs_of)])
+        _, stats = eng.dedup(allr)
+        _, first = np.unique(root, return_index=True)
+        tb = max(int(stats["total_bytes"]), 1)
+        out["results"] = {"dedup": {"records": int(stats["nrecords"]), "unique": int(stats["nunique"]),
+                                    "duplicate_bytes_frac": round(1.0 - int(stats["unique_bytes"]) / tb, 4),
+                                    "expected_duplicate_frac": round(1.0 - len(first) / len(root), 4)}}
+    if not a.no_cpu_baseline:
+        # oracle on whole files sampled uniformly over the timed files (regenerated from their seeds), 32 threads
+        from oracle import oracle as O
+        O.build()
+        ocfg = O.new_config(a.avg)
+        nsamp = max(4, min(len(recs_of), int(a.cpu_sample_gib * GiB * 8 / fbytes)))
+        ids = sorted(recs_of)[:: max(1, len(recs_of) // nsamp)][:nsamp]
+        res, lock = {"ok": True, "records": 0, "bad": None}, threading.Lock()
+
+        def check(g):
+            seed, kind = spec(g)
+            w = O.chunk_and_digest(ocfg, O.fill(fbytes, seed, kind), [(0, fbytes)], impl=1)
+            r = recs_of[g]
+            same = bool(r.size == w.size and np.array_equal(r["end"], w["end"]) and np.array_equal(r["digest"], w["digest"]))
+            with lock:
+                res["records"] += int(w.size)
+                if not same and res["ok"]:
+                    res["ok"], res["bad"] = False, int(g)
+
+        t1 = time.perf_counter()
+        it, itl = iter(ids), threading.Lock()
+
+        def worker():
+            while True:
+                with itl:
+                    g = next(it, None)
+                if g is None:
+                    return
+                check(g)
+        ths = [threading.Thread(target=worker) for _ in range(max(1, min(32, os.cpu_count() or 1)))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t1
+        tiles = all(int(r["end"][-1]) == fbytes and int(r["size"].astype(np.int64).sum()) == fbytes for r in recs_of.values())
+        out["cpu_baseline"] = {"value": round(len(ids) * fbytes / GiB / dt, 3), "unit": "GiB/s", "cores": len(ths), "kind": "port",
+                               "sample": f"{len(ids)} whole files spread over the {len(recs_of)} timed files, regenerated from "
+                                         f"their seeds, oracle chunk_and_digest on {len(ths)} threads",
+                               "records_match_gpu": bool(res["ok"] and tiles), "records_checked": res["records"],
+                               "first_bad_file": res["bad"], "every_file_tiled_by_its_records": bool(tiles)}
     ring.close()
     eng.close()
     return out

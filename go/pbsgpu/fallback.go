@@ -103,6 +103,7 @@ func (r *Ring) Commit(uint32, uint64, bool) error                               
 func (r *Ring) FillSynthetic(uint32, uint64, uint32, uint64, bool) (uint64, error) { return 0, ErrNotBuilt }
 func (r *Ring) Pump() error                                                      { return ErrNotBuilt }
 func (r *Ring) Poll(uint32, int) ([]ChunkInfo, bool, error)                      { return nil, false, ErrNotBuilt }
+func (r *Ring) PollAny(int, int) ([]ChunkInfo, []uint32, error)                  { return nil, nil, ErrNotBuilt }
 func (r *Ring) CloseStream(uint32) error                                         { return ErrNotBuilt }
 func (r *Ring) Quiesce() error                                                   { return ErrNotBuilt }
 func (r *Ring) Stats() (RingStats, error)                                        { return RingStats{}, ErrNotBuilt }

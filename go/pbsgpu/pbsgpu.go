@@ -706,6 +706,27 @@ func (r *Ring) Poll(stream uint32, max int) (recs []ChunkInfo, done bool, err er
 	return fromRecords(buf, int(n)), fin != 0, nil
 }
 
+// PollAny returns finished entries of ANY open stream (Segment = stream id, each stream's entries in order) and the ids
+// of the streams that have just handed out their last entry — for jobs with one stream per file.
+func (r *Ring) PollAny(max, maxFinished int) (recs []ChunkInfo, finished []uint32, err error) {
+	defer runtime.KeepAlive(r)
+	if max <= 0 || maxFinished <= 0 {
+		return nil, nil, errors.New("pbsgpu: PollAny(max <= 0)")
+	}
+	buf := make([]C.pbsgpu_record, max)
+	fin := make([]C.uint32_t, maxFinished)
+	var n C.uint64_t
+	var nf C.uint32_t
+	if err = check(C.pbsgpu_ring_poll_any(r.h, &buf[0], C.uint64_t(max), &n, &fin[0], C.uint32_t(maxFinished), &nf), "ring_poll_any"); err != nil {
+		return nil, nil, err
+	}
+	finished = make([]uint32, int(nf))
+	for i := range finished {
+		finished[i] = uint32(fin[i])
+	}
+	return fromRecords(buf, int(n)), finished, nil
+}
+
 // CloseStream releases a finished, fully polled stream's slot.
 func (r *Ring) CloseStream(stream uint32) error {
 	defer runtime.KeepAlive(r)

@@ -310,6 +310,12 @@ int pbsgpu_ring_pump(pbsgpu_ring *ring);
 /* Up to cap finished records of the stream, in stream order; *finished = 1 once the stream has ended and every record
  * has been handed out. */
 int pbsgpu_ring_poll(pbsgpu_ring *ring, uint32_t stream, pbsgpu_record *out, uint64_t cap, uint64_t *n, int *finished);
+/* The same for ANY open stream in one call (each stream's records in its own order, `segment` = stream id): for callers
+ * that keep hundreds or thousands of short streams open — one per file of a many-file job (BASELINE.json configs[2]) —
+ * and cannot ask each of them after every pump. Streams that have ended and handed out their last record are listed
+ * once in `finished` (up to fcap per call); close them afterwards. */
+int pbsgpu_ring_poll_any(pbsgpu_ring *ring, pbsgpu_record *out, uint64_t cap, uint64_t *n, uint32_t *finished, uint32_t fcap,
+                         uint32_t *nfinished);
 /* Release a finished, fully polled stream's slot. */
 int pbsgpu_ring_close(pbsgpu_ring *ring, uint32_t stream);
 /* Wait until everything enqueued is hashed and stop the service kernel (the device is then idle as far as the ring is

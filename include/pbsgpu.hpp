@@ -320,5 +320,89 @@ class PayloadWriter {
     Sink sink_;
 };
 
+// Several archives at once on bytes that are (or arrive) in device memory: the page ring (pbsgpu_ring_*). One writer
+// per archive in the reference (commit_reuse.go:457, converter.go:836); here each archive is a stream of the ring and
+// the sink receives its (End, Digest) entries in stream order. One thread drives a PageRing.
+class PageRing {
+  public:
+    using Sink = std::function<void(uint32_t stream, const datastore::ChunkInfo &, uint32_t size)>;
+
+    static Result<std::unique_ptr<PageRing>> New(std::shared_ptr<Engine> eng, Sink sink, const pbsgpu_ring_options *opt = nullptr) {
+        Result<std::unique_ptr<PageRing>> r;
+        pbsgpu_ring *h = nullptr;
+        const int st = pbsgpu_ring_create(eng->handle(), opt, &h);
+        if (st != PBSGPU_OK) {
+            r.err = errorf("ring create", st);
+            return r;
+        }
+        r.value.reset(new PageRing(std::move(eng), h, std::move(sink)));
+        return r;
+    }
+    ~PageRing() { pbsgpu_ring_destroy(r_); }
+
+    Result<uint32_t> Open() {
+        Result<uint32_t> r;
+        const int st = pbsgpu_ring_open(r_, &r.value);
+        if (st != PBSGPU_OK) r.err = errorf("ring open", st);
+        return r;
+    }
+    // the stream's next page (device pointer, capacity); value.first == nullptr when no page is free right now
+    Result<std::pair<void *, uint64_t>> Reserve(uint32_t stream) {
+        Result<std::pair<void *, uint64_t>> r;
+        r.value = {nullptr, 0};
+        const int st = pbsgpu_ring_reserve(r_, stream, &r.value.first, &r.value.second);
+        if (st != PBSGPU_OK && st != PBSGPU_E_BUSY) r.err = errorf("ring reserve", st);
+        if (st == PBSGPU_E_BUSY) r.value = {nullptr, 0};
+        return r;
+    }
+    std::string Commit(uint32_t stream, uint64_t nbytes, bool final) {
+        const int st = pbsgpu_ring_commit(r_, stream, nbytes, final ? 1 : 0);
+        return st == PBSGPU_OK ? std::string() : errorf("ring commit", st);
+    }
+    // synthetic producer (benchmarks / tests): bytes accepted
+    Result<uint64_t> FillSynthetic(uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, bool final) {
+        Result<uint64_t> r;
+        const int st = pbsgpu_ring_fill(r_, stream, seed, kind, nbytes, final ? 1 : 0, &r.value);
+        if (st != PBSGPU_OK) r.err = errorf("ring fill", st);
+        return r;
+    }
+    // enqueue what has been committed, deliver finished entries of `stream` to the sink; *done: the stream has ended
+    // and everything has been delivered
+    std::string Pump(uint32_t stream, bool *done) {
+        int st = pbsgpu_ring_pump(r_);
+        if (st != PBSGPU_OK) return errorf("ring pump", st);
+        pbsgpu_record buf[256];
+        for (;;) {
+            uint64_t n = 0;
+            int fin = 0;
+            st = pbsgpu_ring_poll(r_, stream, buf, 256, &n, &fin);
+            if (st != PBSGPU_OK) return errorf("ring poll", st);
+            for (uint64_t i = 0; i < n; ++i) {
+                datastore::ChunkInfo ci;
+                ci.End = buf[i].end;
+                std::memcpy(ci.Digest_.data(), buf[i].digest, 32);
+                sink_(stream, ci, buf[i].size);
+            }
+            if (done) *done = fin != 0;
+            if (n < 256) return {};
+        }
+    }
+    std::string CloseStream(uint32_t stream) {
+        const int st = pbsgpu_ring_close(r_, stream);
+        return st == PBSGPU_OK ? std::string() : errorf("ring close", st);
+    }
+    std::string Quiesce() {
+        const int st = pbsgpu_ring_quiesce(r_);
+        return st == PBSGPU_OK ? std::string() : errorf("ring quiesce", st);
+    }
+
+  private:
+    PageRing(std::shared_ptr<Engine> eng, pbsgpu_ring *r, Sink sink) : eng_(std::move(eng)), r_(r), sink_(std::move(sink)) {}
+    PageRing(const PageRing &) = delete;
+    std::shared_ptr<Engine> eng_;
+    pbsgpu_ring *r_;
+    Sink sink_;
+};
+
 }  // namespace transfer
 }  // namespace pbsgpu

@@ -159,6 +159,7 @@ SYMBOLS = {
     "pbsgpu_ring_fill": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, _U64P]),
     "pbsgpu_ring_pump": (C.c_int, [_P]),
     "pbsgpu_ring_poll": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, _U64P, C.POINTER(C.c_int)]),
+    "pbsgpu_ring_poll_any": (C.c_int, [_P, _P, C.c_uint64, _U64P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "pbsgpu_ring_close": (C.c_int, [_P, C.c_uint32]),
     "pbsgpu_ring_quiesce": (C.c_int, [_P]),
     "pbsgpu_ring_get_stats": (C.c_int, [_P, C.POINTER(RingStats)]),

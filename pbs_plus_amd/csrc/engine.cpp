@@ -205,6 +205,7 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
         sg.feed = e->sugg_feed.load(std::memory_order_relaxed);
         sg.absolute = e->sugg_feed_abs.load(std::memory_order_relaxed);
         sg.origin = s.sugg_origin;
+        sg.open_end = s.sugg_open_end ? 1u : 0u;
     }
     // one long stream, no suggested boundaries: follow the cut chain by pointer doubling (one workgroup, ~20 rounds)
     // instead of walking it chunk by chunk on one wave (4.6 ms per 64 GiB, 11 ms next to SHA waves)
@@ -343,6 +344,7 @@ int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32
     s.nseg = nseg;
     s.nsugg = 0;
     s.sugg_origin = sg ? sg->origin : 0;
+    s.sugg_open_end = sg ? sg->open_end : false;
     if (sg && sg->offsets && sg->index) {
         if (sg->index[0] != 0) return PBSGPU_E_INVALID;
         for (uint32_t i = 0; i < nseg; ++i) {

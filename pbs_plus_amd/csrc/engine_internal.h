@@ -167,6 +167,7 @@ struct Slot {
     uint64_t rec_cap = 0;
     uint64_t nsugg = 0;     // suggested offsets staged for this batch (0 = none)
     uint64_t sugg_origin = 0;
+    bool sugg_open_end = false;
     bool host_submit = false;
     uint32_t retries = 0;
     uint64_t nrec = 0, ncand = 0;
@@ -277,6 +278,7 @@ struct SuggestedHost {  // caller's suggested boundaries: offsets[index[s] .. in
     const uint64_t *offsets = nullptr;
     const uint32_t *index = nullptr;
     uint64_t origin = 0;  // stream offset of the (single) segment's first byte: only the absolute feed grid needs it
+    bool open_end = false;  // the segment ends where the bytes seen so far end, not where the stream ends
 };
 
 int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint32_t cap,

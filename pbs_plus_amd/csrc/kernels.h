@@ -82,10 +82,14 @@ struct Suggested {
     uint64_t feed = 1;
     uint64_t origin = 0;
     uint32_t absolute = 0;
+    // the segment's end is NOT the stream's end (a window of the stream writer): a known boundary that lies beyond the
+    // bytes seen so far but in the same reader buffer as a hash cut still pre-empts that cut — the walk stops there and
+    // the rest is the open chunk the next window re-examines
+    uint32_t open_end = 0;
 };
 struct SuggFeed {
     uint64_t feed, origin;
-    uint32_t absolute;
+    uint32_t absolute, open_end;
 };
 
 // min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
@@ -167,15 +171,29 @@ struct alignas(64) RingCtl {   // device memory, one 64-byte line
         };
         unsigned long long tail_stop;  // ... read together as one 64-bit word by the service's lanes
     };
+    union {
+        struct {
+            uint32_t ltail;    // LONG-chunk queue: positions < ltail are published
+            uint32_t lhead;    // ... positions < lhead have been taken (CAS: never runs ahead of ltail)
+        };
+        unsigned long long lq;
+    };
     uint32_t head;         // next queue position to hand out
     uint32_t free_count;   // pages reported free so far
     uint32_t error;        // sticky: a cut round overflowed a capacity (ring.cpp reports PBSGPU_E_DENSITY)
-    uint32_t pad[11];
+    uint32_t pad[9];
 };
 struct RingSource {
     static constexpr bool kRing = true;
     const uint4 *desc;         // ring of positions, 2 x uint4 each: {p1.lo, p1.hi, len, len1} {p2v.lo, p2v.hi, cell, pages}
     uint32_t qmask;            // positions - 1 (power of two)
+    // Chunks of at least `long_bytes` go through a second, smaller queue that idle lanes look at FIRST: a max-size chunk
+    // hashes for ~0.45 s on one lane, so the later it starts the longer the ring's drain (bench: the last such chunk used
+    // to start behind ~0.3 s of queued short chunks). Lanes never wait on this queue (compare-and-swap on lhead only
+    // while lhead < ltail); a lane may take a long chunk while its claim on the main queue stays valid.
+    const uint4 *ldesc;
+    uint32_t lmask;
+    uint32_t long_bytes;       // 0 = no second queue
     RingCtl *ctl;
     uint8_t *cells;            // mapped pinned: 64-byte record cells {end, digest[32], segment, size, flag, pad}
     uint32_t *pending;         // per physical page: chunks not yet loaded + holds of open chunks
@@ -186,7 +204,7 @@ struct RingSource {
 
 
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)
-enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsTileq = 6 /* u64 */, kRsCount = 10 };
+enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsTileq = 6 /* u64 */, kRsCount = 10 };
 
 // One physical page of a round (host-written, mapped pinned memory; read by the round's kernels).
 struct RingPage {
@@ -247,6 +265,7 @@ struct RingRound {
     RingStreamState *streams;
     RingSource q;
     uint4 *desc_w;             // writable view of q.desc
+    uint4 *ldesc_w;            // ... and of q.ldesc
     // work buffers (one set: rounds run in order on one HIP stream)
     uint32_t *scalars;         // SC_* layout of engine_internal.h
     uint32_t *tile_cnt, *tile_off, *tile_slots, *scan_tmp;

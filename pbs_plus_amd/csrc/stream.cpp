@@ -621,12 +621,15 @@ int stream_flush(pbsgpu_stream *s, bool final) {
     }
     // suggested boundaries that can still matter: behind the open chunk's start, inside this window
     while (!s->suggested.empty() && s->suggested.front() <= s->base) s->suggested.pop_front();
+    // (with a reader-buffer rule in force — pbsgpu_engine_set_suggested_feed — also the announced boundaries up to one
+    // max chunk BEYOND the window: one of them may pre-empt a hash cut inside the window, see Suggested::open_end)
+    const uint64_t look = e->sugg_feed.load(std::memory_order_relaxed) > 1 ? (uint64_t)e->cfg.max : 0;
     for (uint64_t b : s->suggested) {
-        if (b > s->base + total) break;
+        if (b > s->base + total + look) break;
         pc.sugg_rel.push_back(b - s->base);
     }
     const uint32_t sidx[2] = {0u, (uint32_t)pc.sugg_rel.size()};
-    SuggestedHost sg{pc.sugg_rel.data(), sidx, s->base};
+    SuggestedHost sg{pc.sugg_rel.data(), sidx, s->base, !final};
     pbsgpu_segment seg{0, total};
     pc.ctx = s->cut_next;
     s->cut_next ^= 1;
@@ -751,8 +754,9 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     s->headroom = ((uint64_t)e->cfg.max + 255) & ~255ull;
     s->devcap = (size_t)window_bytes + (size_t)s->headroom + 256;
     // Ring limit. Chunks of up to 16 MiB hash for ~0.45 s, so a stream needs (ingest rate x ~0.6 s) of windows in
-    // flight: 16 GiB carries ~25 GiB/s. Buffers are allocated on demand — a slow producer never grows its ring.
-    size_t budget_gib = 16;
+    // flight: 32 GiB carries ~50 GiB/s, the H2D rate (16 GiB held one fast writer at 26 GiB/s). Buffers are allocated on
+    // demand — a slow producer never grows its ring — and a failed allocation is back-pressure, not an error.
+    size_t budget_gib = 32;
     if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) budget_gib = (size_t)std::max(1L, atol(v));
     size_t nb = (size_t)((budget_gib << 30) / s->devcap);
     s->max_bufs = std::min<size_t>(std::max<size_t>(nb, 4), 256);

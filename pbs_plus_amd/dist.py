@@ -104,7 +104,9 @@ def global_dedup(engine, local_records: np.ndarray, device=None, group=None, cap
         dup, stats = engine.dedup(np.zeros(0, dtype=RECORD_DTYPE))
         return dup, stats, (np.zeros(0, dtype=RECORD_DTYPE) if want_records else None)
     packed = torch.cat([rows[r, 16:16 + int(counts[r]) * isz] for r in range(ws) if counts[r]])
-    torch.cuda.synchronize(dev)               # the engine's own HIP stream reads the tensor next
+    # the engine's own HIP stream reads the tensor next: wait for THIS stream only. (A device-wide synchronize would
+    # never return while a page ring's persistent SHA-256 service is running.)
+    torch.cuda.current_stream(dev).synchronize()
     dup, stats = engine.dedup_device(packed.data_ptr(), total)
     allrecs = packed.cpu().numpy().view(RECORD_DTYPE).copy() if want_records else None
     return dup, stats, allrecs

@@ -488,6 +488,16 @@ class PageRing:
         check(self._L.pbsgpu_ring_poll(self._h, stream, out.ctypes.data, cap, C.byref(n), C.byref(fin)), "ring_poll")
         return out[: n.value], bool(fin.value)
 
+    def poll_any(self, cap: int = 16384, fcap: int = 4096):
+        """(records of any open stream with `segment` = stream id, ids of the streams that have just finished)"""
+        if getattr(self, "_any_buf", None) is None or self._any_buf.size < cap:
+            self._any_buf = np.zeros(cap, dtype=RECORD_DTYPE)
+            self._fin_buf = np.zeros(fcap, dtype=np.uint32)
+        n, nf = C.c_uint64(), C.c_uint32()
+        check(self._L.pbsgpu_ring_poll_any(self._h, self._any_buf.ctypes.data, cap, C.byref(n), self._fin_buf.ctypes.data,
+                                           min(fcap, self._fin_buf.size), C.byref(nf)), "ring_poll_any")
+        return self._any_buf[: n.value].copy(), self._fin_buf[: nf.value].copy()
+
     def close_stream(self, stream: int) -> None:
         check(self._L.pbsgpu_ring_close(self._h, stream), "ring_close")
 

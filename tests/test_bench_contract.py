@@ -178,6 +178,19 @@ class _FakeRing:
         st["given"] = hi
         return st["recs"][lo:hi].copy(), hi == st["recs"].size
 
+    def poll_any(self, cap=16384, fcap=4096):
+        parts, fin = [], []
+        for sid in list(self.streams):
+            recs, done = self.poll(sid, cap)
+            if recs.size:
+                recs = recs.copy()
+                recs["segment"] = sid
+                parts.append(recs)
+            if done and not self.streams[sid].get("reported"):
+                self.streams[sid]["reported"] = True
+                fin.append(sid)
+        return (np.concatenate(parts) if parts else np.zeros(0, dtype=st_dtype())), np.array(fin, dtype=np.uint32)
+
     def close_stream(self, sid):
         assert self.streams[sid]["given"] == self.streams[sid]["recs"].size
         del self.streams[sid]
@@ -352,6 +365,7 @@ def _patched_main(argv):
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.device_count = lambda: 1
     pbs_plus_amd.Engine = _FakeEngine
+    pbs_plus_amd.PageRing = _FakeRing
     sys.argv = ["bench.py"] + list(argv)
     bench.main()
 
@@ -406,3 +420,30 @@ def test_bench_corpus_dup_two_ranks_digest_set_reduce(scaling):
         assert d["config"]["corpus_segments"] == 64 and d["config"]["segments_per_gpu"] == 32
     else:
         assert d["config"]["corpus_segments"] == 128 and d["config"]["segments_per_gpu"] == 64
+
+
+def test_bench_ring_two_ranks_gloo_reduces_in_step_order():
+    """The DEFAULT workload with world size 2 over gloo: files may finish in any order on a rank, the per-file digest-set
+    reduce is issued in step order on every rank (a collective sequence that differs between ranks would hang), the
+    first contact of the reduce happens before the ring starts."""
+    d = _two_ranks(["--gpus", "2", "--gib", str(12 / 1024), "--avg", "65536", "--steps", "5", "--warmup", "1",
+                    "--ring-streams", "3", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "page ring" in d["config"]["path"] and "2 rank" in d["config"]["parallelism"]
+    st = d["results"]["dedup_last_step"]
+    assert st["nrecords"] > 0 and st["nunique"] == st["nrecords"]        # two different files: no shared chunks
+
+
+@pytest.mark.parametrize("mode", ["ring_manyfiles", "ring_corpus_dup"])
+def test_bench_many_files_through_the_ring(monkeypatch, mode):
+    """configs[2] / configs[3] with one ring stream per file (poll_any): whole sampled files vs the oracle, every file tiled
+    by its records, planted duplicates found exactly."""
+    _patch(monkeypatch)
+    d = _run(monkeypatch, ["--workload", mode, "--gib", str(12 / 1024), "--file-mib", "0.5", "--avg", "16384", "--steps", "3",
+                           "--warmup", "1", "--cpu-sample-gib", str(2 / 1024)])
+    assert d["steps"] == 3 and d["value"] > 0 and d["config"]["files_per_step"] == 24
+    c = d["cpu_baseline"]
+    assert c["records_match_gpu"] is True and c["every_file_tiled_by_its_records"] is True and c["records_checked"] > 50
+    if mode == "ring_corpus_dup":
+        dd = d["results"]["dedup"]
+        assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and dd["expected_duplicate_frac"] > 0.15

@@ -238,3 +238,55 @@ def test_bench_ring_workload_small_scale(gpu_lib, extra):
     assert c["whole_file_restart_points"]["max_offset"] == d["config"]["bytes_per_step"]
     assert d["roofline"]["service_launch_bytes"] == 5 * d["config"]["bytes_per_step"]
     assert d["value"] > 2 and d["config"]["distinct_data_per_step"] is True   # (7.5 GiB + a 0.6 s drain: no throughput claim here)
+
+
+def test_cpp_mirror_page_ring(gpu_lib, O, tmp_path):
+    """include/pbsgpu.hpp's transfer::PageRing driven by a C++ program (tests/native/test_cpp_ring.cpp): three streams,
+    entries delivered through the sink, compared with the oracle."""
+    exe = str(tmp_path / "test_cpp_ring")
+    libdir = os.path.join(ROOT, "pbs_plus_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "tests", "native", "test_cpp_ring.cpp"),
+                    "-L" + libdir, "-lpbsgpu", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "cpp-ring-ok" in out.stdout, out.stdout[-500:] + out.stderr[-1000:]
+    jobs = [(71, 0, 5 * 262144 + 777), (72, 3, 9 * 262144), (73, 4, 100)]
+    want = _oracle_records(O, 65536, jobs)
+    got = {0: [], 1: [], 2: []}
+    for ln in out.stdout.splitlines():
+        if ln.startswith("C "):
+            _, j, end, size, dig = ln.split()
+            got[int(j)].append((int(end), int(size), dig))
+    for j in range(3):
+        assert got[j] == [(int(r["end"]), int(r["size"]), bytes(r["digest"]).hex()) for r in want[j]], j
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ring_randomized_programs(gpu_lib, O, seed, monkeypatch):
+    """Random programs over the ring: 10-40 streams of random lengths (empty, 1 byte, around the window, around one and
+    several pages, up to a few MiB) and data kinds through a SMALL arena (heavy page recycling, streams sharing rounds),
+    1-6 streams fed at a time, with and without the long-chunk queue — every stream bit-exact vs the oracle."""
+    from pbs_plus_amd import PageRing
+
+    rng = np.random.default_rng(1000 + seed)
+    avg = [4096, 65536][seed % 2]
+    page = 65536 if avg == 4096 else 262144
+    npages = int(rng.integers(12, 60))
+    if seed % 3 == 0:
+        monkeypatch.setenv("PBSGPU_RING_LONG_BYTES", str(avg * 2))
+    eng = _engine(avg)
+    ring = PageRing(eng, arena_bytes=npages * (page + 256), page_bytes=page, max_streams=16, sha_cus=int(rng.integers(2, 24)),
+                    round_pages=int(rng.integers(2, 12)))
+    special = [0, 1, 63, 64, 65, page - 1, page, page + 1, 3 * page, 3 * page + 5, avg * 4, avg * 4 + 1]
+    jobs = []
+    for i in range(int(rng.integers(10, 40))):
+        n = int(rng.choice(special)) if rng.random() < 0.4 else int(rng.integers(1, 12 * page))
+        jobs.append((5000 + 100 * seed + i, int(rng.integers(0, 5)), n))
+    got = ring.ingest_synthetic(jobs, timeout_s=90.0, concurrent=int(rng.integers(1, 7)))
+    ring.quiesce()
+    st = ring.stats()
+    want = _oracle_records(O, avg, jobs)
+    for i, (g, w) in enumerate(zip(got, want)):
+        _assert_same(g, w, (seed, i, jobs[i]))
+    assert st["pages_free"] == st["pages_total"] and st["pages_recycled"] == st["pages_enqueued"], st
+    ring.close()
+    eng.close()
