@@ -417,11 +417,14 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         r->min_round_pages = std::max(1u, r->round_pages / 4);
         if (const char *v = getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = (uint32_t)std::max(1, atoi(v));
         if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kInputs);
-        // candidate slots per scan tile: twice the batch path's default for this tile size
+        // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
+        // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
+        // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
+        // configs[2]'s repeating 4 KiB files have one per 4 KiB). 12 bytes per slot: ~400 MB at the default round size.
         const double lambda = 3.0 * r->tile_bytes / ((double)e->cfg.mask + 1.0);
         uint32_t capv = 8;
         while (capv < 4.0 * lambda + 16.0) capv <<= 1;
-        r->cap = std::min<uint32_t>(capv * 2, r->tile_bytes);
+        r->cap = std::min<uint32_t>(std::max<uint32_t>(capv * 2, r->tile_bytes / 128), r->tile_bytes);
         const uint64_t ntiles = (uint64_t)r->round_pages * r->tpp;
         if (ntiles * r->cap >= (1ull << 32)) return PBSGPU_E_DENSITY;
         const uint32_t minsz = std::min(e->effmin, e->cfg.min);
