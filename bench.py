@@ -717,7 +717,7 @@ def ring_run(a, rank, local_rank, world, ctx):
                     reduce_in_order(fidx - state["first_timed"], allr)
                     done += 1
             if time.perf_counter() - t_last > 60:
-                raise SystemExit(f"ring made no progress for 60 s: {ring.stats()}")
+                raise SystemExit(f"ring made no progress for 60 s: {ring.stats()}\n{ring.debug() if hasattr(ring, 'debug') else ''}")
         state["next_file"] = base + nfiles
         return out
 
@@ -899,7 +899,7 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
                     recs_of[g] = r
                 done += 1
             if time.perf_counter() - t_last > 60:
-                raise SystemExit(f"ring made no progress for 60 s: {ring.stats()}")
+                raise SystemExit(f"ring made no progress for 60 s: {ring.stats()}\n{ring.debug() if hasattr(ring, 'debug') else ''}")
 
     marks = {}
     if a.warmup:

@@ -273,7 +273,9 @@ int pbsgpu_stream_write_marker(pbsgpu_stream *s, const struct pbsgpu_payload_for
  *   - a page is free again as soon as every chunk touching it has been READ by the service (not when a batch ends);
  *   - poll returns the stream's finished (end, digest) records in stream order; `end` is the absolute stream offset.
  * Results are bit-identical to one pbsgpu_submit_* / pbsgpu_stream_* pass over the same bytes.
- * One thread drives a ring. While the service runs, hipDeviceSynchronize / hipFree block: call quiesce first. */
+ * One thread drives a ring. While the service runs, hipDeviceSynchronize / hipFree block: call quiesce first — also
+ * before a pause: a ring that is not called at all for PBSGPU_RING_IDLE_TIMEOUT_S (default 20 s) while its service runs
+ * considers the host dead, stops the service and answers PBSGPU_E_STATE from then on. */
 typedef struct pbsgpu_ring pbsgpu_ring;
 typedef struct pbsgpu_ring_options {
     uint64_t arena_bytes;  /* device memory for pages; 0 = what is free minus 8 GiB */
@@ -322,6 +324,8 @@ int pbsgpu_ring_close(pbsgpu_ring *ring, uint32_t stream);
  * concerned); the next pump starts it again. */
 int pbsgpu_ring_quiesce(pbsgpu_ring *ring);
 int pbsgpu_ring_get_stats(pbsgpu_ring *ring, pbsgpu_ring_stats *out);
+/* Diagnostic text snapshot of the ring's device-side state (queue words, page reference counts, stream states). */
+int pbsgpu_ring_debug(pbsgpu_ring *ring, char *buf, uint64_t cap);
 
 /* ---- whole-stream SHA-256 batch ---------------------------------------------
  * verification.HashFile (internal/agent/verification/handler.go:36-68) and

@@ -163,6 +163,7 @@ SYMBOLS = {
     "pbsgpu_ring_close": (C.c_int, [_P, C.c_uint32]),
     "pbsgpu_ring_quiesce": (C.c_int, [_P]),
     "pbsgpu_ring_get_stats": (C.c_int, [_P, C.POINTER(RingStats)]),
+    "pbsgpu_ring_debug": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),

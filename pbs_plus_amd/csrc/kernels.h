@@ -199,7 +199,12 @@ struct RingSource {
     uint32_t *pending;         // per physical page: chunks not yet loaded + holds of open chunks
     unsigned long long *free_fifo;  // mapped pinned: (sequence << 32) | page
     uint32_t free_mask;
-    unsigned long long idle_ticks;  // wall-clock ticks (100 MHz) an idle wave waits for work before it gives up
+    // A kernel that only ends on request must not outlive a host that died: every ring call bumps `heartbeat` (mapped
+    // pinned); an idle wave that has seen neither work nor a heartbeat change for idle_ticks (wall-clock ticks, 100 MHz)
+    // gives up AND marks the ring failed (ctl->error = 3) — the host then reports an error instead of waiting forever
+    // for chunks nobody hashes. A slow producer does not trip it: the host keeps calling while it waits for input.
+    const uint32_t *heartbeat;
+    unsigned long long idle_ticks;
 };
 
 

@@ -1607,6 +1607,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         [[maybe_unused]] uint32_t claimed = 0;  // (a word, not a bool: two bool flags set in sibling branches get their stores
                                                 // merged through a selected pointer by the optimiser, which puts both in scratch)
         [[maybe_unused]] unsigned long long idle_since = 0;
+        [[maybe_unused]] uint32_t hb_seen = 0;
         // FIFO of raw blocks in flight: a block is requested D iterations before it is expanded, so
         // HBM/TLB latency of the lane-private streams stays off the serial chain
         constexpr int D = 2;  // even (buffer parity is derived from the slot index)
@@ -1860,7 +1861,23 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                         if (!any_cur && !wave_done) {
                             const unsigned long long now = wall_clock64();
                             if (idle_since == 0) idle_since = now;
-                            if (now - idle_since > src.idle_ticks) exhausted = true;
+                            if (now - idle_since > src.idle_ticks) {
+                                // nothing to do for a whole timeout: is the host still there? (The heartbeat lives in HOST
+                                // memory: it is read once per timeout, not per idle iteration — hundreds of idle waves
+                                // polling it over PCIe every few microseconds slowed the whole ring down 6x.)
+                                const uint32_t hb = __hip_atomic_load(src.heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                if (hb != hb_seen) {  // alive: it just has nothing for us yet
+                                    hb_seen = hb;
+                                    idle_since = now;
+                                } else {
+                                    if (lane == 0) {  // for the round kernels (device) and for the host (mapped pinned, word 16)
+                                        __hip_atomic_store(&src.ctl->error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        __hip_atomic_store(const_cast<uint32_t *>(src.heartbeat) + 16, 1u, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                    exhausted = true;
+                                }
+                            }
                             __builtin_amdgcn_s_sleep(48);
                         } else {
                             idle_since = 0;

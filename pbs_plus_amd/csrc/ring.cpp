@@ -94,7 +94,7 @@ struct pbsgpu_ring {
     uint32_t lslots = 0, long_bytes = 0;
     DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
     // mapped pinned
-    PinnedBuf cells, free_fifo, inputs;
+    PinnedBuf cells, free_fifo, inputs, heartbeat;
     size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_status_off = 0;
     hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
     hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr;
@@ -134,6 +134,7 @@ struct pbsgpu_ring {
         double idle_s = 20.0;
         if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.5, atof(v));
         q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
+        q.heartbeat = heartbeat.as<uint32_t>();
         return q;
     }
 };
@@ -144,6 +145,15 @@ uint32_t pow2_at_least(uint64_t v) {
     uint32_t p = 1;
     while (p < v && p < (1u << 31)) p <<= 1;
     return p;
+}
+
+// every ring call: tell the service the host is alive, and notice a service that ended although nobody stopped it (its
+// idle waves give up when the heartbeat stands still for PBSGPU_RING_IDLE_TIMEOUT_S): the ring then fails loudly
+void ring_heartbeat(pbsgpu_ring *r, bool check_service = false) {
+    volatile uint32_t *hb = r->heartbeat.as<volatile uint32_t>();
+    *hb = *hb + 1u;
+    // word 16 of the heartbeat block is written by a service wave that gave up (no heartbeat for a whole timeout)
+    if (check_service && r->error == PBSGPU_OK && hb[16] != 0) r->error = PBSGPU_E_STATE;
 }
 
 // pages the service has handed back since the last call
@@ -166,7 +176,7 @@ void ring_reap_rounds(pbsgpu_ring *r) {
         if (hs->seq != ri.seq) break;  // rounds complete in order
         std::atomic_thread_fence(std::memory_order_acquire);
         if (hs->error) {
-            r->error = PBSGPU_E_DENSITY;
+            r->error = hs->error == 3 ? PBSGPU_E_STATE : PBSGPU_E_DENSITY;  // 3 = the service gave up (no heartbeat)
         } else {
             const uint32_t n = hs->nrec;
             const uint8_t *cells = r->cells.as<uint8_t>();
@@ -402,6 +412,12 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
             arena_bytes = fr > (12ull << 30) ? fr - (8ull << 30) : fr / 2;
         }
         r->npages = (uint32_t)std::min<uint64_t>(arena_bytes / r->stride, 65534);
+        {   // the chunk FIFO and the record cells are sized for every chunk the arena can hold (arena / min chunk size):
+            // with small average chunk sizes that bound, not HBM, limits the arena (4 M resident chunks = 128 MB of
+            // descriptors + 1 GB of pinned record cells)
+            const uint64_t lim = (4ull << 20) * std::min(e->effmin, e->cfg.min) / r->page_bytes;
+            if (r->npages > lim) r->npages = (uint32_t)std::max<uint64_t>(lim, 4);
+        }
         if (r->npages < 4) return PBSGPU_E_INVALID;
         r->max_streams = o.max_streams ? o.max_streams : 64;
         if (r->max_streams > 4096) return PBSGPU_E_INVALID;
@@ -466,6 +482,8 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         HIPCHK(hipMemset(r->pending.p, 0, (size_t)r->npages * 4 + 64));
         HIPCHK(hipMemset(r->scalars.p, 0, pbsk::kRsCount * 4 + 64));
         CHK(r->cells.ensure((size_t)r->ncells * 64));
+        CHK(r->heartbeat.ensure(128));
+        std::memset(r->heartbeat.p, 0, 128);
         CHK(r->free_fifo.ensure((size_t)r->nfree * 8));
         std::memset(r->free_fifo.p, 0, (size_t)r->nfree * 8);
         r->in_pages_off = 0;
@@ -548,6 +566,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
                           &r->seg_open})
             b->release();
         r->cells.release();
+        r->heartbeat.release();
         r->free_fifo.release();
         r->inputs.release();
     }
@@ -658,6 +677,7 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
 int pbsgpu_ring_pump(pbsgpu_ring *r) {
     if (!r) return PBSGPU_E_INVALID;
     CHK(set_device(r->eng));
+    ring_heartbeat(r, true);
     ring_reap_free(r);
     ring_reap_rounds(r);
     for (int i = 0; i < 4; ++i) {
@@ -671,6 +691,7 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
 int pbsgpu_ring_poll(pbsgpu_ring *r, uint32_t stream, pbsgpu_record *out, uint64_t cap, uint64_t *n, int *finished) {
     if (!r || !n || stream >= r->slots.size() || !r->slots[stream].open || (!out && cap)) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
+    ring_heartbeat(r);
     ring_reap_rounds(r);
     *n = 0;
     const uint8_t *cells = r->cells.as<uint8_t>();
@@ -703,6 +724,7 @@ int pbsgpu_ring_poll(pbsgpu_ring *r, uint32_t stream, pbsgpu_record *out, uint64
 int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint64_t *n, uint32_t *finished, uint32_t fcap,
                          uint32_t *nfinished) {
     if (!r || !n || !nfinished || (!out && cap) || (!finished && fcap)) return PBSGPU_E_INVALID;
+    ring_heartbeat(r);
     ring_reap_rounds(r);
     *n = 0;
     *nfinished = 0;
@@ -734,6 +756,50 @@ int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint6
     }
     while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
     return r->error;
+}
+
+// Diagnostic snapshot (text) of the device-side state: queue control words, per-page reference counts, stream states
+// and what the host thinks. Safe while the service runs (plain copies on the null stream; the ring's streams are
+// non-blocking).
+int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
+    if (!r || !buf || cap < 64) return PBSGPU_E_INVALID;
+    CHK(set_device(r->eng));
+    pbsk::RingCtl ctl{};
+    std::vector<uint32_t> pend(r->npages);
+    std::vector<pbsk::RingStreamState> sts(r->max_streams);
+    HIPCHK(hipMemcpy(&ctl, r->ctl.p, sizeof(ctl), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pend.data(), r->pending.p, (size_t)r->npages * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sts.data(), r->streams.p, (size_t)r->max_streams * sizeof(pbsk::RingStreamState), hipMemcpyDeviceToHost));
+    size_t o = 0;
+    auto put = [&](const char *fmt, auto... a) {
+        if (o + 1 < cap) o += (size_t)std::max(0, snprintf(buf + o, (size_t)(cap - o), fmt, a...));
+        if (o >= cap) o = (size_t)cap - 1;
+    };
+    put("ctl: tail=%u stop=%u head=%u ltail=%u lhead=%u free_count=%u error=%u | host: free_read=%u free_pages=%zu rounds=%zu "
+        "next_seq=%u service_running=%d\n", ctl.tail, ctl.stop, ctl.head, ctl.ltail, ctl.lhead, ctl.free_count, ctl.error,
+        r->free_read, r->free_pages.size(), r->rounds.size(), r->next_seq, (int)r->service_running);
+    uint32_t nz = 0;
+    for (uint32_t p = 0; p < r->npages && nz < 64; ++p)
+        if (pend[p]) {
+            put("page %u pending=%u\n", p, pend[p]);
+            ++nz;
+        }
+    for (uint32_t i = 0; i < r->slots.size(); ++i) {
+        const StreamSlot &s = r->slots[i];
+        if (!s.open) continue;
+        put("stream %u: committed=%llu enqueued=%llu final_committed=%d final_enqueued=%d final_done=%d ready=%zu cells=%zu out=%llu | "
+            "device c=%llu end=%llu\n", i, (unsigned long long)s.bytes_committed, (unsigned long long)s.bytes_enqueued,
+            (int)s.final_committed, (int)s.final_enqueued, (int)s.final_done, s.ready.size(), s.cells.size(),
+            (unsigned long long)s.records_out, (unsigned long long)sts[i].c, (unsigned long long)sts[i].end);
+        if (!s.cells.empty()) {
+            const uint8_t *c = r->cells.as<uint8_t>() + (size_t)s.cells.front().cell * 64;
+            pbsgpu_record rec;
+            std::memcpy(&rec, c, sizeof(rec));
+            put("  waiting for cell %u: end=%llu size=%u flag=%u\n", s.cells.front().cell, (unsigned long long)rec.end, rec.size,
+                *reinterpret_cast<const uint32_t *>(c + 48));
+        }
+    }
+    return PBSGPU_OK;
 }
 
 int pbsgpu_ring_get_stats(pbsgpu_ring *r, pbsgpu_ring_stats *out) {

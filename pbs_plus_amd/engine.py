@@ -509,6 +509,11 @@ class PageRing:
         check(self._L.pbsgpu_ring_get_stats(self._h, C.byref(st)), "ring_get_stats")
         return {k: getattr(st, k) for k, _ in _lib.RingStats._fields_}
 
+    def debug(self) -> str:
+        buf = C.create_string_buffer(1 << 16)
+        check(self._L.pbsgpu_ring_debug(self._h, buf, len(buf)), "ring_debug")
+        return buf.value.decode(errors="replace")
+
     def ingest_synthetic(self, jobs, timeout_s: float = 120.0, concurrent: int | None = None):
         """Drive whole synthetic streams through the ring: jobs = [(seed, kind, nbytes)]; returns one record array per
         job. At most `concurrent` (default: all slots) streams are open at a time."""
@@ -548,7 +553,7 @@ class PageRing:
                     self.close_stream(sid)
                     del active[sid]
             if time.perf_counter() - t0 > timeout_s:
-                raise TimeoutError(f"ring ingest did not finish in {timeout_s} s: {self.stats()}")
+                raise TimeoutError(f"ring ingest did not finish in {timeout_s} s: {self.stats()}\n{self.debug()}")
         return [np.concatenate(r) if r else np.zeros(0, dtype=RECORD_DTYPE) for r in res]
 
     def close(self):

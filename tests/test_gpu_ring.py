@@ -290,3 +290,47 @@ def test_ring_randomized_programs(gpu_lib, O, seed, monkeypatch):
     assert st["pages_free"] == st["pages_total"] and st["pages_recycled"] == st["pages_enqueued"], st
     ring.close()
     eng.close()
+
+
+def test_ring_service_gives_up_without_a_heartbeat_and_the_ring_fails_loudly(gpu_lib, O, monkeypatch):
+    """The service is a kernel that only ends on request: if the host stops calling the ring (died, or paused without
+    quiesce) its idle waves give up after PBSGPU_RING_IDLE_TIMEOUT_S — and the ring must then REPORT it (PBSGPU_E_STATE)
+    instead of waiting forever for chunks nobody hashes. A host that keeps calling while it has nothing to feed is fine."""
+    import time
+
+    from pbs_plus_amd import PageRing, PbsGpuError, _lib
+
+    monkeypatch.setenv("PBSGPU_RING_IDLE_TIMEOUT_S", "1")
+    eng = _engine(4096)
+    ring = PageRing(eng, arena_bytes=24 * (65536 + 256), **SMALL)
+    sid = ring.open()
+    assert ring.fill(sid, 5, 0, 3 * 65536, final=False) == 3 * 65536
+    got = []
+    t0 = time.time()
+    while time.time() - t0 < 3.5:          # 3.5 s with nothing to feed, but the host keeps polling: the service stays
+        ring.pump()
+        got.append(ring.poll(sid)[0].copy())
+        time.sleep(0.01)
+    assert ring.fill(sid, 5, 0, 65536 + 17, final=True) == 65536 + 17
+    t0 = time.time()
+    while time.time() - t0 < 20:
+        ring.pump()
+        recs, fin = ring.poll(sid)
+        got.append(recs.copy())
+        if fin:
+            break
+    want = O.chunk_and_digest(O.new_config(4096), O.fill(4 * 65536 + 17, 5, 0), [(0, 4 * 65536 + 17)])
+    _assert_same(np.concatenate(got), want, "slow producer")
+    ring.close_stream(sid)
+    sid = ring.open()
+    ring.fill(sid, 6, 0, 2 * 65536, final=False)
+    ring.pump()
+    time.sleep(4.0)                         # silence: no ring call at all (the service gives up after 1-2 timeouts)
+    with pytest.raises(PbsGpuError) as ei:
+        for _ in range(2000):
+            ring.pump()
+            ring.poll(sid)
+            time.sleep(0.001)
+    assert ei.value.status == _lib.E_STATE
+    ring.close()
+    eng.close()
