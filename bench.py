@@ -685,6 +685,7 @@ def ring_run(a, rank, local_rank, world, ctx):
         out, active, opened, done = {}, {}, 0, 0
         marks.clear()
         base = state["next_file"]
+        enq0 = ring.stats()["bytes_enqueued"]
         t_last = time.perf_counter()
         while done < nfiles:
             # S files are being FED at any time; a file whose bytes are all in (its last chunks still hashing, up to ~0.45 s)
@@ -700,8 +701,11 @@ def ring_run(a, rank, local_rank, world, ctx):
                     want = min(st[1], quota)
                     st[1] -= ring.fill(sid, seed_of(st[0]), kind, want, final=(want == st[1]))
             ring.pump()
-            if opened == nfiles and "t_fed" not in marks and not any(st[1] for st in active.values()):
-                marks["t_fed"] = time.perf_counter()     # every byte of the last file has been handed to the ring
+            if (opened == nfiles and "t_fed" not in marks and not any(st[1] for st in active.values())
+                    and ring.stats()["bytes_enqueued"] >= enq0 + nfiles * file_bytes):
+                marks["t_fed"] = time.perf_counter()     # every byte of the last file is in a cut round
+                if os.environ.get("PBS_BENCH_RING_TRACE"):   # queue state at the end of the feed phase (diagnostic)
+                    marks["fed_state"] = (ring.debug().splitlines()[0], ring.stats())
             for sid in list(active):
                 recs, fin = ring.poll(sid, 8192)
                 if recs.size:
@@ -747,6 +751,9 @@ def ring_run(a, rank, local_rank, world, ctx):
     t0 = time.perf_counter()
     kept = run_files(a.steps, True)
     t_fed = marks.get("t_fed", None)
+    if "fed_state" in marks and rank == 0:
+        print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
+              "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)
     ring.quiesce()
     torch.cuda.synchronize()
     if ctx.dist is not None:
@@ -815,7 +822,7 @@ def ring_run(a, rank, local_rank, world, ctx):
                 "feed_phase": None if t_fed is None else {
                     "seconds": round(t_fed - t0, 4), "GiBps": round(a.steps * file_bytes / GiB / max(t_fed - t0, 1e-9), 1),
                     "drain_seconds": round(elapsed - (t_fed - t0), 4),
-                    "note": "timed region = feed phase (idle ring -> last page of the last file handed over; pages are cut, "
+                    "note": "timed region = feed phase (idle ring -> last page of the last file in a cut round; pages are cut, "
                             "hashed and recycled all the while) + drain (the last chunks' serial SHA-256 chains, up to one "
                             "max-size chunk = ~0.45 s, with no new work: a fixed cost per timed region whatever its length)"},
                 "path": {"achieved": round(gbs, 1), "frac_of_valu_peak": round(gbs / SHA_VALU_GBS, 4),
@@ -869,6 +876,7 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
     def run(first, count, keep):
         nxt, done, active, t_last = first, 0, {}, time.perf_counter()
         marks.clear()
+        enq0 = ring.stats()["bytes_enqueued"]
         while done < count:
             nfeed = sum(1 for st in active.values() if st[1])
             while nxt < first + count and nfeed < feeding and len(active) < 4000:
@@ -882,7 +890,8 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
                     want = min(st[1], quota)
                     st[1] -= ring.fill(sid, seed, kind, want, final=(want == st[1]))
             ring.pump()
-            if nxt == first + count and "t_fed" not in marks and not any(st[1] for st in active.values()):
+            if (nxt == first + count and "t_fed" not in marks and not any(st[1] for st in active.values())
+                    and ring.stats()["bytes_enqueued"] >= enq0 + count * fbytes):
                 marks["t_fed"] = time.perf_counter()
             recs, fin = ring.poll_any()
             if recs.size:

@@ -296,7 +296,9 @@ void pbsgpu_ring_destroy(pbsgpu_ring *ring);
 /* A new stream (fresh chunker state). PBSGPU_E_BUSY when max_streams are open. */
 int pbsgpu_ring_open(pbsgpu_ring *ring, uint32_t *stream);
 /* The stream's next page: a device pointer to write up to *cap (= page size) bytes to — by a kernel, a DMA, a peer.
- * PBSGPU_E_BUSY when no page is free right now (pump / poll and retry). */
+ * PBSGPU_E_BUSY when no page is free right now, or when enough bytes already wait in front of the SHA-256 service
+ * (committed pages not yet in a round + rounds in flight + published chunks no lane has claimed > the backlog limit,
+ * default 128 MiB per service CU, PBSGPU_RING_BACKLOG_MIB, 0 = no limit): pump / poll and retry. */
 int pbsgpu_ring_reserve(pbsgpu_ring *ring, uint32_t stream, void **dptr, uint64_t *cap);
 /* The first nbytes of the reserved page are the stream's next bytes and are VISIBLE to the device (the producer has
  * finished). Every page but the stream's last must be full; final != 0 ends the stream (nbytes may then be 0, also

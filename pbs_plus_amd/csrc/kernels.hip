@@ -1680,7 +1680,15 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 if (mw) {
                     uint32_t first = 0;
                     const int leader = __ffsll((long long)mw) - 1;
-                    if (lane == leader) first = atomicAdd(&src.ctl->head, (uint32_t)__popcll(mw));
+                    if (lane == leader) {
+                        const uint32_t cnt = (uint32_t)__popcll(mw);
+                        first = atomicAdd(&src.ctl->head, cnt);
+                        // claim progress for the host's backlog gate (ring.cpp): one posted write to mapped pinned
+                        // memory whenever the head crosses a multiple of 256
+                        if (((first + cnt) ^ first) >> 8)
+                            __hip_atomic_store(const_cast<uint32_t *>(src.heartbeat) + 32, first + cnt, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                     first = __shfl(first, leader, 64);
                     if (want) {
                         claim = first + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));

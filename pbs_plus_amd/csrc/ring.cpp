@@ -73,6 +73,7 @@ struct RoundInfo {
     bool reaped = false;
     std::vector<uint32_t> finals;         // slots whose stream ended with this round
     std::vector<uint32_t> phys;           // pages carried (diagnostics)
+    uint64_t new_bytes = 0;               // stream bytes this round added
 };
 
 double now_ms() {
@@ -87,6 +88,13 @@ struct pbsgpu_ring {
     uint64_t page_bytes = 0, stride = 0;
     uint32_t tile_bytes = 0, tpp = 0, npages = 0, max_streams = 0, sha_cus = 0, round_pages = 0, min_round_pages = 0, cap = 0;
     uint32_t max_inflight = 3;
+    // backlog gate: no page is handed out while more than this many bytes wait in front of the service — committed pages
+    // not yet in a round, rounds in flight, published chunks no lane has claimed. A full arena of unhashed chunks feeds
+    // the service no faster than a short queue does; it only adds its length to every latency (and to the final drain).
+    uint64_t backlog_limit = 0;
+    uint64_t ready_bytes = 0, inflight_bytes = 0;
+    uint32_t tail_seen = 0;               // queue tail after the last reaped round
+    uint64_t pub_positions = 0, pub_bytes = 0;  // queue positions / stream bytes of all reaped rounds (average chunk size)
     uint64_t rec_cap = 0, dense_cap = 0;
     uint32_t qslots = 0, ncells = 0, nfree = 0;
     // device
@@ -191,8 +199,12 @@ void ring_reap_rounds(pbsgpu_ring *r) {
                 r->st.chunks++;
             }
             r->st.candidates += hs->ncand;
+            r->pub_positions += (uint32_t)(hs->tail - r->tail_seen);
+            r->pub_bytes += ri.new_bytes;
+            r->tail_seen = hs->tail;
         }
         for (uint32_t s : ri.finals) r->slots[s].final_done = true;
+        r->inflight_bytes -= ri.new_bytes;
         ri.reaped = true;
         r->input_busy[ri.input] = false;
         r->st.rounds_done++;
@@ -203,6 +215,7 @@ void ring_reap_rounds(pbsgpu_ring *r) {
 int ring_start_service(pbsgpu_ring *r) {
     if (r->service_running) return PBSGPU_OK;
     // head := tail, stop := 0 behind everything on the control stream; the service starts behind that
+    r->heartbeat.as<volatile uint32_t>()[32] = r->tail_seen;  // (k_ring_reset: head := tail; every round was reaped by now)
     HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));
     HIPCHK(hipEventRecord(r->ev_reset, r->cs));
     HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));
@@ -359,6 +372,9 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     CHK(ring_start_service(r));
     HIPCHK(pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in]));
     r->input_busy[in] = true;
+    ri.new_bytes = new_bytes;
+    r->ready_bytes -= new_bytes;
+    r->inflight_bytes += new_bytes;
     r->rounds.push_back(std::move(ri));
     r->st.rounds++;
     r->st.bytes_enqueued += new_bytes;
@@ -368,6 +384,15 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
 }
 
 int ring_take_page(pbsgpu_ring *r, uint32_t *phys) {
+    if (r->backlog_limit && r->service_running) {
+        // published and unclaimed: queue tail of the last reaped round minus the service's claim progress (word 32 of the
+        // heartbeat block, written whenever the head crosses a multiple of 256 — hence the slack: idle lanes claim ahead
+        // of the tail, so with nothing left to claim the difference always falls below 256)
+        const int32_t behind = (int32_t)(r->tail_seen - r->heartbeat.as<volatile uint32_t>()[32]) - 256;
+        double wait = (double)r->ready_bytes + (double)r->inflight_bytes;
+        if (behind > 0 && r->pub_positions) wait += (double)behind * ((double)r->pub_bytes / (double)r->pub_positions);
+        if (wait > (double)r->backlog_limit) return PBSGPU_E_BUSY;
+    }
     if (r->free_pages.empty()) ring_reap_free(r);
     if (r->free_pages.empty()) return PBSGPU_E_BUSY;
     *phys = r->free_pages.back();
@@ -432,6 +457,9 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         r->round_pages = std::min(r->round_pages, r->npages);
         r->min_round_pages = std::max(1u, r->round_pages / 4);
         if (const char *v = getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = (uint32_t)std::max(1, atoi(v));
+        // ~30 ms of the service's throughput (4.3 GiB/s per CU measured) is plenty to ride out the gaps between rounds
+        r->backlog_limit = (uint64_t)r->sha_cus << 27;
+        if (const char *v = getenv("PBSGPU_RING_BACKLOG_MIB")) r->backlog_limit = (uint64_t)(std::max(0.0, atof(v)) * 1048576.0);
         if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kInputs);
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
@@ -482,8 +510,8 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         HIPCHK(hipMemset(r->pending.p, 0, (size_t)r->npages * 4 + 64));
         HIPCHK(hipMemset(r->scalars.p, 0, pbsk::kRsCount * 4 + 64));
         CHK(r->cells.ensure((size_t)r->ncells * 64));
-        CHK(r->heartbeat.ensure(128));
-        std::memset(r->heartbeat.p, 0, 128);
+        CHK(r->heartbeat.ensure(256));
+        std::memset(r->heartbeat.p, 0, 256);
         CHK(r->free_fifo.ensure((size_t)r->nfree * 8));
         std::memset(r->free_fifo.p, 0, (size_t)r->nfree * 8);
         r->in_pages_off = 0;
@@ -630,6 +658,7 @@ int pbsgpu_ring_commit(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int fin
     q.valid = (uint32_t)nbytes;
     q.final = final != 0;
     s.ready.push_back(q);
+    r->ready_bytes += nbytes;
     s.reserved = -1;
     s.bytes_committed += nbytes;
     if (final) s.final_committed = true;
@@ -667,6 +696,7 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
         q.kind = kind;
         q.fill_off = s.bytes_committed;  // the generator's stream offset = the page's offset in its stream
         s.ready.push_back(q);
+        r->ready_bytes += n;
         s.bytes_committed += n;
         *taken += n;
         if (q.final) s.final_committed = true;
@@ -776,8 +806,9 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
         if (o >= cap) o = (size_t)cap - 1;
     };
     put("ctl: tail=%u stop=%u head=%u ltail=%u lhead=%u free_count=%u error=%u | host: free_read=%u free_pages=%zu rounds=%zu "
-        "next_seq=%u service_running=%d\n", ctl.tail, ctl.stop, ctl.head, ctl.ltail, ctl.lhead, ctl.free_count, ctl.error,
-        r->free_read, r->free_pages.size(), r->rounds.size(), r->next_seq, (int)r->service_running);
+        "next_seq=%u service_running=%d tail_seen=%u claim_progress=%u backlog_limit=%llu\n", ctl.tail, ctl.stop, ctl.head,
+        ctl.ltail, ctl.lhead, ctl.free_count, ctl.error, r->free_read, r->free_pages.size(), r->rounds.size(), r->next_seq,
+        (int)r->service_running, r->tail_seen, r->heartbeat.as<volatile uint32_t>()[32], (unsigned long long)r->backlog_limit);
     uint32_t nz = 0;
     for (uint32_t p = 0; p < r->npages && nz < 64; ++p)
         if (pend[p]) {

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    # the page ring's service gives up when the host stops calling for this long: a test process that sits in an oracle
+    # computation on a slow box is alive, not gone (the give-up test sets its own value)
+    os.environ.setdefault("PBSGPU_RING_IDLE_TIMEOUT_S", "90")
 
 
 @pytest.fixture(scope="session")

@@ -201,7 +201,7 @@ class _FakeRing:
 
     def stats(self):
         return {"page_bytes": self.PAGE, "pages_total": 64, "sha_cus": 208, "rounds": self.rounds, "service_launches": self.launches,
-                "service_ms_last": 5.0, "service_bytes_last": getattr(self, "svc_last", 0), "chunks": 0}
+                "service_ms_last": 5.0, "service_bytes_last": getattr(self, "svc_last", 0), "chunks": 0, "bytes_enqueued": self.bytes}
 
     def close(self):
         pass

@@ -264,7 +264,8 @@ def test_cpp_mirror_page_ring(gpu_lib, O, tmp_path):
 def test_ring_randomized_programs(gpu_lib, O, seed, monkeypatch):
     """Random programs over the ring: 10-40 streams of random lengths (empty, 1 byte, around the window, around one and
     several pages, up to a few MiB) and data kinds through a SMALL arena (heavy page recycling, streams sharing rounds),
-    1-6 streams fed at a time, with and without the long-chunk queue — every stream bit-exact vs the oracle."""
+    1-6 streams fed at a time, with and without the long-chunk queue, with and without a tight backlog gate — every stream
+    bit-exact vs the oracle."""
     from pbs_plus_amd import PageRing
 
     rng = np.random.default_rng(1000 + seed)
@@ -273,6 +274,10 @@ def test_ring_randomized_programs(gpu_lib, O, seed, monkeypatch):
     npages = int(rng.integers(12, 60))
     if seed % 3 == 0:
         monkeypatch.setenv("PBSGPU_RING_LONG_BYTES", str(avg * 2))
+    if seed % 2 == 1:
+        # the backlog gate (pages are refused while more than this waits in front of the service) at a limit these small
+        # rings reach all the time: a few pages' worth
+        monkeypatch.setenv("PBSGPU_RING_BACKLOG_MIB", str(round(float(rng.integers(2, 9)) * page / 1048576.0, 4)))
     eng = _engine(avg)
     ring = PageRing(eng, arena_bytes=npages * (page + 256), page_bytes=page, max_streams=16, sha_cus=int(rng.integers(2, 24)),
                     round_pages=int(rng.integers(2, 12)))
