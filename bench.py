@@ -84,6 +84,9 @@ def parse():
                     help="corpus workloads at N > 1: weak = every rank owns a full share; strong = one share split over the ranks")
     ap.add_argument("--producers", type=int, default=8, help="hostfeed: producer threads (one stream each)")
     ap.add_argument("--tee", action="store_true", help="hostfeed: every 1 GiB step is one file with the XXH3-64 tee on")
+    ap.add_argument("--archives", type=int, default=1,
+                    help="hostfeed: archives per producer, written back to back (finish_begin: an archive's last chunks are "
+                         "hashed while the next one is being written)")
     ap.add_argument("--cpu-sample-gib", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spread-check", action="store_true", help="skip the whole-batch restart-point parity check")
@@ -624,18 +627,24 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
                          "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
         except BaseException as exc:  # noqa: BLE001
             res[name] = {"error": repr(exc)}
-    for label, key, producers, gib_steps in (("hostfeed_1_writer", "hostfeed1", 1, 96), ("hostfeed_8_writers", "hostfeed8", 8, 16)):
+    for label, key, producers, gib_steps, archives in (("hostfeed_1_writer", "hostfeed1", 1, 96, 1),
+                                                       ("hostfeed_1_writer_4_archives", "hostfeed1", 1, 96, 4),
+                                                       ("hostfeed_8_writers", "hostfeed8", 8, 32, 1)):
         if key not in legs:
             continue
         b = copy.copy(a)
         b.workload, b.producers, b.steps, b.warmup, b.gib, b.tee = "hostfeed", producers, gib_steps, 4, None, False
+        b.archives = archives
         t0 = time.perf_counter()
         try:
             o = hostfeed_run(b, rank, local_rank, world, ctx)
-            res[label] = {"value": o["value"], "unit": o["unit"], "producers": producers,
+            res[label] = {"value": o["value"], "unit": o["unit"], "producers": producers, "archives_per_producer": archives,
                           "bytes": int(o["config"]["bytes"]),
                           "frac_of_measured_h2d": o["roofline"]["frac_of_measured_h2d"],
                           "measured_h2d_GBps": o["roofline"]["measured_h2d_GBps"],
+                          "write_phase": {k: o["write_phase"][k] for k in ("seconds", "GiBps", "drain_seconds")},
+                          "write_phase_frac_of_measured_h2d": None if not o["roofline"]["measured_h2d_GBps"] else round(
+                              o["write_phase"]["GiBps"] * GiB / 1e9 / o["roofline"]["measured_h2d_GBps"], 3),
                           "records_match_oracle": o["stream_records_match_oracle"],
                           "leg_seconds": round(time.perf_counter() - t0, 1)}
         except BaseException as exc:  # noqa: BLE001
@@ -1421,15 +1430,30 @@ def hostfeed_run(a, rank, local_rank, world, ctx):
     gate = threading.Barrier(P + 1)
     out = [None] * P
     nfiles = [0] * P
+    t_written = [0.0] * P
     errs = []
+
+    A = max(1, min(getattr(a, "archives", 1) or 1, a.steps))   # archives per producer, written back to back
 
     def producer(i):
         try:
-            st = pbs_plus_amd.PayloadStream(eng, 256 << 20)
-            nrec = 0
+            draining = []        # archives whose input is closed (finish_begin) and whose last chunks are still being hashed
+            tot = {"nrec": 0, "bytes": 0}
 
-            def feed(steps):
-                nonlocal nrec
+            def reap(block):
+                for st in list(draining):
+                    if block:
+                        st.finish()
+                    tot["nrec"] += st.poll(1 << 16).size
+                    nfiles[i] += len(st.poll_files())
+                    if block or st.done():
+                        tot["nrec"] += st.poll(1 << 16).size
+                        nfiles[i] += len(st.poll_files())
+                        st.close()               # its window buffers go back to the engine's pool: the next archive takes them
+                        draining.remove(st)
+
+            def archive(steps, count):
+                st = pbs_plus_amd.PayloadStream(eng, 256 << 20)
                 for _ in range(steps):
                     off = 0
                     if a.tee:
@@ -1440,21 +1464,28 @@ def hostfeed_run(a, rank, local_rank, world, ctx):
                         st.write(src[i][o:o + n])
                         off += n
                         if (off // wsize) % 8 == 0:
-                            nrec += st.poll(4096).size
+                            tot["nrec"] += st.poll(4096).size
+                            reap(False)
                     if a.tee:
                         st.end_file()
                         nfiles[i] += len(st.poll_files())
-            feed(warm_steps)
-            gate.wait()          # warm-up written
+                if count:
+                    tot["bytes"] += st.bytes_written()
+                st.finish_begin()    # the goroutine goes on with its next archive; this one drains beside it
+                draining.append(st)
+
+            for k in range(2 if A > 1 else 1):      # warm-up (two overlapping archives when the timed phase overlaps them too)
+                archive(max(1, warm_steps // (2 if A > 1 else 1)), False)
+            reap(True)
+            tot["nrec"] = 0
+            gate.wait()          # warm-up written and drained
             gate.wait()          # timed phase starts
-            b0 = st.bytes_written()
-            feed(a.steps)
-            st.finish()
-            nrec += st.poll().size
-            nfiles[i] += len(st.poll_files())
-            out[i] = (nrec, st.bytes_written() - b0)
-            gate.wait()          # every record of every stream delivered: end of the timed region
-            st.close()
+            for k in range(A):
+                archive(a.steps // A + (1 if k < a.steps % A else 0), True)
+            t_written[i] = time.perf_counter()   # the last archive's last byte has been accepted; what follows is its drain
+            reap(True)
+            out[i] = (tot["nrec"], tot["bytes"])
+            gate.wait()          # every record of every archive delivered: end of the timed region
         except Exception as exc:  # noqa: BLE001
             errs.append(repr(exc))
             gate.abort()
@@ -1510,13 +1541,22 @@ def hostfeed_run(a, rank, local_rank, world, ctx):
             "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic random bytes in HOST memory, written through pbsgpu_stream_write (pinned staging -> H2D)",
             "config": {"workload": f"host-fed payload streams: {P} producer threads x {per_gib:g} GiB per step, "
-                                   f"32 MiB writes, 256 MiB device windows (the WriteEntryReader seam)",
+                                   f"32 MiB writes, 256 MiB device windows (the WriteEntryReader seam)"
+                                   + (f"; {A} archives per producer back to back, each archive's drain overlapped with the next "
+                                      f"one (pbsgpu_stream_finish_begin)" if A > 1 else ""),
+                       "archives_per_producer": A,
                        "producers": P, "avg_chunk": a.avg, "records": int(sum(o[0] for o in out)), "bytes": int(total),
                        "xxh3_tee_files": int(sum(nfiles)) if a.tee else None},
             "roofline": {"kernel": "H2D copy engine (PCIe Gen5 x16)", "bound": "pcie", "achieved": round(gbs / world, 1),
                          "peak": 63.0, "unit": "GB/s", "frac": round(gbs / world / 63.0, 4), "traffic": None,
                          "measured_h2d_GBps": h2d,
                          "frac_of_measured_h2d": None if not h2d else round(gbs / world / h2d, 3)},
+            "write_phase": {"seconds": round(max(t_written) - t0, 4),
+                            "GiBps": round(total / world / GiB / max(max(t_written) - t0, 1e-9), 2),
+                            "drain_seconds": round(elapsed - (max(t_written) - t0), 4),
+                            "note": "until the last writer's last byte was accepted (this rank); the rest is finish(): the last "
+                                    "windows' cut + the serial SHA-256 chain of their longest chunk, a fixed ~0.5-0.7 s per "
+                                    "archive whatever its length"},
             "stream_records_match_oracle": same,
             "cpu_baseline": {"value": round(n_chk / GiB / cpu_dt, 4), "unit": "GiB/s", "cores": 1, "kind": "port",
                              "sample": f"{n_chk >> 20} MiB of one producer's bytes, oracle chunk_and_digest (byte-serial Buzhash + "

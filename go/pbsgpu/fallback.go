@@ -90,6 +90,8 @@ func (s *Stream) Inject(uint64) error                                        { r
 func (s *Stream) PayloadPosition() uint64                                    { return 0 }
 func (s *Stream) SuggestBoundary() error                                     { return ErrNotBuilt }
 func (s *Stream) Finish() error                                              { return ErrNotBuilt }
+func (s *Stream) FinishBegin() error                                         { return ErrNotBuilt }
+func (s *Stream) Done() (bool, error)                                        { return false, ErrNotBuilt }
 func (s *Stream) Poll(int) ([]ChunkInfo, error)                              { return nil, ErrNotBuilt }
 func (s *Stream) Close()                                                     {}
 

@@ -474,6 +474,23 @@ func (s *Stream) Finish() error {
 	return check(C.pbsgpu_stream_finish(s.h), "stream_finish")
 }
 
+// FinishBegin closes the input without waiting for the last chunks' digests: the goroutine goes on with its next
+// archive while this one drains; Poll keeps delivering, Done reports when the last entry is out.
+func (s *Stream) FinishBegin() error {
+	defer runtime.KeepAlive(s)
+	return check(C.pbsgpu_stream_finish_begin(s.h), "stream_finish_begin")
+}
+
+// Done never blocks: true once every entry of a stream closed by Finish / FinishBegin can be polled.
+func (s *Stream) Done() (bool, error) {
+	defer runtime.KeepAlive(s)
+	var d C.int
+	if err := check(C.pbsgpu_stream_done(s.h, &d), "stream_done"); err != nil {
+		return false, err
+	}
+	return d != 0, nil
+}
+
 func (s *Stream) Poll(max int) ([]ChunkInfo, error) {
 	defer runtime.KeepAlive(s) // the finalizer must not run Close while the C call is executing
 	if max <= 0 {

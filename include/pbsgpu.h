@@ -222,8 +222,16 @@ int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len);
  * commit_reuse.go:315-341) and skip `inject_bytes` of injected, already
  * known chunk payload in the stream offsets. */
 int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes);
-/* End of stream: the tail becomes the final chunk. */
+/* End of stream: the tail becomes the final chunk; returns when every record is available to poll (the last window's
+ * cut + the serial SHA-256 chain of its longest chunk: up to ~0.5 s at 16 MiB maximum chunks). */
 int pbsgpu_stream_finish(pbsgpu_stream *s);
+/* The same without the wait, for a writer that goes on with its NEXT archive while this one drains (one goroutine per
+ * archive, archives back to back: internal/tapeio/converter.go:672-680): finish_begin closes the input (tail chunk cut,
+ * every chunk handed to the hash jobs; later writes fail with PBSGPU_E_STATE) and returns; records keep arriving
+ * through poll; pbsgpu_stream_done is non-blocking, *done = 1 once the last record can be polled. pbsgpu_stream_finish
+ * after finish_begin waits for exactly that. */
+int pbsgpu_stream_finish_begin(pbsgpu_stream *s);
+int pbsgpu_stream_done(pbsgpu_stream *s, int *done);
 /* Pop up to `cap` finished records (in stream order). */
 int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint64_t *n);
 /* Encoder().PayloadPosition() (commit_reuse.go:265): bytes written PLUS bytes injected so far — the coordinate

@@ -297,6 +297,25 @@ class PayloadWriter {
         if (st != PBSGPU_OK) return errorf("finish", st);
         return drain();
     }
+    // the same in two steps, for a writer that starts its next archive while this one's last chunks are hashed:
+    // FinishBegin closes the input and returns; Done() delivers what has arrived to the sink and reports whether the
+    // last entry is out (never blocks)
+    std::string FinishBegin() {
+        const int st = pbsgpu_stream_finish_begin(s_);
+        return st == PBSGPU_OK ? std::string() : errorf("finish begin", st);
+    }
+    Result<bool> Done() {
+        Result<bool> r;
+        int d = 0;
+        const int st = pbsgpu_stream_done(s_, &d);
+        if (st != PBSGPU_OK) {
+            r.err = errorf("done", st);
+            return r;
+        }
+        r.err = drain();
+        r.value = d != 0;
+        return r;
+    }
 
   private:
     PayloadWriter(std::shared_ptr<Engine> e, pbsgpu_stream *s, Sink sink) : eng_(std::move(e)), s_(s), sink_(std::move(sink)) {}

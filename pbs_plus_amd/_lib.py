@@ -141,6 +141,8 @@ SYMBOLS = {
     "pbsgpu_stream_commit": (C.c_int, [_P, C.c_size_t]),
     "pbsgpu_stream_cut": (C.c_int, [_P, C.c_uint64]),
     "pbsgpu_stream_finish": (C.c_int, [_P]),
+    "pbsgpu_stream_finish_begin": (C.c_int, [_P]),
+    "pbsgpu_stream_done": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "pbsgpu_stream_poll": (C.c_int, [_P, _P, C.c_uint64, _U64P]),
     "pbsgpu_stream_position": (C.c_int, [_P, _U64P]),
     "pbsgpu_stream_bytes_written": (C.c_int, [_P, _U64P]),

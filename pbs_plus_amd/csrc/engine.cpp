@@ -101,6 +101,7 @@ static void free_engine(pbsgpu_engine *e) {
         (void)hipStreamDestroy(cs);
     }
     for (auto &b : e->win_pool) b.release();
+    stream_pool_release(e);
     for (auto &s : e->slots)
         if (s) s->destroy();  // a failed create leaves a null entry behind (new(nothrow) Slot)
     for (auto &s : e->aux)
@@ -697,6 +698,7 @@ int pbsgpu_engine_trim(pbsgpu_engine *e, uint64_t *freed_bytes) {
         }
         e->win_pool.clear();
     }
+    stream_pool_release(e);
     if (freed_bytes) *freed_bytes = freed;
     return PBSGPU_OK;
 }

@@ -202,20 +202,25 @@ struct HashDispatcher {
     HashJob *open = nullptr;                      // accumulating
     int num_cus = 256;
     // Launch policy. A job lasts ~0.45 s (the chain of a max-size chunk) whatever it holds, and its windows are
-    // released together when it ends. Greedy launching (default) hands the first few windows a lane each and then lumps
-    // everything that arrives while all lanes are busy into one job: completions come in bursts. With several writers
-    // that is harmless (the lump is spread over many rings) and measured fastest (8 writers: 42 GiB/s greedy vs 31-35
-    // with launches spaced by job time / lanes); ONE writer near its ring limit can stall on a lump (the last 8 GiB of a
-    // 24 GiB single-stream run took 0.75 s instead of 0.35) — PBSGPU_HASH_INTERVAL_MS=75 spaces launches for that case
-    // (a launch still goes at once when >= 1 GiB is waiting).
+    // released together when it ends. Greedy launching (PBSGPU_HASH_INTERVAL_MS=0, the default until round 3) hands the
+    // first six windows a lane each within 30 ms and then lumps everything that arrives while all lanes are busy —
+    // 12 GiB for one fast writer — into one job; the lanes then free up together and the pattern repeats: windows wait
+    // up to a whole job time for a lane, and so does the LAST job of an archive (traced: single writer, drain 0.9 s
+    // instead of 0.5). Launches are therefore spaced by 0.8 x job time / lanes (61 ms; a job someone blocks on goes at
+    // once when a lane is free). Measured, 6 lanes (profiles/r03_hostfeed_hash_job_pacing.log): one writer 31.4 -> 40.2
+    // GiB/s over 96 GiB (0.59 -> 0.75 of the H2D rate), eight writers 43 vs 42 (unchanged within their run-to-run
+    // spread); 10-12 lanes lose with eight writers whatever the pacing (hardware queues). Round 2 saw spacing cost
+    // eight writers a quarter: that version still launched at once whenever >= 1 GiB was waiting, i.e. every 25 ms.
     uint64_t open_bytes = 0;
     double last_launch_ms = -1e18;
     double t0_ms = 0;  // trace time base
     double min_interval_ms = 60.0;
+    uint64_t bypass_bytes = ~0ull;  // a launch goes at once, whatever the pacing, when this much is waiting
 };
 
 }  // namespace pbse
 
+struct pbsgpu_stream;
 struct pbsgpu_engine {
     int device = 0;
     int num_cus = 256;
@@ -247,6 +252,10 @@ struct pbsgpu_engine {
     // stream teardown that frees a 16 GiB ring stalls for as long as other streams' hash jobs run)
     std::mutex pool_mu;
     std::vector<pbse::DevBuf> win_pool;
+    // ... and whole stream contexts (cut contexts, pinned staging, tee buffers) of closed streams, for the same reason:
+    // a writer that closes one archive while its next one is already being hashed must not sit in hipFree/hipHostFree
+    // until those hash jobs end (stream.cpp: stream_park / stream_unpark)
+    std::vector<pbsgpu_stream *> stream_pool;
     std::vector<hipStream_t> copy_streams;
     std::atomic<uint32_t> copy_rr{0};
     pbse::HashDispatcher hd;
@@ -305,6 +314,9 @@ int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes);
 // Large copies are therefore split over a few helper threads of a process-wide pool (started at the first large
 // write; PBSGPU_COPY_THREADS, default 4 incl. the caller, 1 = off). Small writes stay on the caller's thread.
 void parallel_memcpy(void *dst, const void *src, size_t n);
+
+// stream contexts parked in pbsgpu_engine::stream_pool (stream.cpp): really free them (engine teardown, trim)
+void stream_pool_release(pbsgpu_engine *e);
 
 // hash dispatcher (stream.cpp)
 int hd_init(pbsgpu_engine *e);

@@ -119,9 +119,12 @@ int hd_init(pbsgpu_engine *e) {
     if (const char *v = getenv("PBSGPU_HASH_LANES")) nlanes = std::min(16, std::max(1, atoi(v)));
     hd.lanes.assign((size_t)nlanes, nullptr);
     hd.lane_job.assign((size_t)nlanes, nullptr);
-    hd.min_interval_ms = 0.0;  // greedy by default: measured best with several writers (engine_internal.h)
+    // launches are SPACED by 0.8 x (chain of a max-size chunk) / lanes = 61 ms at 16 MiB chunks and 6 lanes (policy and
+    // measurements: engine_internal.h); small maximum chunk sizes make the interval vanish
+    hd.min_interval_ms = 0.8 * ((double)e->cfg.max / 64.0 * 1.75e-3) / (double)nlanes;
     hd.t0_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (const char *v = getenv("PBSGPU_HASH_INTERVAL_MS")) hd.min_interval_ms = atof(v);
+    if (const char *v = getenv("PBSGPU_HASH_BYPASS_GIB")) hd.bypass_bytes = (uint64_t)(atof(v) * 1073741824.0);
     for (auto &st : hd.lanes) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return PBSGPU_OK;
 }
@@ -178,7 +181,7 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev, 
     HashJob *j = hd.open;
     if (!j || j->descs.empty()) return PBSGPU_OK;
     // pacing (engine_internal.h): go at once when a good amount of work is waiting, otherwise keep launches spaced
-    if (!force && hd.open_bytes < (1ull << 30) && hd_now_ms() - hd.last_launch_ms < hd.min_interval_ms) return PBSGPU_OK;
+    if (!force && hd.open_bytes < hd.bypass_bytes && hd_now_ms() - hd.last_launch_ms < hd.min_interval_ms) return PBSGPU_OK;
     int lane = -1;
     for (int i = 0; i < (int)hd.lanes.size() && lane < 0; ++i) {
         HashJob *lj = hd.lane_job[i];
@@ -280,7 +283,7 @@ int hd_ensure_launched(pbsgpu_engine *e, HashJob *j, bool block) {
             std::lock_guard<std::mutex> lk(hd.mu);
             if (j->state == HashJob::LAUNCHED) return PBSGPU_OK;
             bool launched = false;
-            CHK(hd_try_launch_locked(e, &launched, &busy));
+            CHK(hd_try_launch_locked(e, &launched, &busy, block));  // someone waits for this job: no pacing
             if (launched || j->state == HashJob::LAUNCHED) return PBSGPU_OK;
         }
         if (!block) return PBSGPU_OK;
@@ -361,7 +364,8 @@ struct pbsgpu_stream {
     uint64_t written = 0;
     uint64_t inject_total = 0;
     uint32_t section = 0;
-    bool finished = false;
+    bool finished = false;  // input closed (the final flush is enqueued)
+    bool drained = false;   // ... and every record has been delivered to `out`
     std::deque<uint64_t> suggested;  // pending suggested boundaries (absolute offsets, ascending)
     std::deque<WindowInFlight> inflight;
     std::deque<pbsgpu_record> out;
@@ -741,11 +745,23 @@ void chunker_push_tail(pbsgpu_chunker *c, const uint8_t *p, size_t n) {
 
 extern "C" {
 
+static pbsgpu_stream *stream_unpark(pbsgpu_engine *e, uint64_t window_bytes);  // contexts of closed streams are recycled, see below
+
 int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream **out) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = nullptr;
     if (window_bytes == 0) window_bytes = 256ull << 20;
     if (window_bytes < e->cfg.max) window_bytes = e->cfg.max;
+    if (pbsgpu_stream *parked = stream_unpark(e, window_bytes)) {
+        int st = set_device(e);
+        if (st == PBSGPU_OK) st = stream_buffer_ensure(parked, parked->dev[0]);
+        if (st != PBSGPU_OK) {
+            pbsgpu_stream_destroy(parked);
+            return st;
+        }
+        *out = parked;
+        return PBSGPU_OK;
+    }
     pbsgpu_stream *s = new (std::nothrow) pbsgpu_stream();
     if (!s) return PBSGPU_E_NOMEM;
     engine_ref(e);
@@ -787,6 +803,108 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     return PBSGPU_OK;
 }
 
+// ---- stream contexts are recycled --------------------------------------------------------------------------------
+// Everything a stream owns besides its window buffers (two cut contexts with their device tables and mapped pinned
+// result buffers, 3 x 32 MiB pinned staging, the tee's buffers, events, one HIP stream) is parked in the engine when the
+// stream closes and handed to the engine's next stream of the same window size. Freeing it (hipFree / hipHostFree) waits
+// for the whole device — for a writer that closes archive k while archive k+1 is already being hashed that is a stall
+// of up to one chunk chain (0.45 s) on the thread that should be writing.
+static void stream_free_context(pbsgpu_stream *s) {
+    for (auto &ev : s->piece_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    s->cut[1].destroy();
+    s->cut[0].destroy();
+    for (auto &b : s->dev) b.release();
+    for (auto &b : s->stage) b.release();
+    s->tee_states.release();
+    s->tee_queue.release();
+    s->tee_items.release();
+    s->tee_sums.release();
+    s->h_tee_items.release();
+    s->h_tee_out.release();
+    for (auto &ev : s->stage_ev)
+        if (ev) (void)hipEventDestroy(ev);
+}
+
+// back to the state pbsgpu_stream_create leaves a stream in (the resources stay)
+static void stream_reset_state(pbsgpu_stream *s) {
+    s->dev.clear();
+    s->dev.resize(2);
+    s->dev_busy.assign(2, 0);
+    s->cur = 0;
+    s->carry = 0;
+    s->fill = 0;
+    s->cut_next = 0;
+    s->piece_used[0] = s->piece_used[1] = false;
+    s->pend = PendingCut{};
+    s->stage_idx = 0;
+    s->stage_fill = 0;
+    s->reserved = -1;
+    s->base = 0;
+    s->written = 0;
+    s->inject_total = 0;
+    s->section = 0;
+    s->finished = false;
+    s->drained = false;
+    s->suggested.clear();
+    s->inflight.clear();
+    s->out.clear();
+    s->descs.clear();
+    s->files.clear();
+    s->next_file = 0;
+    s->n_stateful = 0;
+    s->file_open = false;
+    s->entry_left = 0;
+    s->in_entry = false;
+    s->file_out.clear();
+}
+
+static bool stream_park(pbsgpu_engine *e, pbsgpu_stream *s) {
+    static const size_t limit = []() -> size_t {
+        const char *v = getenv("PBSGPU_STREAM_CTX_POOL");
+        return (size_t)(v ? std::max(0L, atol(v)) : 8L);
+    }();
+    stream_reset_state(s);
+    s->eng = nullptr;  // (a parked context holds no reference: the engine owns it)
+    std::lock_guard<std::mutex> lk(e->pool_mu);
+    if (e->destroyed || e->stream_pool.size() >= limit) return false;
+    e->stream_pool.push_back(s);
+    return true;
+}
+
+static pbsgpu_stream *stream_unpark(pbsgpu_engine *e, uint64_t window_bytes) {
+    pbsgpu_stream *s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        for (size_t i = 0; i < e->stream_pool.size(); ++i)
+            if (e->stream_pool[i]->window == window_bytes) {
+                s = e->stream_pool[i];
+                e->stream_pool.erase(e->stream_pool.begin() + (long)i);
+                break;
+            }
+    }
+    if (!s) return nullptr;
+    engine_ref(e);
+    s->eng = e;
+    return s;
+}
+
+}  // extern "C"
+namespace pbse {
+void stream_pool_release(pbsgpu_engine *e) {
+    std::vector<pbsgpu_stream *> v;
+    {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        v.swap(e->stream_pool);
+    }
+    for (pbsgpu_stream *s : v) {
+        stream_free_context(s);
+        delete s;
+    }
+}
+}  // namespace pbse
+extern "C" {
+
 void pbsgpu_stream_destroy(pbsgpu_stream *s) {
     if (!s) return;
     pbsgpu_engine *e = s->eng;
@@ -799,18 +917,14 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
         }
         for (int k = 0; k < kStreamStages; ++k)
             if (s->stage_ev[k]) (void)hipEventSynchronize(s->stage_ev[k]);  // pieces still copying from our staging
-        for (auto &ev : s->piece_ev)
-            if (ev) (void)hipEventDestroy(ev);
         if (s->hs) (void)hipStreamSynchronize(s->hs);
-        s->cut[1].destroy();
-        s->cut[0].destroy();
         {   // window buffers go back to the engine for the next stream (hipFree waits for the whole device, i.e. for other
             // streams' running hash jobs). The pool is bounded in BYTES (one default ring, PBSGPU_STREAM_POOL_GIB): a
-            // long-lived engine that opens one stream per backup job must not pin tens of GiB of HBM; what does not fit
-            // is freed below. pbsgpu_engine_trim() empties the pool on request.
+            // long-lived engine that opens one stream per backup job must not pin tens of GiB of HBM for ever; what does
+            // not fit is freed below. pbsgpu_engine_trim() empties the pool on request.
             static const uint64_t pool_limit = []() -> uint64_t {
                 const char *v = getenv("PBSGPU_STREAM_POOL_GIB");
-                return (uint64_t)(v ? std::max(0L, atol(v)) : 16L) << 30;
+                return (uint64_t)(v ? std::max(0L, atol(v)) : 32L) << 30;
             }();
             std::lock_guard<std::mutex> lk(e->pool_mu);
             uint64_t held = 0;
@@ -822,15 +936,11 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
                 }
         }
         for (auto &b : s->dev) b.release();
-        for (auto &b : s->stage) b.release();
-        s->tee_states.release();
-        s->tee_queue.release();
-        s->tee_items.release();
-        s->tee_sums.release();
-        s->h_tee_items.release();
-        s->h_tee_out.release();
-        for (auto &ev : s->stage_ev)
-            if (ev) (void)hipEventDestroy(ev);
+        if (stream_park(e, s)) {  // the context waits for the engine's next stream: nothing else is freed, nothing waits
+            engine_unref(e);
+            return;
+        }
+        stream_free_context(s);
     }
     delete s;
     if (e) engine_unref(e);
@@ -989,15 +1099,40 @@ int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
     return PBSGPU_OK;
 }
 
-int pbsgpu_stream_finish(pbsgpu_stream *s) {
-    if (!s) return PBSGPU_E_INVALID;
+// close the input: the tail chunk is cut, every chunk is with the hash jobs; nothing here waits for a hash
+static int stream_close_input(pbsgpu_stream *s) {
     if (s->finished) return PBSGPU_OK;
     if (s->reserved >= 0 || s->file_open) return PBSGPU_E_STATE;
     CHK(set_device(s->eng));
     CHK(stream_push_staged(s));
     CHK(stream_flush(s, true));
-    CHK(stream_drain(s));
     s->finished = true;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_finish(pbsgpu_stream *s) {
+    if (!s) return PBSGPU_E_INVALID;
+    CHK(stream_close_input(s));
+    if (s->drained) return PBSGPU_OK;
+    CHK(stream_drain(s));
+    s->drained = true;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_stream_finish_begin(pbsgpu_stream *s) {
+    if (!s) return PBSGPU_E_INVALID;
+    return stream_close_input(s);
+}
+
+int pbsgpu_stream_done(pbsgpu_stream *s, int *done) {
+    if (!s || !done) return PBSGPU_E_INVALID;
+    *done = 0;
+    if (!s->finished) return PBSGPU_OK;
+    if (!s->drained) {
+        CHK(stream_reap(s));
+        s->drained = !s->pend.active && s->inflight.empty();
+    }
+    *done = s->drained ? 1 : 0;
     return PBSGPU_OK;
 }
 

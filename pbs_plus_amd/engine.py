@@ -333,6 +333,16 @@ class PayloadStream:
     def finish(self) -> None:
         check(self._L.pbsgpu_stream_finish(self._h), "stream_finish")
 
+    def finish_begin(self) -> None:
+        """Close the input without waiting for the last records (the writer goes on with its next archive); poll() keeps
+        delivering, done() tells when the last record is out."""
+        check(self._L.pbsgpu_stream_finish_begin(self._h), "stream_finish_begin")
+
+    def done(self) -> bool:
+        d = C.c_int()
+        check(self._L.pbsgpu_stream_done(self._h, C.byref(d)), "stream_done")
+        return bool(d.value)
+
     def poll(self, cap: int = 1 << 16) -> np.ndarray:
         outs = []
         while True:

@@ -126,3 +126,71 @@ def test_sha256_many_policy_and_trim(eng4k):
     freed = C.c_uint64()
     assert L.pbsgpu_engine_trim(eng4k._h, C.byref(freed)) == 0 and freed.value > 0
     assert L.pbsgpu_engine_trim(eng4k._h, C.byref(freed)) == 0 and freed.value == 0
+
+
+def test_archives_back_to_back_finish_begin_and_recycled_stream_contexts(eng4k, O):
+    """pbsgpu_stream_finish_begin / pbsgpu_stream_done: a writer closes an archive's input and goes on with the next
+    archive while the first one's last chunks are hashed; closed streams hand their contexts (cut contexts, staging, tee
+    buffers) to the engine's next stream of the same window size — five generations through the same contexts, with the
+    XXH3 tee and a forced cut in some of them, every archive bit-exact vs the oracle."""
+    import time
+
+    import xxhash
+
+    from pbs_plus_amd import PayloadStream, _lib
+
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(321)
+    draining = []
+    checked = 0
+
+    def settle(block):
+        nonlocal checked
+        for item in list(draining):
+            ps, data, want_files, parts = item
+            if block:
+                ps.finish()
+            parts.append(ps.poll())
+            if block or ps.done():
+                assert ps.done()
+                parts.append(ps.poll())
+                got = np.concatenate(parts)
+                want = O.chunk_and_digest(cfg, data, [(0, data.size)])
+                assert records_equal(got, want), describe_mismatch(got, want)
+                files = ps.poll_files()
+                assert [(f[1], f[2]) for f in files] == want_files
+                ps.close()
+                draining.remove(item)
+                checked += 1
+
+    for gen in range(5):
+        n = int(rng.integers(700_000, 2_500_000))
+        data = O.fill(n, 500 + gen, gen % 4)
+        ps = PayloadStream(eng4k, window_bytes=1 << 20)
+        want_files = []
+        pos = 0
+        while pos < n:
+            m = min(int(rng.integers(1, 300_000)), n - pos)
+            tee = gen % 2 == 1
+            if tee:
+                ps.begin_file()
+            ps.write(data[pos:pos + m])
+            if tee:
+                ps.end_file()
+                want_files.append((m, xxhash.xxh3_64_intdigest(data[pos:pos + m].tobytes())))
+            pos += m
+            settle(False)
+        ps.finish_begin()
+        assert ps.bytes_written() == n
+        with pytest.raises(_lib.PbsGpuError) as ei:
+            ps.write(data[:10])
+        assert ei.value.status == _lib.E_STATE
+        draining.append((ps, data, want_files, []))
+        assert len(draining) <= 5
+    t0 = time.time()
+    while draining and time.time() - t0 < 30:
+        settle(False)
+        time.sleep(0.002)
+    assert not draining, "pbsgpu_stream_done never reported the end"
+    settle(True)
+    assert checked == 5
