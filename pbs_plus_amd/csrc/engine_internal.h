@@ -215,6 +215,7 @@ struct HashDispatcher {
     double last_launch_ms = -1e18;
     double t0_ms = 0;  // trace time base
     double min_interval_ms = 60.0;
+    int regular_lanes = 6;          // lanes [0, regular_lanes) take paced launches; the rest are the reserve
     uint64_t bypass_bytes = ~0ull;  // a launch goes at once, whatever the pacing, when this much is waiting
 };
 

@@ -117,8 +117,14 @@ int hd_init(pbsgpu_engine *e) {
     hd.num_cus = e->num_cus;
     int nlanes = kHashLanes;
     if (const char *v = getenv("PBSGPU_HASH_LANES")) nlanes = std::min(16, std::max(1, atoi(v)));
-    hd.lanes.assign((size_t)nlanes, nullptr);
-    hd.lane_job.assign((size_t)nlanes, nullptr);
+    // + reserve lanes, taken only by a job somebody BLOCKS on (the last job of an archive, a writer whose ring is full)
+    // when every regular lane is busy: lanes do not stay evenly staggered (jobs last 0.3-0.55 s depending on their longest
+    // chunk), so without them such a job waits up to a whole job time for a lane
+    int nreserve = 0;  // (measured: no gain for one writer, -15 % for eight, profiles/r03_hostfeed_hash_job_pacing.log)
+    if (const char *v = getenv("PBSGPU_HASH_RESERVE_LANES")) nreserve = std::min(8, std::max(0, atoi(v)));
+    hd.regular_lanes = nlanes;
+    hd.lanes.assign((size_t)(nlanes + nreserve), nullptr);
+    hd.lane_job.assign((size_t)(nlanes + nreserve), nullptr);
     // launches are SPACED by 0.8 x (chain of a max-size chunk) / lanes = 61 ms at 16 MiB chunks and 6 lanes (policy and
     // measurements: engine_internal.h); small maximum chunk sizes make the interval vanish
     hd.min_interval_ms = 0.8 * ((double)e->cfg.max / 64.0 * 1.75e-3) / (double)nlanes;
@@ -183,7 +189,8 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev, 
     // pacing (engine_internal.h): go at once when a good amount of work is waiting, otherwise keep launches spaced
     if (!force && hd.open_bytes < hd.bypass_bytes && hd_now_ms() - hd.last_launch_ms < hd.min_interval_ms) return PBSGPU_OK;
     int lane = -1;
-    for (int i = 0; i < (int)hd.lanes.size() && lane < 0; ++i) {
+    const int usable = force ? (int)hd.lanes.size() : hd.regular_lanes;
+    for (int i = 0; i < usable && lane < 0; ++i) {
         HashJob *lj = hd.lane_job[i];
         if (!lj) {
             lane = i;
@@ -203,8 +210,8 @@ int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev, 
     if (lane < 0) {
         if (busy_ev) {  // the job launched first is the next to finish (all last about one max-size chunk chain)
             HashJob *oldest = hd.lane_job[0];
-            for (auto *lj : hd.lane_job)
-                if (lj->launched_ms < oldest->launched_ms) oldest = lj;
+            for (int i = 0; i < usable; ++i)
+                if (hd.lane_job[i]->launched_ms < oldest->launched_ms) oldest = hd.lane_job[i];
             *busy_ev = oldest->done;
         }
         return PBSGPU_OK;
@@ -410,6 +417,10 @@ int stream_complete_oldest(pbsgpu_stream *s, bool block) {
         std::memcpy(w.recs[i].digest, w.job->digest(w.first + (uint32_t)i), 32);
         s->out.push_back(w.recs[i]);
     }
+    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
+    if (trace && w.job->refs.load() == 1)  // the job's last window: the job is over
+        fprintf(stderr, "[pbsgpu] t=%.1f ms hash job of lane %d (launched t=%.1f ms, %u chunks) delivered%s\n",
+                hd_now_ms() - s->eng->hd.t0_ms, w.job->lane, w.job->launched_ms - s->eng->hd.t0_ms, w.job->n, block ? " (waited)" : "");
     w.job->refs.fetch_sub(1);
     s->dev_busy[w.buf] = 0;
     s->inflight.pop_front();
@@ -680,6 +691,10 @@ int stream_reap(pbsgpu_stream *s) {
 int stream_drain(pbsgpu_stream *s) {
     CHK(set_device(s->eng));
     CHK(stream_resolve_pending(s));
+    // The NEWEST window's job first: it is usually still the open job, and nothing launches it while this thread sits in
+    // the older jobs' events below — it then started only after the last of them (traced: +0.34 s on every finish). Now it
+    // takes the first lane that frees up and runs beside the older jobs.
+    if (!s->inflight.empty()) CHK(hd_ensure_launched(s->eng, s->inflight.back().job, true));
     while (!s->inflight.empty()) CHK(stream_complete_oldest(s, true));
     return PBSGPU_OK;
 }
