@@ -505,10 +505,6 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         CHK(r->seg_newc.ensure((size_t)r->max_streams * 8 + 16));
         CHK(r->seg_open.ensure((size_t)r->max_streams * 4 + 16));
         CHK(r->recs.ensure((size_t)r->rec_cap * sizeof(pbsgpu_record) + 64));
-        HIPCHK(hipMemset(r->ctl.p, 0, 256));
-        HIPCHK(hipMemset(r->streams.p, 0, (size_t)r->max_streams * sizeof(pbsk::RingStreamState)));
-        HIPCHK(hipMemset(r->pending.p, 0, (size_t)r->npages * 4 + 64));
-        HIPCHK(hipMemset(r->scalars.p, 0, pbsk::kRsCount * 4 + 64));
         CHK(r->cells.ensure((size_t)r->ncells * 64));
         CHK(r->heartbeat.ensure(256));
         std::memset(r->heartbeat.p, 0, 256);
@@ -522,6 +518,17 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         std::memset(r->inputs.p, 0, r->input_stride * kInputs);
         HIPCHK(hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&r->fs, hipStreamNonBlocking));
+        // The device-side state starts from zero — cleared ON THE CONTROL STREAM and waited for. A plain hipMemset is
+        // queued on the null stream and returns at once for device memory; the ring's streams are non-blocking, i.e. not
+        // ordered against the null stream: when the null stream was held up (it waits for every blocking stream's earlier
+        // work, e.g. the previous engine's last kernels) the clear arrived AFTER the first rounds had run and wiped queue
+        // tail, stream states and page reference counts — pages never came back, lanes waited at positions the tail had
+        // been reset below (the one-in-a-few-hundred hang of the small-ring tests).
+        HIPCHK(hipMemsetAsync(r->ctl.p, 0, 256, r->cs));
+        HIPCHK(hipMemsetAsync(r->streams.p, 0, (size_t)r->max_streams * sizeof(pbsk::RingStreamState), r->cs));
+        HIPCHK(hipMemsetAsync(r->pending.p, 0, (size_t)r->npages * 4 + 64, r->cs));
+        HIPCHK(hipMemsetAsync(r->scalars.p, 0, pbsk::kRsCount * 4 + 64, r->cs));
+        HIPCHK(hipStreamSynchronize(r->cs));
         for (auto &ev : r->ev_fill) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         // the service must never share a hardware queue with a stream that enqueues behind it (packets of one queue
         // run in order: work queued behind a kernel that only ends on request would never start). HIP keeps one queue

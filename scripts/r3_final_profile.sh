@@ -10,6 +10,8 @@ OUT=$ROOT/${1:-gpurun_out/r3final}
 mkdir -p $OUT
 cd $ROOT
 (time timeout 1200 python -X faulthandler -m pytest tests -x -q -m gpu) > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log | cut -c1-300
+(timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") 2>&1 | tail -2
+(timeout 400 python scripts/r3_ring_stress.py ${STRESS_ITERS:-300}) > $OUT/ring_stress.log 2>&1; tail -2 $OUT/ring_stress.log | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
 EXP="python3 $ROOT/scripts/rocpd_export.py"
 db() { find $1 -name "*_results.db" | head -1; }

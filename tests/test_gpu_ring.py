@@ -339,3 +339,37 @@ def test_ring_service_gives_up_without_a_heartbeat_and_the_ring_fails_loudly(gpu
     assert ei.value.status == _lib.E_STATE
     ring.close()
     eng.close()
+
+
+def test_ring_create_is_ordered_against_a_busy_null_stream(gpu_lib, O):
+    """The ring's device-side state (queue control words, stream states, page reference counts) is cleared at create — on
+    the ring's own control stream. A plain hipMemset is queued on the NULL stream and returns at once; the ring's streams
+    are non-blocking, i.e. not ordered against it, and the clear used to land after the first rounds once in a few
+    hundred creates (scripts/r3_probe_memset_order.py, profiles/r03_probe_hipmemset_ordering.log: 1 in 500 on an idle null
+    stream, always on a busy one) — the queue tail and the page counts were wiped, no page ever came back. Here: creates
+    right behind 0.1 s of large memsets queued on the null stream through the same HIP runtime, every page must come back.
+    (Not a deterministic reproducer of the old defect — create's later allocations happened to wait for the null stream.)"""
+    import ctypes as C
+
+    from pbs_plus_amd import PageRing
+
+    hip = C.CDLL("libamdhip64.so.7", mode=os.RTLD_NOLOAD)      # the runtime instance libpbsgpu.so is linked against
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemset.restype = C.c_int
+    jobs = [(91, 0, (1 << 20) + 5), (92, 1, 300 * 1024), (93, 4, 700 * 1024 + 3), (94, 0, 64)]
+    want = _oracle_records(O, 4096, jobs)
+    eng = _engine(4096)
+    big = eng.alloc(64 << 30)
+    for rep in range(4):
+        for _ in range(8):
+            assert hip.hipMemset(big.ptr, rep, big.nbytes) == 0     # asynchronous for device memory: queued on the null stream
+        ring = PageRing(eng, arena_bytes=10 * (65536 + 256), page_bytes=65536, max_streams=2, sha_cus=2, round_pages=3)
+        got = ring.ingest_synthetic(jobs, timeout_s=30.0, concurrent=2)
+        ring.quiesce()
+        for i, (g, w) in enumerate(zip(got, want)):
+            _assert_same(g, w, (rep, i))
+        st = ring.stats()
+        assert st["pages_free"] == st["pages_total"], st
+        ring.close()
+    big.free()
+    eng.close()
