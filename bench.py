@@ -627,12 +627,11 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
                          "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
         except BaseException as exc:  # noqa: BLE001
             res[name] = {"error": repr(exc)}
-    # The host-fed legs go LAST. Open observation (profiles/r03_extras_leg_order.log): whatever runs in this process behind
-    # the first host-fed leg loses 20-30 % (with the host-fed legs first: batch path 386 instead of 497 GiB/s, ring legs
-    # 289 / 343 instead of 424 / 520, one writer 31 instead of 40; the eight-writer leg therefore shows 29-33 here and
-    # 38-44 in a process of its own). Not the allocator (400 x 272 MiB of churn changes nothing,
-    # scripts/r3_probe_alloc_churn.py) and not visible in a plain one-slot batch pass after eight streams
-    # (scripts/r3_probe_queue_residue.py).
+    # The host-fed legs go LAST (profiles/r03_extras_leg_order.log): whatever runs in this process behind the first
+    # host-fed leg loses 20-30 % (with the host-fed legs first: batch path 386 instead of 497 GiB/s, ring legs 289 / 343
+    # instead of 424 / 520, one writer 31 instead of 40; the eight-writer leg therefore shows 29-33 here and 38-44 in a
+    # process of its own). Cause: a process that has used more than ~20 hardware queues is time-sliced by the hardware
+    # scheduler from then on (GPU_MAX_HW_QUEUES=24 here; with 20 the effect is gone) - DESIGN.md section 9.
     for label, key, producers, gib_steps, archives in (("hostfeed_1_writer", "hostfeed1", 1, 96, 1),
                                                        ("hostfeed_1_writer_4_archives", "hostfeed1", 1, 96, 4),
                                                        ("hostfeed_8_writers", "hostfeed8", 8, 32, 1)):
