@@ -102,6 +102,10 @@ static void free_engine(pbsgpu_engine *e) {
     }
     for (auto &b : e->win_pool) b.release();
     stream_pool_release(e);
+    for (auto cs : e->cut_streams) {
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamDestroy(cs);
+    }
     for (auto &s : e->slots)
         if (s) s->destroy();  // a failed create leaves a null entry behind (new(nothrow) Slot)
     for (auto &s : e->aux)

@@ -257,6 +257,13 @@ struct pbsgpu_engine {
     // a writer that closes one archive while its next one is already being hashed must not sit in hipFree/hipHostFree
     // until those hash jobs end (stream.cpp: stream_park / stream_unpark)
     std::vector<pbsgpu_stream *> stream_pool;
+    // OPT-IN (PBSGPU_SHARED_CUT_STREAMS=n, default 0 = one HIP stream per payload stream): n engine-wide HIP streams
+    // that all payload streams put their cuts, tees and carry copies on — short kernels, the hash jobs have their own
+    // lanes. Eight writers then need 2 copy + 6 hash + n cut streams instead of 16 + the engine's own, which keeps a
+    // process under the ~20 hardware queues beyond which every kernel pays 19 %. Written at the end of
+    // round 3 without GPU minutes left to measure it: to be A/B'd before it becomes the default.
+    std::vector<hipStream_t> cut_streams;
+    uint32_t cut_rr = 0;
     std::vector<hipStream_t> copy_streams;
     std::atomic<uint32_t> copy_rr{0};
     pbse::HashDispatcher hd;

@@ -792,7 +792,23 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     size_t nb = (size_t)((budget_gib << 30) / s->devcap);
     s->max_bufs = std::min<size_t>(std::max<size_t>(nb, 4), 256);
     int st = set_device(e);
-    if (st == PBSGPU_OK) st = s->cut[0].init();
+    hipStream_t shared = nullptr;
+    if (st == PBSGPU_OK) {  // opt-in: engine-wide cut streams (engine_internal.h, cut_streams)
+        static const int nshared = []() {
+            const char *v = getenv("PBSGPU_SHARED_CUT_STREAMS");
+            return v ? std::min(16, std::max(0, atoi(v))) : 0;
+        }();
+        if (nshared > 0) {
+            std::lock_guard<std::mutex> lk(e->pool_mu);
+            while ((int)e->cut_streams.size() < nshared && st == PBSGPU_OK) {
+                hipStream_t cs = nullptr;
+                if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+                else e->cut_streams.push_back(cs);
+            }
+            if (st == PBSGPU_OK) shared = e->cut_streams[e->cut_rr++ % e->cut_streams.size()];
+        }
+    }
+    if (st == PBSGPU_OK) st = s->cut[0].init(shared);
     if (st == PBSGPU_OK) st = s->cut[1].init(s->cut[0].stream);
     s->hs = s->cut[0].stream;
     for (auto &ev : s->piece_ev)
