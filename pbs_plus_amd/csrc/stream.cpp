@@ -762,12 +762,20 @@ extern "C" {
 
 static pbsgpu_stream *stream_unpark(pbsgpu_engine *e, uint64_t window_bytes);  // contexts of closed streams are recycled, see below
 
+static size_t stream_ring_limit(size_t devcap) {  // window buffers per stream (PBSGPU_STREAM_RING_GIB, default 32 GiB)
+    size_t budget_gib = 32;
+    if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) budget_gib = (size_t)std::max(1L, atol(v));
+    const size_t nb = (size_t)((budget_gib << 30) / devcap);
+    return std::min<size_t>(std::max<size_t>(nb, 4), 256);
+}
+
 int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream **out) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = nullptr;
     if (window_bytes == 0) window_bytes = 256ull << 20;
     if (window_bytes < e->cfg.max) window_bytes = e->cfg.max;
     if (pbsgpu_stream *parked = stream_unpark(e, window_bytes)) {
+        parked->max_bufs = stream_ring_limit(parked->devcap);  // (a previous life under memory pressure may have lowered it)
         int st = set_device(e);
         if (st == PBSGPU_OK) st = stream_buffer_ensure(parked, parked->dev[0]);
         if (st != PBSGPU_OK) {
@@ -787,10 +795,7 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
     // Ring limit. Chunks of up to 16 MiB hash for ~0.45 s, so a stream needs (ingest rate x ~0.6 s) of windows in
     // flight: 32 GiB carries ~50 GiB/s, the H2D rate (16 GiB held one fast writer at 26 GiB/s). Buffers are allocated on
     // demand — a slow producer never grows its ring — and a failed allocation is back-pressure, not an error.
-    size_t budget_gib = 32;
-    if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) budget_gib = (size_t)std::max(1L, atol(v));
-    size_t nb = (size_t)((budget_gib << 30) / s->devcap);
-    s->max_bufs = std::min<size_t>(std::max<size_t>(nb, 4), 256);
+    s->max_bufs = stream_ring_limit(s->devcap);
     int st = set_device(e);
     hipStream_t shared = nullptr;
     if (st == PBSGPU_OK) {  // opt-in: engine-wide cut streams (engine_internal.h, cut_streams)
