@@ -26,6 +26,9 @@ CASES = [
     ("rand_avg64k", 65536, [(31, 0, 8 << 20)]),
     ("zero_extents_avg64k", 65536, [(41, 3, 6 << 20), (42, 1, 1 << 20)]),
     ("rand_avg4m", 4 << 20, [(51, 0, 48 << 20)]),
+    # generator kind 4 (two ChaCha quarter-rounds per 16 bytes): the bytes the page-ring bench refills its pages with
+    ("arx_avg4k", 4096, [(61, 4, 1 << 20), (62, 4, 65)]),
+    ("arx_avg4m", 4 << 20, [(63, 4, 40 << 20)]),
     # upstream Proxmox chunker test input: LE u32 counters 0..262143, avg 64 KiB (generated, not filled)
 ]
 

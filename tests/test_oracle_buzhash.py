@@ -214,10 +214,13 @@ def test_golden_fixture(O):
 
 
 def test_fill_is_offset_consistent(O):
-    for kind in range(4):
+    for kind in range(5):
         whole = O.fill(300_000, 5, kind)
-        for off in (8, 4096, 65536 + 8, 131072):
+        for off in ((16, 4096, 65536 + 16, 131072) if kind == 4 else (8, 4096, 65536 + 8, 131072)):   # kind 4 works in 16-byte blocks
             assert np.array_equal(O.fill(1000, 5, kind, stream_off=off), whole[off:off + 1000]), (kind, off)
+    arx = O.fill(4 << 20, 5, 4)      # the ring bench's refill bytes: every byte value about equally often
+    hist = np.bincount(arx, minlength=256)
+    assert hist.min() > 0.9 * arx.size / 256 and hist.max() < 1.1 * arx.size / 256
     assert not O.fill(1 << 16, 5, 1).any()
     z = O.fill(8 << 20, 5, 3)
     frac = 1.0 - np.count_nonzero(z.reshape(-1, 65536).any(axis=1)) / (z.size / 65536)
