@@ -38,7 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight batch: ROCm's default of 4 would make engine streams share queues
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -19,7 +19,7 @@ import os as _os
 # hardware queues would make them share queues, and with 8 two of eight slots still collide (measured: a
 # pair of batches then runs back to back). Must be set before the HIP runtime initialises (import this
 # package first).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 from . import buzhash  # noqa: F401,E402
 from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401,E402

@@ -13,7 +13,7 @@
 // (default 4) and reads the variable when the HIP runtime initialises, i.e. at the first HIP call of the process.
 // Setting a default when this library is loaded covers hosts that bind the C ABI directly (cgo, JNI, ctypes)
 // without going through the Python package; an explicit setting of the host always wins.
-__attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+__attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
 
 namespace pbse {
 std::atomic<int> g_last_hip_error{0};

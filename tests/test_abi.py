@@ -145,7 +145,7 @@ def test_product_never_touches_the_oracle():
 
 
 def test_library_load_sets_hw_queue_default_but_never_overrides():
-    """libpbsgpu.so's load-time constructor exports GPU_MAX_HW_QUEUES=24 for hosts that bind the C ABI directly
+    """libpbsgpu.so's load-time constructor exports GPU_MAX_HW_QUEUES=20 for hosts that bind the C ABI directly
     (the engine overlaps up to 16 batches on separate HIP streams; ROCm's default of 4 queues serialises them),
     and leaves an explicit setting of the host alone."""
     import subprocess
@@ -159,7 +159,7 @@ def test_library_load_sets_hw_queue_default_but_never_overrides():
             "print((g(b'GPU_MAX_HW_QUEUES') or b'').decode())\n" % LIB_PATH)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
-    assert out.stdout.strip() == "24", out.stdout + out.stderr
+    assert out.stdout.strip() == "20", out.stdout + out.stderr
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="6"), capture_output=True,
                          text=True, timeout=120)
     assert out.stdout.strip() == "6", out.stdout + out.stderr
