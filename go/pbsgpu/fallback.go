@@ -108,5 +108,7 @@ func (r *Ring) Poll(uint32, int) ([]ChunkInfo, bool, error)                     
 func (r *Ring) PollAny(int, int) ([]ChunkInfo, []uint32, error)                  { return nil, nil, ErrNotBuilt }
 func (r *Ring) CloseStream(uint32) error                                         { return ErrNotBuilt }
 func (r *Ring) Quiesce() error                                                   { return ErrNotBuilt }
+func (r *Ring) Park() error                                                      { return ErrNotBuilt }
+func (r *Ring) Suggest(uint32, uint64) error                                     { return ErrNotBuilt }
 func (r *Ring) Stats() (RingStats, error)                                        { return RingStats{}, ErrNotBuilt }
 func (r *Ring) Close()                                                           {}

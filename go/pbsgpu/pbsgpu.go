@@ -631,7 +631,11 @@ func (e *Engine) XXH3Files(buf []byte, offsets, lengths []uint64) ([]uint64, err
 // back page by page as soon as the chunks touching a page have been read by the persistent SHA-256 service, not when a
 // whole batch has been hashed. One goroutine drives a Ring (like one goroutine owns a writer,
 // internal/tapeio/converter.go:672-680); bytes reach a stream's pages through Reserve/Commit (a device pointer for
-// a DMA, a peer GPU or a kernel) or WriteHost.
+// a DMA, a peer GPU or a kernel). HOST bytes go through PayloadStream (pbsgpu_stream_*), which is a client of the engine's
+// own ring: pinned staging, H2D straight into a reserved page, the same cut rounds and SHA-256 service.
+// The goroutine may block in a Read for as long as it likes: a ring that is not called for the idle timeout stops its idle
+// service by itself and the next Pump starts it again (nothing is lost); Park does so at once. A stream whose data
+// overflows the candidate provisioning (a crafted short period) fails alone with ErrDensity, the others go on.
 type Ring struct {
 	h   *C.pbsgpu_ring
 	eng *Engine
@@ -754,6 +758,21 @@ func (r *Ring) CloseStream(stream uint32) error {
 func (r *Ring) Quiesce() error {
 	defer runtime.KeepAlive(r)
 	return check(C.pbsgpu_ring_quiesce(r.h), "ring_quiesce")
+}
+
+// Park is Quiesce without the wait: the service ends by itself once it has hashed what is enqueued and the next Pump
+// starts a new one. Call it before the driving goroutine sits in a blocking Read (internal/tapeio/converter.go:672-680)
+// if hipFree / device-wide synchronisation elsewhere in the process must not wait for this ring. Not calling it is safe
+// too: a ring that is not called for PBSGPU_RING_IDLE_TIMEOUT_S stops its idle service on its own and loses nothing.
+func (r *Ring) Park() error {
+	defer runtime.KeepAlive(r)
+	return check(C.pbsgpu_ring_park(r.h), "ring_park")
+}
+
+// Suggest announces a suggested chunk boundary `offset` bytes into the stream (ascending, ahead of the bytes around it).
+func (r *Ring) Suggest(stream uint32, offset uint64) error {
+	defer runtime.KeepAlive(r)
+	return check(C.pbsgpu_ring_suggest(r.h, C.uint32_t(stream), C.uint64_t(offset)), "ring_suggest")
 }
 
 // RingStats mirrors the counters of pbsgpu_ring_stats a caller sizes its feed with.

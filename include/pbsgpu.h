@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSGPU_ABI_VERSION 3
+#define PBSGPU_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------- */
 #define PBSGPU_OK 0
@@ -114,8 +114,10 @@ typedef struct pbsgpu_engine pbsgpu_engine;
 int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight, pbsgpu_engine **out);
 void pbsgpu_engine_destroy(pbsgpu_engine *eng);
 int pbsgpu_engine_config(const pbsgpu_engine *eng, pbsgpu_config *out);
-/* Release device memory the engine only holds for re-use (window buffers of destroyed payload streams, bounded by
- * PBSGPU_STREAM_POOL_GIB, default 16). Waits for the device to go idle: call it between jobs. */
+/* Release what the engine only holds for re-use: the page ring of its payload streams (arena of PBSGPU_STREAM_RING_GIB,
+ * default 48 GiB, created by the first pbsgpu_stream_create; released only while no payload stream is alive) and the
+ * parked contexts of closed streams (pinned staging). *freed_bytes = device memory that came back. Waits for the device
+ * to go idle: call it between jobs. */
 int pbsgpu_engine_trim(pbsgpu_engine *eng, uint64_t *freed_bytes);
 
 /* Batch path (the data-parallel form of WriteEntryReader's chunk loop —
@@ -207,8 +209,18 @@ int pbsgpu_chunker_reset(pbsgpu_chunker *c);
  * The seam WriteEntryReader feeds (transfer.ArchiveWriter, mocked at
  * internal/pxarmount/commit_test.go:33-67): bytes are appended to ONE
  * continuous stream; finished (end, digest) records become available as the
- * stream advances. `end` in the records is the absolute stream offset.
- * `window_bytes` = device batch size (0 -> 256 MiB). */
+ * stream advances. `end` in the records is the absolute stream offset
+ * (payload position: written + injected), `segment` the section (number of
+ * pbsgpu_stream_cut calls before the chunk).
+ * All payload streams of an engine are clients of ONE engine-owned page ring
+ * (see "page ring" below): host bytes are staged in pinned memory and copied
+ * straight into a reserved page; cut rounds, the persistent SHA-256 service, page-granular
+ * release and record delivery are shared. `window_bytes` is accepted for
+ * compatibility and ignored (rounds 1-3: bytes per private device window).
+ * A stream whose DATA defeats the candidate provisioning (a crafted short period: more
+ * than one candidate per 128 bytes over a whole scan tile) fails with PBSGPU_E_DENSITY from
+ * its next call; records cut before that point are still delivered, other streams are
+ * not affected. Such data goes through pbsgpu_submit_* (capacity retry). */
 typedef struct pbsgpu_stream pbsgpu_stream;
 int pbsgpu_stream_create(pbsgpu_engine *eng, uint64_t window_bytes, pbsgpu_stream **out);
 void pbsgpu_stream_destroy(pbsgpu_stream *s);
@@ -222,8 +234,8 @@ int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len);
  * commit_reuse.go:315-341) and skip `inject_bytes` of injected, already
  * known chunk payload in the stream offsets. */
 int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes);
-/* End of stream: the tail becomes the final chunk; returns when every record is available to poll (the last window's
- * cut + the serial SHA-256 chain of its longest chunk: up to ~0.5 s at 16 MiB maximum chunks). */
+/* End of stream: the tail becomes the final chunk; returns when every record is available to poll (the serial SHA-256
+ * chain of the last chunks: up to ~0.5 s at 16 MiB maximum chunks). */
 int pbsgpu_stream_finish(pbsgpu_stream *s);
 /* The same without the wait, for a writer that goes on with its NEXT archive while this one drains (one goroutine per
  * archive, archives back to back: internal/tapeio/converter.go:672-680): finish_begin closes the input (tail chunk cut,
@@ -281,9 +293,15 @@ int pbsgpu_stream_write_marker(pbsgpu_stream *s, const struct pbsgpu_payload_for
  *   - a page is free again as soon as every chunk touching it has been READ by the service (not when a batch ends);
  *   - poll returns the stream's finished (end, digest) records in stream order; `end` is the absolute stream offset.
  * Results are bit-identical to one pbsgpu_submit_* / pbsgpu_stream_* pass over the same bytes.
- * One thread drives a ring. While the service runs, hipDeviceSynchronize / hipFree block: call quiesce first — also
- * before a pause: a ring that is not called at all for PBSGPU_RING_IDLE_TIMEOUT_S (default 20 s) while its service runs
- * considers the host dead, stops the service and answers PBSGPU_E_STATE from then on. */
+ * One thread drives a ring. While the service runs, hipDeviceSynchronize / hipFree of the process block (the library's own
+ * frees are parked meanwhile): call quiesce or park first. A ring that is not called at all for
+ * PBSGPU_RING_IDLE_TIMEOUT_S (default 20 s) while its service has nothing to do — a writer in a blocking tape read,
+ * internal/tapeio/converter.go:672-680 — loses NOTHING: the service stops on its own (a handshake with the host
+ * guarantees that no chunk is left behind) and the next pump starts it again.
+ * Failure containment: a stream whose data overflows a scan tile's candidate slots (more than one candidate per 128 bytes
+ * over a whole tile: a crafted short period) fails ALONE — its calls answer PBSGPU_E_DENSITY after the records cut before
+ * the failure, its pages are released — every other stream of the ring goes on. A stream is limited to 1 TiB
+ * (40-bit offsets inside a round); PBSGPU_E_INVALID beyond. */
 typedef struct pbsgpu_ring pbsgpu_ring;
 typedef struct pbsgpu_ring_options {
     uint64_t arena_bytes;  /* device memory for pages; 0 = what is free minus 8 GiB */
@@ -328,11 +346,19 @@ int pbsgpu_ring_poll(pbsgpu_ring *ring, uint32_t stream, pbsgpu_record *out, uin
  * once in `finished` (up to fcap per call); close them afterwards. */
 int pbsgpu_ring_poll_any(pbsgpu_ring *ring, pbsgpu_record *out, uint64_t cap, uint64_t *n, uint32_t *finished, uint32_t fcap,
                          uint32_t *nfinished);
-/* Release a finished, fully polled stream's slot. */
+/* Release a finished, fully polled stream's slot. A FAILED stream may be closed at any time: the slot is released and the
+ * call answers PBSGPU_E_DENSITY (its record list is incomplete). */
 int pbsgpu_ring_close(pbsgpu_ring *ring, uint32_t stream);
+/* Suggested boundary (see pbsgpu_submit_device_suggested) at `offset` bytes from the stream's start; ascending; announce
+ * it before the bytes around it are committed. The reader-buffer rule of pbsgpu_engine_set_suggested_feed applies. */
+int pbsgpu_ring_suggest(pbsgpu_ring *ring, uint32_t stream, uint64_t offset);
 /* Wait until everything enqueued is hashed and stop the service kernel (the device is then idle as far as the ring is
  * concerned); the next pump starts it again. */
 int pbsgpu_ring_quiesce(pbsgpu_ring *ring);
+/* The same without the wait: the service ends by itself once it has hashed what is enqueued; the next pump starts a new
+ * one. For a binding that is about to sit in a blocking read, or that wants hipFree / device-wide synchronisation of the
+ * process to be possible again soon. */
+int pbsgpu_ring_park(pbsgpu_ring *ring);
 int pbsgpu_ring_get_stats(pbsgpu_ring *ring, pbsgpu_ring_stats *out);
 /* Diagnostic text snapshot of the ring's device-side state (queue words, page reference counts, stream states). */
 int pbsgpu_ring_debug(pbsgpu_ring *ring, char *buf, uint64_t cap);

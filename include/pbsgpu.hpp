@@ -414,6 +414,16 @@ class PageRing {
         const int st = pbsgpu_ring_quiesce(r_);
         return st == PBSGPU_OK ? std::string() : errorf("ring quiesce", st);
     }
+    // Quiesce without the wait: for a writer about to sit in a blocking read (internal/tapeio/converter.go:672-680)
+    std::string Park() {
+        const int st = pbsgpu_ring_park(r_);
+        return st == PBSGPU_OK ? std::string() : errorf("ring park", st);
+    }
+    // a suggested chunk boundary `offset` bytes into the stream ("a file starts here"), announced ahead of its bytes
+    std::string Suggest(uint32_t stream, uint64_t offset) {
+        const int st = pbsgpu_ring_suggest(r_, stream, offset);
+        return st == PBSGPU_OK ? std::string() : errorf("ring suggest", st);
+    }
 
   private:
     PageRing(std::shared_ptr<Engine> eng, pbsgpu_ring *r, Sink sink) : eng_(std::move(eng)), r_(r), sink_(std::move(sink)) {}

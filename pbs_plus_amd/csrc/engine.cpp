@@ -17,7 +17,44 @@ __attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GP
 
 namespace pbse {
 std::atomic<int> g_last_hip_error{0};
+std::atomic<int> g_services{0};
+
+namespace {
+std::mutex g_grave_mu;
+std::vector<void *> g_grave_dev, g_grave_host;
+}  // namespace
+
+void dev_free(void *p) {
+    if (!p) return;
+    if (g_services.load(std::memory_order_acquire) > 0) {
+        std::lock_guard<std::mutex> lk(g_grave_mu);
+        g_grave_dev.push_back(p);
+        return;
+    }
+    (void)hipFree(p);
 }
+
+void host_free(void *p) {
+    if (!p) return;
+    if (g_services.load(std::memory_order_acquire) > 0) {
+        std::lock_guard<std::mutex> lk(g_grave_mu);
+        g_grave_host.push_back(p);
+        return;
+    }
+    (void)hipHostFree(p);
+}
+
+void graveyard_flush() {
+    std::vector<void *> d, h;
+    {
+        std::lock_guard<std::mutex> lk(g_grave_mu);
+        d.swap(g_grave_dev);
+        h.swap(g_grave_host);
+    }
+    for (void *p : d) (void)hipFree(p);
+    for (void *p : h) (void)hipHostFree(p);
+}
+}  // namespace pbse
 using namespace pbse;
 
 
@@ -95,22 +132,21 @@ AuxLease::~AuxLease() {
 
 static void free_engine(pbsgpu_engine *e) {
     (void)hipSetDevice(e->device);
-    hd_destroy(e);
+    engine_ring_release(e);  // (stops its SHA-256 service: everything below may free)
     for (auto cs : e->copy_streams) {
         (void)hipStreamSynchronize(cs);
         (void)hipStreamDestroy(cs);
     }
-    for (auto &b : e->win_pool) b.release();
-    stream_pool_release(e);
-    for (auto cs : e->cut_streams) {
+    for (auto cs : e->tee_streams) {
         (void)hipStreamSynchronize(cs);
         (void)hipStreamDestroy(cs);
     }
+    stream_pool_release(e);
     for (auto &s : e->slots)
         if (s) s->destroy();  // a failed create leaves a null entry behind (new(nothrow) Slot)
     for (auto &s : e->aux)
         if (s) s->destroy();
-    if (e->d_table_rot) (void)hipFree(e->d_table_rot);
+    if (e->d_table_rot) dev_free(e->d_table_rot);
     delete e;
 }
 
@@ -666,7 +702,11 @@ int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight
             if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
             else e->copy_streams.push_back(cs);
         }
-        if (st == PBSGPU_OK) st = hd_init(e);
+        for (int i = 0; i < 2 && st == PBSGPU_OK; ++i) {
+            hipStream_t ts = nullptr;
+            if (hipStreamCreateWithFlags(&ts, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+            else e->tee_streams.push_back(ts);
+        }
     } while (0);
     if (st != PBSGPU_OK) {
         pbsgpu_engine_destroy(e);
@@ -688,19 +728,22 @@ void pbsgpu_engine_destroy(pbsgpu_engine *e) {
     engine_unref(e);
 }
 
-// Give back what the engine only keeps for re-use: window buffers parked by destroyed streams (hipFree waits for the
-// device to go idle, so this is for quiet moments — between backup jobs, or when another allocation has failed).
+// Give back what the engine only keeps for re-use: the page ring of its payload streams (when no stream is alive) and the
+// parked contexts of closed streams (hipFree waits for the device to go idle, so this is for quiet moments — between
+// backup jobs, or when another allocation has failed). *freed_bytes = device memory that came back.
 int pbsgpu_engine_trim(pbsgpu_engine *e, uint64_t *freed_bytes) {
     if (!e) return PBSGPU_E_INVALID;
     CHK(set_device(e));
     uint64_t freed = 0;
-    {
-        std::lock_guard<std::mutex> lk(e->pool_mu);
-        for (auto &b : e->win_pool) {
-            freed += b.cap;
-            b.release();
+    {   // the engine's page ring (arena + tables), unless a payload stream is alive
+        std::lock_guard<std::mutex> lk(e->sring_mu);
+        if (e->sring && e->sring_users == 0) {
+            size_t f0 = 0, f1 = 0, tot = 0;
+            (void)hipMemGetInfo(&f0, &tot);
+            engine_ring_release(e);
+            (void)hipMemGetInfo(&f1, &tot);
+            if (f1 > f0) freed += f1 - f0;
         }
-        e->win_pool.clear();
     }
     stream_pool_release(e);
     if (freed_bytes) *freed_bytes = freed;
@@ -1041,7 +1084,7 @@ int pbsgpu_device_alloc(pbsgpu_engine *e, uint64_t nbytes, void **dptr) {
 int pbsgpu_device_free(pbsgpu_engine *e, void *dptr) {
     if (!e) return PBSGPU_E_INVALID;
     CHK(set_device(e));
-    if (dptr) HIPCHK(hipFree(dptr));
+    if (dptr) dev_free(dptr);  // (parked while a page-ring service runs: hipFree would wait for it)
     return PBSGPU_OK;
 }
 

@@ -7,8 +7,8 @@
 //     logical user at a time: a batch ticket (pool slots), one synchronous helper call (aux slots, leased; callers
 //     WAIT for a lease instead of failing), or one stream / chunker handle (private slot, never shared).
 //   * Slot::op serialises concurrent operations on the same ticket (wait / collect / timing from two threads).
-//   * streaming writers hash through the engine-wide HashDispatcher (own mutex): chunks of many windows and many
-//     streams share SHA-256 launches, so the number of concurrent kernels stays bounded however many streams feed.
+//   * streaming writers (pbsgpu_stream_*) are clients of ONE engine-owned page ring (ring_internal.h; own mutex): pages,
+//     cut rounds, the persistent SHA-256 service and record delivery are shared by all streams of the engine.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -44,6 +44,16 @@ extern std::atomic<int> g_last_hip_error;
         if (_s != PBSGPU_OK) return _s; \
     } while (0)
 
+// hipFree / hipHostFree wait for the WHOLE device — including a page ring's persistent SHA-256 service, which only ends
+// on request: a free issued while a service runs would block until someone stops it (for ever, if the caller is the
+// thread that would). Every release in this library therefore goes through these two: while any service is running the
+// pointer is parked in a graveyard and really freed when the last service has stopped (ring.cpp: quiesce / park / the
+// service's own stop) or at engine teardown.
+extern std::atomic<int> g_services;   // page-ring services launched and not yet known to have ended
+void dev_free(void *p);
+void host_free(void *p);
+void graveyard_flush();               // really free what was parked (call with no service running)
+
 // growable device buffer
 struct DevBuf {
     void *p = nullptr;
@@ -59,7 +69,7 @@ struct DevBuf {
     int ensure(size_t bytes) {
         if (bytes <= cap) return PBSGPU_OK;
         if (p) {
-            (void)hipFree(p);  // device-wide wait: see PinnedBuf::ensure
+            dev_free(p);  // device-wide wait: see PinnedBuf::ensure
             p = nullptr;
             bytes = std::max(bytes, std::min<size_t>(cap * 2, cap + (256u << 20)));
             cap = 0;
@@ -81,7 +91,7 @@ struct DevBuf {
         return PBSGPU_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -101,7 +111,7 @@ struct PinnedBuf {
     int ensure(size_t bytes) {
         if (bytes <= cap) return PBSGPU_OK;
         if (p) {
-            (void)hipHostFree(p);
+            host_free(p);
             bytes = std::max(bytes, cap * 2);
         }
         p = nullptr;
@@ -117,7 +127,7 @@ struct PinnedBuf {
         return PBSGPU_OK;
     }
     void release() {
-        if (p) (void)hipHostFree(p);
+        if (p) host_free(p);
         p = nullptr;
         cap = 0;
     }
@@ -176,52 +186,10 @@ struct Slot {
     void destroy();  // frees everything (device must be current)
 };
 
-// ---- shared SHA-256 jobs of the streaming writers -------------------------------------------------------------
-// A job collects the chunk descriptors of every window flushed (by any stream of the engine) since the previous
-// launch and hashes them in ONE k_sha256_pair launch on one of a few hash lanes (HIP streams). A launch lasts as
-// long as its longest chunk's serial chain (up to ~0.43 s for 16 MiB), so lanes are the scarce resource, not CUs.
-struct HashJob {
-    // host side (pinned: uploaded / downloaded asynchronously)
-    std::vector<pbsk::HashDesc> descs;  // accumulated while the job is open
-    PinnedBuf h_desc, h_order, h_dig;
-    DevBuf d_queue;
-    hipEvent_t done = nullptr;
-    uint32_t n = 0;          // descriptors launched
-    int lane = -1;
-    double launched_ms = 0;  // when it was launched (the oldest running job is the next to finish)
-    enum State { OPEN, LAUNCHED } state = OPEN;
-    std::atomic<int> refs{0};  // windows that still have to read their digests
-    const uint8_t *digest(uint32_t i) const { return h_dig.as<uint8_t>() + (size_t)i * 32; }
-};
-
-struct HashDispatcher {
-    std::mutex mu;
-    std::vector<hipStream_t> lanes;
-    std::vector<HashJob *> lane_job;              // job running (or last run) on each lane
-    std::vector<std::unique_ptr<HashJob>> jobs;   // pool (all jobs ever created)
-    HashJob *open = nullptr;                      // accumulating
-    int num_cus = 256;
-    // Launch policy. A job lasts ~0.45 s (the chain of a max-size chunk) whatever it holds, and its windows are
-    // released together when it ends. Greedy launching (PBSGPU_HASH_INTERVAL_MS=0, the default until round 3) hands the
-    // first six windows a lane each within 30 ms and then lumps everything that arrives while all lanes are busy —
-    // 12 GiB for one fast writer — into one job; the lanes then free up together and the pattern repeats: windows wait
-    // up to a whole job time for a lane, and so does the LAST job of an archive (traced: single writer, drain 0.9 s
-    // instead of 0.5). Launches are therefore spaced by 0.8 x job time / lanes (61 ms; a job someone blocks on goes at
-    // once when a lane is free). Measured, 6 lanes (profiles/r03_hostfeed_hash_job_pacing.log): one writer 31.4 -> 40.2
-    // GiB/s over 96 GiB (0.59 -> 0.75 of the H2D rate), eight writers 43 vs 42 (unchanged within their run-to-run
-    // spread); 10-12 lanes lose with eight writers whatever the pacing (hardware queues). Round 2 saw spacing cost
-    // eight writers a quarter: that version still launched at once whenever >= 1 GiB was waiting, i.e. every 25 ms.
-    uint64_t open_bytes = 0;
-    double last_launch_ms = -1e18;
-    double t0_ms = 0;  // trace time base
-    double min_interval_ms = 60.0;
-    int regular_lanes = 6;          // lanes [0, regular_lanes) take paced launches; the rest are the reserve
-    uint64_t bypass_bytes = ~0ull;  // a launch goes at once, whatever the pacing, when this much is waiting
-};
-
 }  // namespace pbse
 
 struct pbsgpu_stream;
+struct pbsgpu_ring;
 struct pbsgpu_engine {
     int device = 0;
     int num_cus = 256;
@@ -245,28 +213,26 @@ struct pbsgpu_engine {
     std::atomic<uint32_t> cap_hint_tile{0};  // ... for this tile size
     std::mutex mu;
     std::condition_variable cv;  // an aux lease was returned
-    // Host -> device payload copies of ALL streams go through these few engine-wide HIP streams (pieces alternate
-    // between them). Measured: one HIP copy stream per payload stream maps 8 streams unevenly onto the SDMA engines
+    // Host -> device payload copies of ALL streams go through these few engine-wide HIP streams (a page's copies stay on
+    // one of them). Measured: one HIP copy stream per payload stream maps 8 streams unevenly onto the SDMA engines
     // (17 GiB/s aggregate, some streams 4x slower than others); two always-busy copy queues carry ~50 GiB/s whatever
     // the number of producers. Only ready copies are ever enqueued here (nothing that waits for a kernel).
-    // window buffers returned by destroyed streams, re-used by later ones (hipFree waits for the whole device: a
-    // stream teardown that frees a 16 GiB ring stalls for as long as other streams' hash jobs run)
-    std::mutex pool_mu;
-    std::vector<pbse::DevBuf> win_pool;
-    // ... and whole stream contexts (cut contexts, pinned staging, tee buffers) of closed streams, for the same reason:
-    // a writer that closes one archive while its next one is already being hashed must not sit in hipFree/hipHostFree
-    // until those hash jobs end (stream.cpp: stream_park / stream_unpark)
-    std::vector<pbsgpu_stream *> stream_pool;
-    // OPT-IN (PBSGPU_SHARED_CUT_STREAMS=n, default 0 = one HIP stream per payload stream): n engine-wide HIP streams
-    // that all payload streams put their cuts, tees and carry copies on — short kernels, the hash jobs have their own
-    // lanes. Eight writers then need 2 copy + 6 hash + n cut streams instead of 16 + the engine's own, which keeps a
-    // process under the ~20 hardware queues beyond which every kernel pays 19 %. Written at the end of
-    // round 3 without GPU minutes left to measure it: to be A/B'd before it becomes the default.
-    std::vector<hipStream_t> cut_streams;
-    uint32_t cut_rr = 0;
     std::vector<hipStream_t> copy_streams;
     std::atomic<uint32_t> copy_rr{0};
-    pbse::HashDispatcher hd;
+    // ... and the per-file XXH3 tees of all streams through these (short kernels behind a page's copy; a stream keeps
+    // to one of them so that its pieces run in order). Few engine-wide HIP streams instead of one per payload stream keep a
+    // process under the ~20 hardware queues beyond which every kernel pays 19 %.
+    std::vector<hipStream_t> tee_streams;
+    std::atomic<uint32_t> tee_rr{0};
+    // The engine's page ring: every payload stream of the engine is a client of it (stream.cpp). Created by the first
+    // pbsgpu_stream_create, destroyed with the engine (or by pbsgpu_engine_trim when no stream is alive).
+    std::mutex sring_mu;             // creation / destruction only; the ring has its own lock for use
+    pbsgpu_ring *sring = nullptr;
+    int sring_users = 0;             // live payload streams (under sring_mu)
+    // whole stream contexts (pinned staging, tee buffers, events) of closed streams, re-used by the engine's next stream:
+    // allocating 100 MB of pinned memory per archive costs tens of milliseconds, freeing it would wait for the device
+    std::mutex pool_mu;
+    std::vector<pbsgpu_stream *> stream_pool;
     int refs = 1;                // owner + live streams / chunkers (under mu); freed when it drops to 0
     bool destroyed = false;      // pbsgpu_engine_destroy was called (children may still be alive)
 };
@@ -326,8 +292,7 @@ void parallel_memcpy(void *dst, const void *src, size_t n);
 // stream contexts parked in pbsgpu_engine::stream_pool (stream.cpp): really free them (engine teardown, trim)
 void stream_pool_release(pbsgpu_engine *e);
 
-// hash dispatcher (stream.cpp)
-int hd_init(pbsgpu_engine *e);
-void hd_destroy(pbsgpu_engine *e);
+// the engine's page ring (stream.cpp): destroyed at engine teardown / trim
+void engine_ring_release(pbsgpu_engine *e);
 
 }  // namespace pbse

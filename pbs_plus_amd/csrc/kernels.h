@@ -52,7 +52,7 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
                           uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st,
-                          const struct RingPage *ring_pages = nullptr, uint32_t ring_tpp = 0);
+                          const struct RingPage *ring_pages = nullptr, uint32_t ring_tpp = 0, uint32_t *ring_seg_fail = nullptr);
 
 // one long stream without suggested boundaries: the cut chain followed by pointer doubling (kernels.hip); `scratch` holds
 // resolve_par_scratch_bytes(node_cap, levels); falls back to the serial walk when there are more candidates than node_cap - 1
@@ -91,14 +91,28 @@ struct SuggFeed {
     uint64_t feed, origin;
     uint32_t absolute, open_end;
 };
+// Page-ring rounds (ring_kernels.inc): segments are the streams' open chunks + new pages in LOGICAL coordinates
+// ((slot << 40) | offset), suggested offsets are relative to the stream's byte 0, a segment's end is the stream's end only
+// when its RingSeg says final, and the walk reports per segment what the round leaves behind (all null otherwise).
+constexpr uint64_t kRingOffMask = (1ull << 40) - 1ull;  // logical coordinates of a ring round: (stream slot << 40) | offset
+struct RingSeg;
+struct ResolveRing {
+    const RingSeg *segs_in = nullptr;
+    const uint32_t *seg_fail = nullptr;   // 1 = skip the segment (its stream failed)
+    const uint64_t *ecand_in = nullptr;   // carried hash candidate of the open chunk (~0 = none)
+    uint64_t *ecand_out = nullptr;        // written by the write pass when the segment produced records:
+    uint32_t *open_out = nullptr;         //   1 = the last record is the still-open chunk
+    uint64_t *newc_out = nullptr;         //   start of the open chunk (stream offset) after this round
+};
 
 // min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt,
-                                const Suggested &sg, hipStream_t st);
+                                const Suggested &sg, hipStream_t st, const ResolveRing *rr = nullptr, unsigned lds_tag = 0);
 hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
-                                pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st);
+                                pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st,
+                                const ResolveRing *rr = nullptr, unsigned lds_tag = 0);
 
 hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
@@ -180,8 +194,10 @@ struct alignas(64) RingCtl {   // device memory, one 64-byte line
     };
     uint32_t head;         // next queue position to hand out
     uint32_t free_count;   // pages reported free so far
-    uint32_t error;        // sticky: a cut round overflowed a capacity (ring.cpp reports PBSGPU_E_DENSITY)
-    uint32_t pad[9];
+    uint32_t error;        // sticky, ring-wide: a round overflowed its record / cell capacity (never a single stream's fault)
+    uint32_t rounds_done;  // rounds published so far (k_ring_publish); the service compares it with the host's count of
+                           // enqueued rounds before it stops on its own
+    uint32_t pad[8];
 };
 struct RingSource {
     static constexpr bool kRing = true;
@@ -199,13 +215,17 @@ struct RingSource {
     uint32_t *pending;         // per physical page: chunks not yet loaded + holds of open chunks
     unsigned long long *free_fifo;  // mapped pinned: (sequence << 32) | page
     uint32_t free_mask;
-    // A kernel that only ends on request must not outlive a host that died: every ring call bumps `heartbeat` (mapped
-    // pinned); an idle wave that has seen neither work nor a heartbeat change for idle_ticks (wall-clock ticks, 100 MHz)
-    // gives up AND marks the ring failed (ctl->error = 3) — the host then reports an error instead of waiting forever
-    // for chunks nobody hashes. A slow producer does not trip it: the host keeps calling while it waits for input.
+    // A kernel that only ends on request must not outlive a host that died or sits in a blocking read: every ring call
+    // bumps word 0 of the `heartbeat` block (mapped pinned); when the service's designated wave (workgroup 0, first
+    // producer) has seen neither work nor a heartbeat change for idle_ticks (wall-clock ticks, 100 MHz) it stops the
+    // service ON ITS OWN — a handshake with the host makes that safe (kernels.hip, k_sha256_pair): the ring stays
+    // healthy, the next pump finds the service gone and starts it again.
+    // Heartbeat block (uint32 words): [0] heartbeat (host), [16] stop intent (device), [17] stop committed (device),
+    // [32] claim progress (device, for the backlog gate), [33] rounds enqueued so far (host).
     const uint32_t *heartbeat;
     unsigned long long idle_ticks;
 };
+constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHbRoundsEnq = 33;
 
 
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)
@@ -233,6 +253,7 @@ struct RingSeg {
     uint64_t new_end;      // logical length of the stream after this round
     uint32_t reset;        // first round of a new stream in this slot: state starts from zero
     uint32_t pad;
+    uint64_t origin;       // payload position of the stream's byte 0 (suggested boundaries on the absolute reader grid)
 };
 // Device-resident state of a stream slot.
 constexpr uint64_t kRingMaxStream = 1ull << 40;  // logical coordinates are (stream slot << 40) | offset
@@ -240,15 +261,20 @@ constexpr uint32_t kRingPT = 64;       // page-table window per stream (open chu
 struct RingStreamState {
     uint64_t c;            // start of the open chunk (logical offset in the stream)
     uint64_t end;          // bytes received so far
+    uint64_t ecand;        // ~0 or: the hash candidate inside the open chunk that a suggested boundary beyond the bytes
+                           // seen so far pre-empts (reader-buffer rule); it is not rescanned, so it is carried here
+    uint32_t failed;       // a scan tile of this stream overflowed its candidate slots: the stream is dropped, its pages
+    uint32_t pad;          // are released, every other stream of the ring goes on
     uint32_t pt[kRingPT];  // logical page k -> physical page, at [k % kRingPT]
 };
 struct RingRoundStatus {   // mapped pinned: written last by a round
     uint32_t seq;          // round number + 1
     uint32_t nrec;         // record cells written (open chunks included as void cells)
     uint32_t ncand;
-    uint32_t error;        // 1 = a scan tile overflowed its candidate capacity, 2 = record capacity
+    uint32_t error;        // 2 = record / cell capacity (ring-wide); a candidate overflow only fails ITS stream (seg_status)
     uint32_t tail;         // queue tail after this round
-    uint32_t pad[3];
+    uint32_t nfailed;      // segments of this round whose stream failed (seg_status[s] = 1)
+    uint32_t pad[2];
 };
 struct RingRound {
     // geometry / constants
@@ -282,6 +308,19 @@ struct RingRound {
     uint64_t rec_cap;
     uint64_t *seg_newc;        // per segment: the open chunk's start after this round
     uint32_t *seg_open;        // per segment: 1 = the round left an open chunk
+    uint64_t *seg_ecand_in;    // per segment: RingStreamState::ecand before / after this round
+    uint64_t *seg_ecand;
+    uint32_t *seg_fail;        // per segment: 1 = the stream is (or has just) failed
+    uint32_t *seg_status;      // mapped pinned, per segment: the host's copy of seg_fail
+    // suggested boundaries (optional): sugg[sugg_idx[s] .. sugg_idx[s+1]) ascending, offsets within stream s
+    const uint64_t *sugg;
+    const uint32_t *sugg_idx;
+    uint64_t sugg_feed;        // reader-buffer rule (Suggested::feed / absolute)
+    uint32_t sugg_abs;
+    uint32_t pad0;
+    // fused control kernel: records of segment s go to recs[seg_rec_base[s] .. seg_rec_base[s + 1]) — the host's bound on
+    // what the stream's open chunk + new pages can produce (mapped pinned, nseg + 1 entries)
+    const uint32_t *seg_rec_base;
 };
 // enqueue one cut round on `st` (fill -> pads/segments -> scan -> compaction -> resolve -> descriptors -> publish)
 // (`fill_st` / `fill_ev`: the synthetic producer's own stream and the event the cut waits for; null = same stream)

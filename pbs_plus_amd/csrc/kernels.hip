@@ -791,11 +791,15 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const uint32_t *tile_off,
                                                  const uint32_t *tile_slots, uint32_t cap, uint64_t ntiles,
                                                  uint32_t lead, uint64_t *dense, uint64_t dense_cap,
-                                                 uint32_t tile_bytes, const RingPage *ring_pages, uint32_t ring_tpp) {
+                                                 uint32_t tile_bytes, const RingPage *ring_pages, uint32_t ring_tpp,
+                                                 uint32_t *ring_seg_fail) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     const uint32_t c = min(tile_cnt[t], cap);
     if (c == 0) return;
+    // page ring: a tile that overflowed its slot list fails the STREAM that owns the page, nothing else (the slots it did
+    // record land in that stream's logical range of the dense list, where only its own, skipped, segment would look)
+    if (ring_seg_fail && tile_cnt[t] > cap) ring_seg_fail[ring_pages[t / ring_tpp].seg] = 1u;
     const uint32_t *sl = tile_slots + t * cap;
     const uint64_t base = tile_off[t];
     // page ring: candidates are reported in LOGICAL stream coordinates ((slot << 40) | offset), pages ascending
@@ -833,12 +837,12 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
                           uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st, const RingPage *ring_pages,
-                          uint32_t ring_tpp) {
+                          uint32_t ring_tpp, uint32_t *ring_seg_fail) {
     (void)nbytes;
     if (ntiles == 0) return hipSuccess;
     const uint64_t nb = (ntiles + 255) / 256;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
-                       lead, dense, dense_cap, tile_bytes, ring_pages, ring_tpp);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), ring_pages ? 1024u : 0u, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
+                       lead, dense, dense_cap, tile_bytes, ring_pages, ring_tpp, ring_seg_fail);
     return hipGetLastError();
 }
 
@@ -854,23 +858,30 @@ hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, co
 // the first suggested boundary b with min <= b - s <= max; boundaries with b - s < min are dropped for good. For
 // min >= 65 they behave exactly like extra candidates; the separate list keeps the min = 64 corner (hash cuts need
 // chunk_size >= 65, a suggested one only >= min) exact.
+// The walk of ONE segment by ONE wave (all 64 lanes call it with the same arguments). Returns the number of records;
+// WRITE: record k goes to recs[rbase + k] (lane 0), `seg` is stored in its segment field.
+// Page-ring rounds (rr.segs_in != null; ring_kernels.inc): the segment is a stream's open chunk + its new pages in logical
+// coordinates ((slot << 40) | offset); suggested offsets are relative to the STREAM's byte 0; the segment's end is the
+// stream's end only if RingSeg::final; and the walk reports what the round leaves behind: is the last record the still-open
+// chunk (it is unless the serial chunker cuts exactly at the current end: a max-size chunk, a candidate or a winning
+// suggested boundary there), where that chunk starts, and — reader-buffer rule only — the hash candidate inside it that a
+// boundary beyond the bytes seen so far pre-empts. Such a candidate lies in pages the next round does not scan again, so
+// it is carried in the stream state and handed back as `ecand_first`.
 template <bool WRITE>
-__global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const uint32_t *ncand_p,
-                                                 const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
-                                                 uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
-                                                 pbsgpu_record *recs, uint64_t rec_cap, const uint64_t *sugg,
-                                                 const uint32_t *sugg_idx, uint32_t cmin, const uint32_t *gate,
-                                                 SuggFeed fr) {
-    const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+__device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const uint64_t n, const uint64_t A, const uint64_t B,
+                                                 const uint32_t seg, const uint32_t effmin, const uint32_t maxsz,
+                                                 const uint64_t rbase, pbsgpu_record *recs, const uint64_t rec_cap,
+                                                 const uint64_t *sugg, const uint64_t sbeg, const uint64_t send,
+                                                 const uint32_t cmin, const SuggFeed fr, const bool ring,
+                                                 const uint64_t ecand_first, bool *last_real_out, uint64_t *last_start_out,
+                                                 uint64_t *ecand_out) {
     const int lane = threadIdx.x & 63;
-    if (seg >= nseg) return;
-    if (gate && *gate == 0) return;  // fallback launch behind k_resolve_par: only if that kernel handed the job back
-    __builtin_amdgcn_s_setprio(2);  // a latency-bound serial walk: do not queue behind throughput waves on this SIMD
-    const uint64_t n = *ncand_p;
-    const uint64_t A = segs[seg].offset, B = A + segs[seg].length;
     uint64_t s = A;
     uint32_t k = 0;
-    const uint64_t rbase = WRITE ? (uint64_t)seg_off[seg] : 0;
+    // coordinates of the suggested offsets / of the absolute reader grid: the segment start, or (ring) the stream's byte 0
+    const uint64_t P = ring ? (A & ~kRingOffMask) : A;
+    bool last_real = true;
+    uint64_t last_start = A, last_ecand = ~0ull;
 
     // first candidate index with value >= A + effmin (uniform binary search)
     uint64_t lo = 0, hi = n;
@@ -881,10 +892,9 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
     }
     uint64_t wb = lo;  // window base: lane holds cands[wb + lane]
     uint64_t cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
-    // suggested boundaries of this segment (relative to A): same wave-wide window walk
-    const uint64_t sbeg = sugg ? sugg_idx[seg] : 0, send = sugg ? sugg_idx[seg + 1] : 0;
+    // suggested boundaries of this segment: same wave-wide window walk
     uint64_t swb = sbeg;
-    uint64_t sv = (swb + lane < send) ? A + sugg[swb + lane] : ~0ull;
+    uint64_t sv = (swb + lane < send) ? P + sugg[swb + lane] : ~0ull;
 
     while (s < B) {
         const uint64_t tlo = s + effmin, thi = s + maxsz;
@@ -899,8 +909,11 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
             wb += 64;
             cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
         }
-        uint64_t e = (c < thi) ? c : thi;
-        if (e > B) e = B;
+        if (s == A && ecand_first != ~0ull) c = ecand_first;  // older than every listed candidate, >= tlo by construction
+        const uint64_t e0 = (c < thi) ? c : thi;  // where the hash / max rule cuts, were the bytes there
+        uint64_t e = (e0 > B) ? B : e0;
+        bool real = e0 <= B;
+        uint64_t ec = ~0ull;
         if (send > sbeg) {  // segment-uniform
             const uint64_t slo = s + cmin;
             uint64_t b;
@@ -911,20 +924,30 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
                     break;
                 }
                 swb += 64;
-                sv = (swb + lane < send) ? A + sugg[swb + lane] : ~0ull;
+                sv = (swb + lane < send) ? P + sugg[swb + lane] : ~0ull;
             }
             if (fr.feed <= 1) {
-                if (b < e) e = b;  // b >= s + min and b < e <= s + max: a legal chunk
+                if (b <= e) {  // b >= s + min and b <= e <= s + max: a legal chunk (b == e: the same position, and a cut)
+                    e = b;
+                    real = true;
+                }
             } else if (b <= B && b - s <= maxsz) {
                 // the reference's payload chunker sees `feed` bytes per scan call: a boundary inside the call's buffer is
                 // taken before the hash scan of that buffer runs, so it also wins over an EARLIER hash cut in the same
                 // buffer; buffers are counted from the last cut, or (absolute) from the stream start
-                const uint64_t ob = fr.absolute ? fr.origin + (b - A) : b - s, oe = fr.absolute ? fr.origin + (e - A) : e - s;
+                const uint64_t ob = fr.absolute ? fr.origin + (b - P) : b - s, oe = fr.absolute ? fr.origin + (e - P) : e - s;
                 const uint64_t jb = (ob - 1) / fr.feed, je = (oe - 1) / fr.feed;
-                if (jb <= je) e = b;
+                if (jb <= je) {
+                    e = b;
+                    real = true;
+                }
             } else if (fr.open_end && b != ~0ull && b > B && b - s <= maxsz) {
-                const uint64_t ob = fr.absolute ? fr.origin + (b - A) : b - s, oe = fr.absolute ? fr.origin + (e - A) : e - s;
-                if ((ob - 1) / fr.feed <= (oe - 1) / fr.feed) e = B;  // decided by bytes that are not here yet: open chunk
+                const uint64_t ob = fr.absolute ? fr.origin + (b - P) : b - s, oe = fr.absolute ? fr.origin + (e - P) : e - s;
+                if ((ob - 1) / fr.feed <= (oe - 1) / fr.feed) {  // the cut is at b, beyond the bytes that are here: open chunk
+                    if (e0 <= B && e0 == c) ec = c;              // ... and the hash cut it pre-empts still counts if the stream ends first
+                    e = B;
+                    real = false;
+                }
             }
         }
         if (WRITE) {
@@ -935,31 +958,77 @@ __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const ui
                 r->size = (uint32_t)(e - s);
             }
         }
+        last_real = real;
+        last_start = s;
+        last_ecand = ec;
         ++k;
         s = e;
     }
+    *last_real_out = last_real;
+    *last_start_out = last_start;
+    *ecand_out = last_ecand;
+    return k;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const uint32_t *ncand_p,
+                                                 const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
+                                                 uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
+                                                 pbsgpu_record *recs, uint64_t rec_cap, const uint64_t *sugg,
+                                                 const uint32_t *sugg_idx, uint32_t cmin, const uint32_t *gate,
+                                                 SuggFeed fr, ResolveRing rr) {
+    const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (seg >= nseg) return;
+    if (gate && *gate == 0) return;  // fallback launch behind k_resolve_par: only if that kernel handed the job back
+    if (rr.seg_fail && rr.seg_fail[seg]) {  // page ring: the stream of this segment has failed, it produces nothing
+        if (lane == 0 && seg_cnt) seg_cnt[seg] = 0;
+        return;
+    }
+    __builtin_amdgcn_s_setprio(2);  // a latency-bound serial walk: do not queue behind throughput waves on this SIMD
+    const uint64_t n = *ncand_p;
+    const uint64_t A = segs[seg].offset, B = A + segs[seg].length;
+    const bool ring = rr.segs_in != nullptr;
+    if (ring) {
+        fr.open_end = rr.segs_in[seg].final ? 0u : 1u;
+        fr.origin = rr.segs_in[seg].origin;
+    }
+    bool last_real;
+    uint64_t last_start, ecand;
+    const uint32_t k = resolve_walk<WRITE>(cands, n, A, B, seg, effmin, maxsz, WRITE ? (uint64_t)seg_off[seg] : 0, recs, rec_cap,
+                                           sugg, sugg ? sugg_idx[seg] : 0, sugg ? sugg_idx[seg + 1] : 0, cmin, fr, ring,
+                                           rr.ecand_in ? rr.ecand_in[seg] : ~0ull, &last_real, &last_start, &ecand);
     if (lane == 0 && seg_cnt) seg_cnt[seg] = k;  // count pass; also the single-segment write pass (count -> *nrec)
+    if (WRITE && ring && lane == 0 && k > 0 && rr.open_out) {
+        const bool open = !rr.segs_in[seg].final && !last_real;
+        rr.open_out[seg] = open ? 1u : 0u;
+        rr.newc_out[seg] = (open ? last_start : B) & kRingOffMask;
+        rr.ecand_out[seg] = open ? ecand : ~0ull;
+    }
 }
 
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt, const Suggested &sg,
-                                hipStream_t st) {
+                                hipStream_t st, const ResolveRing *rr, unsigned lds_tag) {
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
-    hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
+    hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), lds_tag, st, cands, ncand, segs, nseg, effmin,
                        maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0, sg.offsets,
-                       sg.index, sg.cmin, (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end});
+                       sg.index, sg.cmin, (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end},
+                       rr ? *rr : ResolveRing{});
     return hipGetLastError();
 }
 
 hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
-                                pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
+                                pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st,
+                                const ResolveRing *rr, unsigned lds_tag) {
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
-    hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
+    hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), lds_tag, st, cands, ncand, segs, nseg, effmin,
                        maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin,
-                       (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end});
+                       (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end},
+                       rr ? *rr : ResolveRing{});
     return hipGetLastError();
 }
 
@@ -1233,7 +1302,7 @@ hipError_t launch_resolve_single_par_grid(const uint64_t *cands, const uint32_t 
     // the serial walk, gated: runs only if there were more candidates than nodes (*fallback != 0)
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
                        rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback,
-                       SuggFeed{1, 0, 0, 0});
+                       SuggFeed{1, 0, 0, 0}, ResolveRing{});
     return hipGetLastError();
 }
 
@@ -1253,7 +1322,7 @@ hipError_t launch_resolve_single_par(const uint64_t *cands, const uint32_t *ncan
     // the serial walk, gated: runs only if the parallel kernel handed the job back (*fallback != 0)
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
                        rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback,
-                       SuggFeed{1, 0, 0, 0});
+                       SuggFeed{1, 0, 0, 0}, ResolveRing{});
     return hipGetLastError();
 }
 
@@ -1263,7 +1332,7 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
                                  pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec,
                        zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin, (const uint32_t *)nullptr,
-                       SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end});
+                       SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end}, ResolveRing{});
     return hipGetLastError();
 }
 
@@ -1862,28 +1931,44 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     bool live = any_cur;
                     if constexpr (Source::kRing) {
                         // a service wave stays until `stop` has reached every lane and its block FIFO has drained; with
-                        // nothing to do it naps instead of spinning through barriers, and a wave that has seen no work for
-                        // idle_ticks gives up (a host that died must not leave a kernel behind that never ends)
+                        // nothing to do it naps instead of spinning through barriers.
+                        // A host that died, or sits in a blocking read for longer than idle_ticks, must not leave a kernel
+                        // behind that never ends: the DESIGNATED wave (workgroup 0, first producer) then stops the service on
+                        // its own. That must never lose a chunk, i.e. no round may publish positions behind lanes that have
+                        // left. Handshake (Dekker, through mapped pinned memory): the wave announces its intent, THEN re-reads
+                        // the heartbeat and the host's count of enqueued rounds; the host bumps heartbeat and count FIRST and
+                        // THEN looks at the intent flag before it enqueues a round (ring.cpp, ring_service_gate). Either the
+                        // wave sees the host and withdraws, or the host sees the intent and waits for the outcome. The stop
+                        // is committed only if every enqueued round has been published (rounds_done) — published positions
+                        // are always served: a lane leaves only at a position the tail has not reached.
                         const bool wave_done = __ballot(!exhausted) == 0ull;
                         live = any_cur || !wave_done;
                         if (!any_cur && !wave_done) {
                             const unsigned long long now = wall_clock64();
                             if (idle_since == 0) idle_since = now;
-                            if (now - idle_since > src.idle_ticks) {
-                                // nothing to do for a whole timeout: is the host still there? (The heartbeat lives in HOST
-                                // memory: it is read once per timeout, not per idle iteration — hundreds of idle waves
-                                // polling it over PCIe every few microseconds slowed the whole ring down 6x.)
-                                const uint32_t hb = __hip_atomic_load(src.heartbeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (blockIdx.x == 0 && wave == 2 && now - idle_since > src.idle_ticks) {
+                                // (the heartbeat lives in HOST memory: it is read once per timeout, not per idle iteration —
+                                // hundreds of idle waves polling it over PCIe every few microseconds slowed the ring down 6x)
+                                uint32_t *hbw = const_cast<uint32_t *>(src.heartbeat);
+                                const uint32_t hb = __hip_atomic_load(hbw + kHbBeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                 if (hb != hb_seen) {  // alive: it just has nothing for us yet
                                     hb_seen = hb;
                                     idle_since = now;
                                 } else {
-                                    if (lane == 0) {  // for the round kernels (device) and for the host (mapped pinned, word 16)
-                                        __hip_atomic_store(&src.ctl->error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        __hip_atomic_store(const_cast<uint32_t *>(src.heartbeat) + 16, 1u, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                                    if (lane == 0) __hip_atomic_store(hbw + kHbIntent, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    __atomic_thread_fence(__ATOMIC_SEQ_CST);  // system scope: the intent is out before the re-reads
+                                    __threadfence_system();
+                                    const uint32_t hb2 = __hip_atomic_load(hbw + kHbBeat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    const uint32_t enq = __hip_atomic_load(hbw + kHbRoundsEnq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    const uint32_t done = __hip_atomic_load(&src.ctl->rounds_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    if (hb2 != hb || enq != done) {  // the host is back, or a round is still on its way: withdraw
+                                        if (lane == 0) __hip_atomic_store(hbw + kHbIntent, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                        hb_seen = hb2;
+                                        idle_since = now;
+                                    } else if (lane == 0) {  // commit: every lane leaves at its next look at {tail, stop}
+                                        __hip_atomic_store(&src.ctl->stop, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                        __hip_atomic_store(hbw + kHbCommitted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                                     }
-                                    exhausted = true;
                                 }
                             }
                             __builtin_amdgcn_s_sleep(48);

@@ -1,5 +1,7 @@
 // libpbsgpu host side, part 3: the PAGE RING — many payload streams through one device arena with page-granular
-// memory release and a persistent cross-stream SHA-256 service.
+// memory release and a persistent cross-stream SHA-256 service. Since round 4 it is THE engine behind every streaming
+// entry point: pbsgpu_ring_* drives it directly (bytes already in device memory), pbsgpu_stream_* (stream.cpp) is a client
+// that feeds host bytes into reserved pages.
 //
 // Why it exists. SHA-256 is serial inside a chunk (a 16 MiB chunk = 262 144 dependent compressions ~ 0.43 s on one
 // lane), so a batch submitted with pbsgpu_submit_device keeps ALL its bytes resident until its longest chunk is done:
@@ -18,136 +20,24 @@
 //     hash time of the longest chunk that touches THAT page, not of the longest chunk of a 64 GiB batch;
 //   * digests and record fields land in host-visible record cells; pbsgpu_ring_poll hands them out per stream, in order.
 // One thread drives a ring (like one goroutine owns a writer, internal/tapeio/converter.go:672-680).
+//
+// Failure containment: a stream whose data overflows a scan tile's candidate slots fails ALONE (PBSGPU_E_DENSITY from
+// its own calls, its pages released on the device); a host that stops calling for longer than the idle timeout finds the
+// service gone and the ring healthy — the next round starts it again.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <deque>
 #include <thread>
 
-#include "engine_internal.h"
+#include "ring_internal.h"
 
 using namespace pbse;
 
 namespace {
 
-constexpr uint32_t kInputs = 16;          // rounds whose host-written tables may be in flight
-constexpr uint32_t kPagesPerStreamRound = 48;  // < kRingPT - 2 (open chunk) with room to spare
-
-struct PageReq {                          // a committed page waiting for its round
-    uint32_t phys = 0;
-    uint64_t k = 0;                       // logical page index in its stream
-    uint32_t valid = 0;
-    bool final = false;
-    bool do_fill = false;
-    uint64_t seed = 0, fill_off = 0;
-    uint32_t kind = 0;
-};
-
-struct CellRef {
-    uint32_t cell;
-    uint32_t round_idx;                   // index into live rounds' accounting (seq)
-};
-
-struct StreamSlot {
-    bool open = false;
-    bool fresh = true;                    // no round has carried this stream yet (device state starts from zero)
-    uint64_t next_k = 0;                  // next logical page
-    uint64_t bytes_committed = 0;
-    uint64_t bytes_enqueued = 0;          // stream length after the rounds enqueued so far
-    bool final_committed = false, final_enqueued = false, final_done = false;
-    bool zero_final = false;              // final commit of 0 bytes still to be carried by a round
-    uint32_t final_seq = 0;
-    int64_t reserved = -1;                // physical page handed out by reserve
-    std::deque<PageReq> ready;
-    std::deque<CellRef> cells;            // record cells in stream order (round results reaped)
-    uint64_t records_out = 0;
-    bool reported = false;                // poll_any has announced the end of this stream
-};
-
-struct RoundInfo {
-    uint32_t seq = 0;                     // round number + 1
-    uint32_t input = 0;
-    uint64_t cell_base = 0;               // monotonic
-    uint32_t cell_cap = 0;
-    uint32_t live_cells = 0;              // cells handed to streams and not yet polled
-    bool reaped = false;
-    std::vector<uint32_t> finals;         // slots whose stream ended with this round
-    std::vector<uint32_t> phys;           // pages carried (diagnostics)
-    uint64_t new_bytes = 0;               // stream bytes this round added
-};
-
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-
-}  // namespace
-
-struct pbsgpu_ring {
-    pbsgpu_engine *eng = nullptr;
-    // geometry
-    uint64_t page_bytes = 0, stride = 0;
-    uint32_t tile_bytes = 0, tpp = 0, npages = 0, max_streams = 0, sha_cus = 0, round_pages = 0, min_round_pages = 0, cap = 0;
-    uint32_t max_inflight = 3;
-    // backlog gate: no page is handed out while more than this many bytes wait in front of the service — committed pages
-    // not yet in a round, rounds in flight, published chunks no lane has claimed. A full arena of unhashed chunks feeds
-    // the service no faster than a short queue does; it only adds its length to every latency (and to the final drain).
-    uint64_t backlog_limit = 0;
-    uint64_t ready_bytes = 0, inflight_bytes = 0;
-    uint32_t tail_seen = 0;               // queue tail after the last reaped round
-    uint64_t pub_positions = 0, pub_bytes = 0;  // queue positions / stream bytes of all reaped rounds (average chunk size)
-    uint64_t rec_cap = 0, dense_cap = 0;
-    uint32_t qslots = 0, ncells = 0, nfree = 0;
-    // device
-    DevBuf arena, ctl, streams, pending, desc, ldesc;
-    uint32_t lslots = 0, long_bytes = 0;
-    DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
-    // mapped pinned
-    PinnedBuf cells, free_fifo, inputs, heartbeat;
-    size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_status_off = 0;
-    hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
-    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr;
-    hipEvent_t ev_fill[kInputs] = {};
-    bool service_running = false;
-    // host bookkeeping
-    std::vector<uint32_t> free_pages;
-    uint32_t free_read = 0;               // entries of the free FIFO consumed
-    std::vector<StreamSlot> slots;
-    std::deque<RoundInfo> rounds;         // enqueued, oldest first; popped when reaped AND all their cells were polled
-    bool input_busy[kInputs] = {};
-    uint32_t next_seq = 1;
-    uint64_t cell_cursor = 0;
-    int error = PBSGPU_OK;
-    pbsgpu_ring_stats st{};
-    double svc_t0 = 0;
-    uint64_t svc_bytes0 = 0;
-
-    uint8_t *in(uint32_t i) const { return inputs.as<uint8_t>() + (size_t)i * input_stride; }
-    pbsk::RingPage *in_pages(uint32_t i) const { return reinterpret_cast<pbsk::RingPage *>(in(i) + in_pages_off); }
-    pbsk::RingSeg *in_segs(uint32_t i) const { return reinterpret_cast<pbsk::RingSeg *>(in(i) + in_segs_off); }
-    pbsk::RingRoundStatus *in_status(uint32_t i) const {
-        return reinterpret_cast<pbsk::RingRoundStatus *>(in(i) + in_status_off);
-    }
-    pbsk::RingSource source() const {
-        pbsk::RingSource q{};
-        q.desc = desc.as<uint4>();
-        q.qmask = qslots - 1;
-        q.ldesc = ldesc.as<uint4>();
-        q.lmask = lslots - 1;
-        q.long_bytes = long_bytes;
-        q.ctl = ctl.as<pbsk::RingCtl>();
-        q.cells = cells.as<uint8_t>();
-        q.pending = pending.as<uint32_t>();
-        q.free_fifo = free_fifo.as<unsigned long long>();
-        q.free_mask = nfree - 1;
-        double idle_s = 20.0;
-        if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.5, atof(v));
-        q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
-        q.heartbeat = heartbeat.as<uint32_t>();
-        return q;
-    }
-};
-
-namespace {
 
 uint32_t pow2_at_least(uint64_t v) {
     uint32_t p = 1;
@@ -155,13 +45,51 @@ uint32_t pow2_at_least(uint64_t v) {
     return p;
 }
 
-// every ring call: tell the service the host is alive, and notice a service that ended although nobody stopped it (its
-// idle waves give up when the heartbeat stands still for PBSGPU_RING_IDLE_TIMEOUT_S): the ring then fails loudly
-void ring_heartbeat(pbsgpu_ring *r, bool check_service = false) {
-    volatile uint32_t *hb = r->heartbeat.as<volatile uint32_t>();
-    *hb = *hb + 1u;
-    // word 16 of the heartbeat block is written by a service wave that gave up (no heartbeat for a whole timeout)
-    if (check_service && r->error == PBSGPU_OK && hb[16] != 0) r->error = PBSGPU_E_STATE;
+volatile uint32_t *hb_words(const pbsgpu_ring *r) { return r->heartbeat.as<volatile uint32_t>(); }
+
+// the service launched last is known to have ended: statistics, the service count, parked frees
+void ring_service_ended(pbsgpu_ring *r) {
+    if (r->svc == SvcState::Stopped) return;
+    r->svc = SvcState::Stopped;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r->ev_svc0, r->ev_svc1) == hipSuccess) {
+        r->st.service_ms_last = ms;
+        r->st.service_ms_total += ms;
+    } else {
+        (void)hipGetLastError();
+    }
+    r->st.service_bytes_last = r->st.bytes_enqueued - r->svc_bytes0;
+    volatile uint32_t *hb = hb_words(r);
+    hb[pbsk::kHbIntent] = 0;
+    hb[pbsk::kHbCommitted] = 0;
+    if (g_services.fetch_sub(1, std::memory_order_acq_rel) == 1) graveyard_flush();
+}
+
+// Did the service stop on its own (idle timeout, kernels.hip)? Then wait the few microseconds until the kernel is gone.
+// With `gate` (a round is about to be enqueued) also settle an ANNOUNCED stop: the caller has bumped heartbeat and round
+// count before coming here, so the service either withdraws or commits within a PCIe round trip.
+int ring_service_check(pbsgpu_ring *r, bool gate) {
+    if (r->svc != SvcState::Running) return PBSGPU_OK;
+    volatile uint32_t *hb = hb_words(r);
+    if (gate && hb[pbsk::kHbIntent] != 0 && hb[pbsk::kHbCommitted] == 0) {
+        const double t0 = now_ms();
+        while (hb[pbsk::kHbIntent] != 0 && hb[pbsk::kHbCommitted] == 0) {
+            if (now_ms() - t0 > 5000.0) return r->error = PBSGPU_E_STATE;  // neither withdrawn nor committed: the device is gone
+            std::this_thread::yield();
+        }
+    }
+    if (hb[pbsk::kHbCommitted] != 0) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        HIPCHK(hipStreamSynchronize(r->ss));
+        ring_service_ended(r);
+    }
+    return PBSGPU_OK;
+}
+
+// every ring call: tell the service the host is alive
+void ring_heartbeat(pbsgpu_ring *r) {
+    volatile uint32_t *hb = hb_words(r);
+    hb[pbsk::kHbBeat] = hb[pbsk::kHbBeat] + 1u;
 }
 
 // pages the service has handed back since the last call
@@ -176,6 +104,21 @@ void ring_reap_free(pbsgpu_ring *r) {
     }
 }
 
+// a stream has failed on the device (candidate overflow): what the host still holds of it goes back
+void ring_fail_stream(pbsgpu_ring *r, uint32_t slot) {
+    StreamSlot &s = r->slots[slot];
+    if (s.failed) return;
+    s.failed = true;
+    for (auto &q : s.ready) {
+        r->free_pages.push_back(q.phys);
+        r->ready_bytes -= q.valid;
+        if (q.dep) ring_event_put(r, q.dep);
+    }
+    s.ready.clear();
+    s.zero_final = false;
+    s.sugg.clear();
+}
+
 // round results in order: record cells to their streams, finished streams, input tables reusable
 void ring_reap_rounds(pbsgpu_ring *r) {
     for (auto &ri : r->rounds) {
@@ -184,7 +127,7 @@ void ring_reap_rounds(pbsgpu_ring *r) {
         if (hs->seq != ri.seq) break;  // rounds complete in order
         std::atomic_thread_fence(std::memory_order_acquire);
         if (hs->error) {
-            r->error = hs->error == 3 ? PBSGPU_E_STATE : PBSGPU_E_DENSITY;  // 3 = the service gave up (no heartbeat)
+            r->error = PBSGPU_E_DENSITY;  // record / cell capacity of a round exceeded: the ring's own bound was wrong
         } else {
             const uint32_t n = hs->nrec;
             const uint8_t *cells = r->cells.as<uint8_t>();
@@ -197,6 +140,11 @@ void ring_reap_rounds(pbsgpu_ring *r) {
                 r->slots[slot].cells.push_back(CellRef{c, ri.seq});
                 ri.live_cells++;
                 r->st.chunks++;
+            }
+            if (hs->nfailed) {
+                const volatile uint32_t *ss = r->in_segstat(ri.input);
+                for (size_t s = 0; s < ri.seg_slots.size(); ++s)
+                    if (ss[s]) ring_fail_stream(r, ri.seg_slots[s]);
             }
             r->st.candidates += hs->ncand;
             r->pub_positions += (uint32_t)(hs->tail - r->tail_seen);
@@ -213,16 +161,19 @@ void ring_reap_rounds(pbsgpu_ring *r) {
 }
 
 int ring_start_service(pbsgpu_ring *r) {
-    if (r->service_running) return PBSGPU_OK;
-    // head := tail, stop := 0 behind everything on the control stream; the service starts behind that
-    r->heartbeat.as<volatile uint32_t>()[32] = r->tail_seen;  // (k_ring_reset: head := tail; every round was reaped by now)
+    if (r->svc == SvcState::Running) return PBSGPU_OK;
+    // head := tail, stop := 0 behind everything on the control stream — and behind the END of a service that is still
+    // stopping (park): its lanes may hold claims beyond the tail that the reset hands out again
+    if (r->svc == SvcState::Stopping) HIPCHK(hipStreamWaitEvent(r->cs, r->ev_svc1, 0));
+    else g_services.fetch_add(1, std::memory_order_acq_rel);
+    r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
+    hb_words(r)[pbsk::kHbClaim] = r->tail_seen;  // (k_ring_reset: head := tail; every round was reaped or is behind us on cs)
     HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));
     HIPCHK(hipEventRecord(r->ev_reset, r->cs));
     HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));
     HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
     HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
     HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
-    r->service_running = true;
     r->svc_t0 = now_ms();
     r->svc_bytes0 = r->st.bytes_enqueued;
     r->st.service_launches++;
@@ -243,7 +194,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
         ready += s.ready.size();
     }
     if (!any) return PBSGPU_OK;
-    // A round costs a dozen dependent launches whatever it holds: while earlier rounds keep the device busy, wait until
+    // A round costs a few dependent launches whatever it holds: while earlier rounds keep the device busy, wait until
     // a quarter of a full round has gathered (pages come back from the SHA service one by one). A stream's end and an
     // idle device go at once.
     {
@@ -255,7 +206,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
         if (inflight >= r->max_inflight) return PBSGPU_OK;
     }
     int in = -1;
-    for (uint32_t i = 0; i < kInputs; ++i)
+    for (uint32_t i = 0; i < kRingInputs; ++i)
         if (!r->input_busy[i]) { in = (int)i; break; }
     if (in < 0) return PBSGPU_OK;
     // record cells: a round takes a contiguous (modulo the ring) range; wait while older rounds still own what the
@@ -266,18 +217,26 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     }
     pbsk::RingPage *pg = r->in_pages((uint32_t)in);
     pbsk::RingSeg *sg = r->in_segs((uint32_t)in);
+    uint32_t *recbase = r->in_recbase((uint32_t)in);
+    uint32_t *suggidx = r->in_suggidx((uint32_t)in);
     uint32_t np = 0, ns = 0;
     uint64_t cells_needed = 0, new_bytes = 0;
     RoundInfo ri;
+    std::vector<hipEvent_t> deps;
+    std::vector<uint64_t> sugg;
     const uint32_t minsz = std::min(e->effmin, e->cfg.min);
+    const uint64_t feed = e->sugg_feed.load(std::memory_order_relaxed);
+    const uint64_t look = feed > 1 ? (uint64_t)e->cfg.max : 0;  // reader-buffer rule: boundaries just beyond the bytes matter too
     for (uint32_t si = 0; si < r->slots.size() && np < r->round_pages; ++si) {
         StreamSlot &s = r->slots[si];
-        if (!s.open || (s.ready.empty() && !s.zero_final)) continue;
+        if (!s.open || s.failed || (s.ready.empty() && !s.zero_final)) continue;
         pbsk::RingSeg g{};
         g.slot = si;
         g.first_page = np;
         g.reset = s.fresh ? 1u : 0u;
-        uint64_t end = s.bytes_enqueued;
+        g.origin = s.origin;
+        const uint64_t end_old = s.bytes_enqueued;
+        uint64_t end = end_old;
         uint32_t take = 0;
         while (!s.ready.empty() && take < kPagesPerStreamRound && np < r->round_pages) {
             const PageReq &q = s.ready.front();
@@ -293,7 +252,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
             p.fill_off = q.fill_off;
             p.fill_kind = q.kind;
             pg[np++] = p;
-            ri.phys.push_back(q.phys);
+            if (q.dep) deps.push_back(q.dep);
             end += q.valid;
             new_bytes += q.valid;
             if (q.final) g.final = 1;
@@ -312,11 +271,39 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
             s.final_enqueued = true;
             ri.finals.push_back(si);
         }
+        // suggested boundaries that can still matter: behind the open chunk's start (>= end_old - max, the chunk is
+        // shorter than max), up to the new end (+ one max chunk under the reader-buffer rule)
+        suggidx[ns] = (uint32_t)sugg.size();
+        {
+            const uint64_t lower = end_old > e->cfg.max ? end_old - e->cfg.max : 0;
+            while (!s.sugg.empty() && s.sugg.front() < lower) s.sugg.pop_front();
+            for (uint64_t b : s.sugg) {
+                if (b > end + look) break;
+                sugg.push_back(b);
+            }
+        }
+        recbase[ns] = (uint32_t)cells_needed;
         cells_needed += ((uint64_t)take * r->page_bytes + e->cfg.max) / minsz + 2;
+        ri.seg_slots.push_back(si);
         sg[ns++] = g;
     }
     if (ns == 0) return PBSGPU_OK;
+    suggidx[ns] = (uint32_t)sugg.size();
     if (cells_needed > r->rec_cap) cells_needed = r->rec_cap;  // (the bound above is never larger: rec_cap is the same formula for a full round)
+    recbase[ns] = (uint32_t)cells_needed;
+    // From here on the popped pages and the streams' new lengths exist only in this round: any failure is the ring's (sticky).
+    auto fail = [&](int st) {
+        r->error = st;
+        for (hipEvent_t ev : deps) ring_event_put(r, ev);
+        return st;
+    };
+    const uint64_t *sugg_dev = nullptr;
+    if (!sugg.empty()) {
+        PinnedBuf &sb = r->sugg_in[in];
+        if (sb.ensure(std::max<size_t>(sugg.size() * 8, 4096)) != PBSGPU_OK) return fail(PBSGPU_E_NOMEM);
+        std::memcpy(sb.p, sugg.data(), sugg.size() * 8);
+        sugg_dev = sb.as<uint64_t>();
+    }
     ri.cell_base = r->cell_cursor;
     ri.cell_cap = (uint32_t)cells_needed;
     r->cell_cursor += cells_needed;
@@ -327,7 +314,15 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     ri.input = (uint32_t)in;
     pbsk::RingRoundStatus *hs = r->in_status((uint32_t)in);
     hs->seq = 0;
-    std::atomic_thread_fence(std::memory_order_release);
+    // the service's self-stop handshake (kernels.hip): count and heartbeat first, THEN look at its intent flag
+    volatile uint32_t *hb = hb_words(r);
+    hb[pbsk::kHbRoundsEnq] = ++r->rounds_enq;
+    ring_heartbeat(r);
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    {
+        const int st = ring_service_check(r, true);
+        if (st != PBSGPU_OK) return fail(st);
+    }
 
     pbsk::RingRound rr{};
     rr.arena = r->arena.as<uint8_t>();
@@ -369,8 +364,31 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.rec_cap = r->rec_cap;
     rr.seg_newc = r->seg_newc.as<uint64_t>();
     rr.seg_open = r->seg_open.as<uint32_t>();
-    CHK(ring_start_service(r));
-    HIPCHK(pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in]));
+    rr.seg_ecand_in = r->seg_ecand_in.as<uint64_t>();
+    rr.seg_ecand = r->seg_ecand.as<uint64_t>();
+    rr.seg_fail = r->seg_fail.as<uint32_t>();
+    rr.seg_status = r->in_segstat((uint32_t)in);
+    rr.sugg = sugg_dev;
+    rr.sugg_idx = sugg_dev ? suggidx : nullptr;
+    rr.sugg_feed = feed;
+    rr.sugg_abs = e->sugg_feed_abs.load(std::memory_order_relaxed);
+    rr.seg_rec_base = recbase;
+    std::atomic_thread_fence(std::memory_order_release);
+    {
+        const int st = ring_start_service(r);
+        if (st != PBSGPU_OK) return fail(st);
+    }
+    for (hipEvent_t ev : deps)  // host-fed pages: the cut waits for their copies (device-side wait; the copies never wait for a kernel)
+        if (hipStreamWaitEvent(r->cs, ev, 0) != hipSuccess) return fail(PBSGPU_E_HIP);
+    for (hipEvent_t ev : deps) ring_event_put(r, ev);
+    deps.clear();
+    {
+        const hipError_t he = pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in]);
+        if (he != hipSuccess) {
+            g_last_hip_error.store((int)he);
+            return fail(PBSGPU_E_HIP);
+        }
+    }
     r->input_busy[in] = true;
     ri.new_bytes = new_bytes;
     r->ready_bytes -= new_bytes;
@@ -384,11 +402,11 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
 }
 
 int ring_take_page(pbsgpu_ring *r, uint32_t *phys) {
-    if (r->backlog_limit && r->service_running) {
-        // published and unclaimed: queue tail of the last reaped round minus the service's claim progress (word 32 of the
+    if (r->backlog_limit && r->svc == SvcState::Running) {
+        // published and unclaimed: queue tail of the last reaped round minus the service's claim progress (a word of the
         // heartbeat block, written whenever the head crosses a multiple of 256 — hence the slack: idle lanes claim ahead
         // of the tail, so with nothing left to claim the difference always falls below 256)
-        const int32_t behind = (int32_t)(r->tail_seen - r->heartbeat.as<volatile uint32_t>()[32]) - 256;
+        const int32_t behind = (int32_t)(r->tail_seen - hb_words(r)[pbsk::kHbClaim]) - 256;
         double wait = (double)r->ready_bytes + (double)r->inflight_bytes;
         if (behind > 0 && r->pub_positions) wait += (double)behind * ((double)r->pub_bytes / (double)r->pub_positions);
         if (wait > (double)r->backlog_limit) return PBSGPU_E_BUSY;
@@ -402,9 +420,115 @@ int ring_take_page(pbsgpu_ring *r, uint32_t *phys) {
 
 }  // namespace
 
-extern "C" {
+pbsk::RingSource pbsgpu_ring::source() const {
+    pbsk::RingSource q{};
+    q.desc = desc.as<uint4>();
+    q.qmask = qslots - 1;
+    q.ldesc = ldesc.as<uint4>();
+    q.lmask = lslots - 1;
+    q.long_bytes = long_bytes;
+    q.ctl = ctl.as<pbsk::RingCtl>();
+    q.cells = cells.as<uint8_t>();
+    q.pending = pending.as<uint32_t>();
+    q.free_fifo = free_fifo.as<unsigned long long>();
+    q.free_mask = nfree - 1;
+    double idle_s = 20.0;
+    if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.05, atof(v));
+    q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
+    q.heartbeat = heartbeat.as<uint32_t>();
+    return q;
+}
 
-int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_ring **out) {
+namespace pbse {
+
+// records of one stream that are ready, in order, into out[*n ..)
+void ring_pop_records(pbsgpu_ring *r, uint32_t slot, pbsgpu_record *out, uint64_t cap, uint64_t *n) {
+    StreamSlot &s = r->slots[slot];
+    const uint8_t *cells = r->cells.as<uint8_t>();
+    while (*n < cap && !s.cells.empty()) {
+        const CellRef cr = s.cells.front();
+        const uint8_t *c = cells + (size_t)cr.cell * 64;
+        const volatile uint32_t *flag = reinterpret_cast<const volatile uint32_t *>(c + 48);
+        if (*flag != 1u) break;  // its chunk is still being hashed: records come out in stream order
+        std::atomic_thread_fence(std::memory_order_acquire);
+        pbsgpu_record rec;
+        std::memcpy(&rec, c, sizeof(rec));
+        rec.segment = slot;
+        out[(*n)++] = rec;
+        s.cells.pop_front();
+        s.records_out++;
+        for (auto &ri : r->rounds)
+            if (ri.seq == cr.round_idx) {
+                ri.live_cells--;
+                break;
+            }
+    }
+}
+
+int ring_event_get(pbsgpu_ring *r, hipEvent_t *ev) {
+    if (!r->ev_pool.empty()) {
+        *ev = r->ev_pool.back();
+        r->ev_pool.pop_back();
+        return PBSGPU_OK;
+    }
+    HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return PBSGPU_OK;
+}
+
+void ring_event_put(pbsgpu_ring *r, hipEvent_t ev) {
+    if (ev) r->ev_pool.push_back(ev);
+}
+
+bool ring_idle(const pbsgpu_ring *r) {
+    if (!r->rounds.empty() || r->ready_bytes || r->inflight_bytes) return false;
+    for (auto &s : r->slots)
+        if (s.open && (!s.ready.empty() || s.zero_final || !s.cells.empty())) return false;
+    return true;
+}
+
+// Stop the service behind everything enqueued so far without waiting for it: the kernel drains what is published and
+// ends; the next round starts a new one (which first waits, on the device, for the old one's end).
+int ring_park(pbsgpu_ring *r) {
+    if (r->svc != SvcState::Running) return PBSGPU_OK;
+    CHK(ring_service_check(r, false));
+    if (r->svc != SvcState::Running) return PBSGPU_OK;
+    HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
+    r->svc = SvcState::Stopping;
+    return PBSGPU_OK;
+}
+
+int ring_commit_dep(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final, hipEvent_t dep) {
+    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    StreamSlot &s = r->slots[stream];
+    if (s.failed) return PBSGPU_E_DENSITY;
+    if (s.final_committed) return PBSGPU_E_STATE;
+    if (nbytes > r->page_bytes || (nbytes != r->page_bytes && !final)) return PBSGPU_E_INVALID;  // only a stream's last page is short
+    if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;  // 1 TiB per stream (40-bit logical offsets)
+    if (nbytes == 0) {
+        if (s.reserved >= 0) {  // nothing written: the page goes back
+            r->free_pages.push_back((uint32_t)s.reserved);
+            s.reserved = -1;
+        }
+        s.zero_final = true;
+        s.final_committed = true;
+        return PBSGPU_OK;
+    }
+    if (s.reserved < 0) return PBSGPU_E_STATE;
+    PageReq q;
+    q.phys = (uint32_t)s.reserved;
+    q.k = s.next_k++;
+    q.valid = (uint32_t)nbytes;
+    q.final = final != 0;
+    q.dep = dep;
+    s.ready.push_back(q);
+    r->ready_bytes += nbytes;
+    s.reserved = -1;
+    s.bytes_committed += nbytes;
+    if (final) s.final_committed = true;
+    return PBSGPU_OK;
+}
+
+int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool hold_engine_ref, pbsgpu_ring **out) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = nullptr;
     CHK(set_device(e));
@@ -412,7 +536,8 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
     if (opt) o = *opt;
     pbsgpu_ring *r = new (std::nothrow) pbsgpu_ring();
     if (!r) return PBSGPU_E_NOMEM;
-    engine_ref(e);
+    r->holds_engine_ref = hold_engine_ref;
+    if (hold_engine_ref) engine_ref(e);
     r->eng = e;
     int st = [&]() -> int {
         // page geometry: a whole number of scan tiles, >= the largest chunk (so a chunk touches at most two pages)
@@ -436,7 +561,7 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
             HIPCHK(hipMemGetInfo(&fr, &tot));
             arena_bytes = fr > (12ull << 30) ? fr - (8ull << 30) : fr / 2;
         }
-        r->npages = (uint32_t)std::min<uint64_t>(arena_bytes / r->stride, 65534);
+        r->npages = (uint32_t)std::min<uint64_t>(arena_bytes / r->stride, 65534);  // 16-bit page ids in the queue descriptors
         {   // the chunk FIFO and the record cells are sized for every chunk the arena can hold (arena / min chunk size):
             // with small average chunk sizes that bound, not HBM, limits the arena (4 M resident chunks = 128 MB of
             // descriptors + 1 GB of pinned record cells)
@@ -450,7 +575,8 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         // ~233 CU-ms (128 chains per CU at 1.66-1.75 us per 64-byte block) — measured optimum 192 of 256 CUs
         // (profiles/r03_ring_sweep_*.log: 184 -> 580, 192 -> 597, 200 -> 528, 208 -> 504 GiB/s)
         int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - e->num_cus / 4);
-        if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
+        if (!o.sha_cus)
+            if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
         r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1));
         r->round_pages = o.round_pages ? o.round_pages : 256;
         if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
@@ -460,11 +586,13 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         // ~30 ms of the service's throughput (4.3 GiB/s per CU measured) is plenty to ride out the gaps between rounds
         r->backlog_limit = (uint64_t)r->sha_cus << 27;
         if (const char *v = getenv("PBSGPU_RING_BACKLOG_MIB")) r->backlog_limit = (uint64_t)(std::max(0.0, atof(v)) * 1048576.0);
-        if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kInputs);
+        if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kRingInputs);
+        if (const char *v = getenv("PBSGPU_RING_AUTOPARK_MS")) r->autopark_ms = std::max(0.0, atof(v));
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
         // configs[2]'s repeating 4 KiB files have one per 4 KiB). 12 bytes per slot: ~400 MB at the default round size.
+        // Data beyond that (a crafted short period) fails ITS stream, nothing else.
         const double lambda = 3.0 * r->tile_bytes / ((double)e->cfg.mask + 1.0);
         uint32_t capv = 8;
         while (capv < 4.0 * lambda + 16.0) capv <<= 1;
@@ -504,18 +632,25 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
         CHK(r->seg_off.ensure((size_t)r->max_streams * 4 + 16));
         CHK(r->seg_newc.ensure((size_t)r->max_streams * 8 + 16));
         CHK(r->seg_open.ensure((size_t)r->max_streams * 4 + 16));
+        CHK(r->seg_ecand_in.ensure((size_t)r->max_streams * 8 + 16));
+        CHK(r->seg_ecand.ensure((size_t)r->max_streams * 8 + 16));
+        CHK(r->seg_fail.ensure((size_t)r->max_streams * 4 + 16));
         CHK(r->recs.ensure((size_t)r->rec_cap * sizeof(pbsgpu_record) + 64));
         CHK(r->cells.ensure((size_t)r->ncells * 64));
         CHK(r->heartbeat.ensure(256));
         std::memset(r->heartbeat.p, 0, 256);
         CHK(r->free_fifo.ensure((size_t)r->nfree * 8));
         std::memset(r->free_fifo.p, 0, (size_t)r->nfree * 8);
+        auto al64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
         r->in_pages_off = 0;
-        r->in_segs_off = ((size_t)r->round_pages * sizeof(pbsk::RingPage) + 63) & ~(size_t)63;
-        r->in_status_off = (r->in_segs_off + (size_t)r->max_streams * sizeof(pbsk::RingSeg) + 63) & ~(size_t)63;
+        r->in_segs_off = al64((size_t)r->round_pages * sizeof(pbsk::RingPage));
+        r->in_segstat_off = al64(r->in_segs_off + (size_t)r->max_streams * sizeof(pbsk::RingSeg));
+        r->in_recbase_off = al64(r->in_segstat_off + (size_t)r->max_streams * 4);
+        r->in_suggidx_off = al64(r->in_recbase_off + ((size_t)r->max_streams + 1) * 4);
+        r->in_status_off = al64(r->in_suggidx_off + ((size_t)r->max_streams + 1) * 4);
         r->input_stride = r->in_status_off + 64;
-        CHK(r->inputs.ensure(r->input_stride * kInputs));
-        std::memset(r->inputs.p, 0, r->input_stride * kInputs);
+        CHK(r->inputs.ensure(r->input_stride * kRingInputs));
+        std::memset(r->inputs.p, 0, r->input_stride * kRingInputs);
         HIPCHK(hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&r->fs, hipStreamNonBlocking));
         // The device-side state starts from zero — cleared ON THE CONTROL STREAM and waited for. A plain hipMemset is
@@ -555,31 +690,41 @@ int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_
     return PBSGPU_OK;
 }
 
+}  // namespace pbse
+
+extern "C" {
+
+int pbsgpu_ring_create(pbsgpu_engine *e, const pbsgpu_ring_options *opt, pbsgpu_ring **out) {
+    return ring_create_internal(e, opt, true, out);
+}
+
 // Stop the SHA service behind everything enqueued so far and wait until the device holds no ring work: every chunk of
 // every enqueued round is hashed, the persistent kernel has ended (hipDeviceSynchronize / hipFree can return again).
 // The next pump starts the service again.
 int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
     if (!r) return PBSGPU_E_INVALID;
     CHK(set_device(r->eng));
-    if (r->service_running) {
-        HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
-        HIPCHK(hipStreamSynchronize(r->cs));
+    ring_heartbeat(r);
+    if (r->svc == SvcState::Running) {
+        CHK(ring_service_check(r, false));  // (it may have stopped on its own in the meantime)
+        if (r->svc == SvcState::Running) HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
+    }
+    HIPCHK(hipStreamSynchronize(r->cs));
+    if (r->svc != SvcState::Stopped) {
         HIPCHK(hipStreamSynchronize(r->ss));
         HIPCHK(hipStreamSynchronize(r->fs));
-        r->service_running = false;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, r->ev_svc0, r->ev_svc1) == hipSuccess) {
-            r->st.service_ms_last = ms;
-            r->st.service_ms_total += ms;
-        } else {
-            (void)hipGetLastError();
-        }
-        r->st.service_bytes_last = r->st.bytes_enqueued - r->svc_bytes0;
-    } else {
-        HIPCHK(hipStreamSynchronize(r->cs));
+        ring_service_ended(r);
     }
     ring_reap_free(r);
     ring_reap_rounds(r);
+    return r->error;
+}
+
+int pbsgpu_ring_park(pbsgpu_ring *r) {
+    if (!r) return PBSGPU_E_INVALID;
+    CHK(set_device(r->eng));
+    ring_heartbeat(r);
+    CHK(ring_park(r));
     return r->error;
 }
 
@@ -589,6 +734,10 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
     if (e) {
         (void)hipSetDevice(e->device);
         if (r->cs && r->ss) (void)pbsgpu_ring_quiesce(r);
+        if (r->svc != SvcState::Stopped) {  // quiesce failed half-way (HIP error): the count must not leak
+            r->svc = SvcState::Stopped;
+            g_services.fetch_sub(1, std::memory_order_acq_rel);
+        }
         if (r->ss) (void)hipStreamDestroy(r->ss);
         if (r->cs) (void)hipStreamDestroy(r->cs);
         if (r->fs) (void)hipStreamDestroy(r->fs);
@@ -596,17 +745,23 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
             if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : {r->ev_reset, r->ev_svc0, r->ev_svc1})
             if (ev) (void)hipEventDestroy(ev);
+        for (auto &s : r->slots)
+            for (auto &q : s.ready)
+                if (q.dep) r->ev_pool.push_back(q.dep);
+        for (auto ev : r->ev_pool) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
                           &r->tile_slots, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
-                          &r->seg_open})
+                          &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->seg_fail})
             b->release();
         r->cells.release();
         r->heartbeat.release();
         r->free_fifo.release();
         r->inputs.release();
+        for (auto &b : r->sugg_in) b.release();
     }
+    const bool unref = r->holds_engine_ref;
     delete r;
-    if (e) engine_unref(e);
+    if (e && unref) engine_unref(e);
 }
 
 int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
@@ -625,6 +780,18 @@ int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
 int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
     if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
+    if (s.failed) {  // a failed stream may be closed at any time: what it still holds goes back, its record list is incomplete
+        for (const CellRef &cr : s.cells)
+            for (auto &ri : r->rounds)
+                if (ri.seq == cr.round_idx) {
+                    ri.live_cells--;
+                    break;
+                }
+        s.cells.clear();
+        if (s.reserved >= 0) r->free_pages.push_back((uint32_t)s.reserved);
+        s = StreamSlot{};
+        return PBSGPU_E_DENSITY;
+    }
     if (!s.final_done || !s.cells.empty()) return PBSGPU_E_STATE;  // finish it and poll its records first
     s.open = false;
     return PBSGPU_OK;
@@ -633,6 +800,7 @@ int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
 int pbsgpu_ring_reserve(pbsgpu_ring *r, uint32_t stream, void **dptr, uint64_t *cap) {
     if (!r || !dptr || !cap || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
+    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
     if (r->error != PBSGPU_OK) return r->error;
     uint32_t phys = 0;
@@ -644,31 +812,18 @@ int pbsgpu_ring_reserve(pbsgpu_ring *r, uint32_t stream, void **dptr, uint64_t *
 }
 
 int pbsgpu_ring_commit(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final) {
+    return ring_commit_dep(r, stream, nbytes, final, nullptr);
+}
+
+int pbsgpu_ring_suggest(pbsgpu_ring *r, uint32_t stream, uint64_t offset) {
     if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
+    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed) return PBSGPU_E_STATE;
-    if (nbytes > r->page_bytes || (nbytes != r->page_bytes && !final)) return PBSGPU_E_INVALID;  // only a stream's last page is short
-    if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;
-    if (nbytes == 0) {
-        if (s.reserved >= 0) {  // nothing written: the page goes back
-            r->free_pages.push_back((uint32_t)s.reserved);
-            s.reserved = -1;
-        }
-        s.zero_final = true;
-        s.final_committed = true;
-        return PBSGPU_OK;
-    }
-    if (s.reserved < 0) return PBSGPU_E_STATE;
-    PageReq q;
-    q.phys = (uint32_t)s.reserved;
-    q.k = s.next_k++;
-    q.valid = (uint32_t)nbytes;
-    q.final = final != 0;
-    s.ready.push_back(q);
-    r->ready_bytes += nbytes;
-    s.reserved = -1;
-    s.bytes_committed += nbytes;
-    if (final) s.final_committed = true;
+    if (!s.sugg.empty() && offset < s.sugg.back()) return PBSGPU_E_INVALID;  // ascending
+    // a boundary at or before bytes that are already in a round can no longer take part in those rounds' cuts: it must be
+    // announced before the bytes around it are committed (the stream writer announces at the current position or ahead)
+    s.sugg.push_back(offset);
     return PBSGPU_OK;
 }
 
@@ -677,6 +832,7 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
     if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open || kind > 4) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     *taken = 0;
+    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
     if (r->error != PBSGPU_OK) return r->error;
     if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;
@@ -714,13 +870,28 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
 int pbsgpu_ring_pump(pbsgpu_ring *r) {
     if (!r) return PBSGPU_E_INVALID;
     CHK(set_device(r->eng));
-    ring_heartbeat(r, true);
+    ring_heartbeat(r);
+    CHK(ring_service_check(r, false));
+    if (r->svc == SvcState::Stopping) {  // parked: has the kernel gone yet? (then parked frees can go ahead)
+        const hipError_t q = hipEventQuery(r->ev_svc1);
+        if (q == hipSuccess) ring_service_ended(r);
+        else (void)hipGetLastError();
+    }
     ring_reap_free(r);
     ring_reap_rounds(r);
     for (int i = 0; i < 4; ++i) {
         bool did = false;
         CHK(ring_enqueue_round(r, &did));
         if (!did) break;
+    }
+    if (r->autopark_ms > 0 && r->svc == SvcState::Running) {  // nothing anywhere in the ring: give the CUs (and hipFree) back
+        if (ring_idle(r)) {
+            const double t = now_ms();
+            if (r->idle_since_ms == 0) r->idle_since_ms = t;
+            else if (t - r->idle_since_ms >= r->autopark_ms) CHK(ring_park(r));
+        } else {
+            r->idle_since_ms = 0;
+        }
     }
     return r->error;
 }
@@ -731,33 +902,17 @@ int pbsgpu_ring_poll(pbsgpu_ring *r, uint32_t stream, pbsgpu_record *out, uint64
     ring_heartbeat(r);
     ring_reap_rounds(r);
     *n = 0;
-    const uint8_t *cells = r->cells.as<uint8_t>();
-    while (*n < cap && !s.cells.empty()) {
-        const CellRef cr = s.cells.front();
-        const uint8_t *c = cells + (size_t)cr.cell * 64;
-        const volatile uint32_t *flag = reinterpret_cast<const volatile uint32_t *>(c + 48);
-        if (*flag != 1u) break;  // its chunk is still being hashed: records come out in stream order
-        std::atomic_thread_fence(std::memory_order_acquire);
-        pbsgpu_record rec;
-        std::memcpy(&rec, c, sizeof(rec));
-        rec.segment = stream;
-        out[(*n)++] = rec;
-        s.cells.pop_front();
-        s.records_out++;
-        for (auto &ri : r->rounds)
-            if (ri.seq == cr.round_idx) {
-                ri.live_cells--;
-                break;
-            }
-    }
+    ring_pop_records(r, stream, out, cap, n);
     while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
-    if (finished) *finished = (s.final_done && s.cells.empty()) ? 1 : 0;
-    return r->error;
+    if (finished) *finished = (!s.failed && s.final_done && s.cells.empty()) ? 1 : 0;
+    if (r->error != PBSGPU_OK) return r->error;
+    return (s.failed && s.cells.empty()) ? PBSGPU_E_DENSITY : PBSGPU_OK;  // what was cut before the failure is still delivered
 }
 
 // Records of ANY open stream (each stream's in its own order), `segment` = stream id — for callers that drive hundreds
 // or thousands of short streams (one per file) and cannot afford to ask every one of them after every pump. A stream
-// that has ended and handed out its last record is reported once in `finished`.
+// that has ended and handed out its last record is reported once in `finished`; so is a stream that FAILED (its close
+// then answers PBSGPU_E_DENSITY).
 int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint64_t *n, uint32_t *finished, uint32_t fcap,
                          uint32_t *nfinished) {
     if (!r || !n || !nfinished || (!out && cap) || (!finished && fcap)) return PBSGPU_E_INVALID;
@@ -765,28 +920,11 @@ int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint6
     ring_reap_rounds(r);
     *n = 0;
     *nfinished = 0;
-    const uint8_t *cells = r->cells.as<uint8_t>();
     for (uint32_t si = 0; si < r->slots.size(); ++si) {
         StreamSlot &s = r->slots[si];
         if (!s.open || s.reported) continue;
-        while (*n < cap && !s.cells.empty()) {
-            const CellRef cr = s.cells.front();
-            const uint8_t *c = cells + (size_t)cr.cell * 64;
-            if (*reinterpret_cast<const volatile uint32_t *>(c + 48) != 1u) break;
-            std::atomic_thread_fence(std::memory_order_acquire);
-            pbsgpu_record rec;
-            std::memcpy(&rec, c, sizeof(rec));
-            rec.segment = si;
-            out[(*n)++] = rec;
-            s.cells.pop_front();
-            s.records_out++;
-            for (auto &ri : r->rounds)
-                if (ri.seq == cr.round_idx) {
-                    ri.live_cells--;
-                    break;
-                }
-        }
-        if (s.final_done && s.cells.empty() && *nfinished < fcap) {
+        ring_pop_records(r, si, out, cap, n);
+        if ((s.final_done || s.failed) && s.cells.empty() && *nfinished < fcap) {
             finished[(*nfinished)++] = si;
             s.reported = true;
         }
@@ -812,10 +950,12 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
         if (o + 1 < cap) o += (size_t)std::max(0, snprintf(buf + o, (size_t)(cap - o), fmt, a...));
         if (o >= cap) o = (size_t)cap - 1;
     };
-    put("ctl: tail=%u stop=%u head=%u ltail=%u lhead=%u free_count=%u error=%u | host: free_read=%u free_pages=%zu rounds=%zu "
-        "next_seq=%u service_running=%d tail_seen=%u claim_progress=%u backlog_limit=%llu\n", ctl.tail, ctl.stop, ctl.head,
-        ctl.ltail, ctl.lhead, ctl.free_count, ctl.error, r->free_read, r->free_pages.size(), r->rounds.size(), r->next_seq,
-        (int)r->service_running, r->tail_seen, r->heartbeat.as<volatile uint32_t>()[32], (unsigned long long)r->backlog_limit);
+    volatile uint32_t *hb = hb_words(r);
+    put("ctl: tail=%u stop=%u head=%u ltail=%u lhead=%u free_count=%u error=%u rounds_done=%u | host: free_read=%u free_pages=%zu "
+        "rounds=%zu next_seq=%u rounds_enq=%u service=%d tail_seen=%u claim_progress=%u backlog_limit=%llu intent=%u committed=%u\n",
+        ctl.tail, ctl.stop, ctl.head, ctl.ltail, ctl.lhead, ctl.free_count, ctl.error, ctl.rounds_done, r->free_read,
+        r->free_pages.size(), r->rounds.size(), r->next_seq, r->rounds_enq, (int)r->svc, r->tail_seen, hb[pbsk::kHbClaim],
+        (unsigned long long)r->backlog_limit, hb[pbsk::kHbIntent], hb[pbsk::kHbCommitted]);
     uint32_t nz = 0;
     for (uint32_t p = 0; p < r->npages && nz < 64; ++p)
         if (pend[p]) {
@@ -825,10 +965,11 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
     for (uint32_t i = 0; i < r->slots.size(); ++i) {
         const StreamSlot &s = r->slots[i];
         if (!s.open) continue;
-        put("stream %u: committed=%llu enqueued=%llu final_committed=%d final_enqueued=%d final_done=%d ready=%zu cells=%zu out=%llu | "
-            "device c=%llu end=%llu\n", i, (unsigned long long)s.bytes_committed, (unsigned long long)s.bytes_enqueued,
-            (int)s.final_committed, (int)s.final_enqueued, (int)s.final_done, s.ready.size(), s.cells.size(),
-            (unsigned long long)s.records_out, (unsigned long long)sts[i].c, (unsigned long long)sts[i].end);
+        put("stream %u: committed=%llu enqueued=%llu final_committed=%d final_enqueued=%d final_done=%d failed=%d ready=%zu cells=%zu "
+            "out=%llu | device c=%llu end=%llu failed=%u\n", i, (unsigned long long)s.bytes_committed,
+            (unsigned long long)s.bytes_enqueued, (int)s.final_committed, (int)s.final_enqueued, (int)s.final_done, (int)s.failed,
+            s.ready.size(), s.cells.size(), (unsigned long long)s.records_out, (unsigned long long)sts[i].c,
+            (unsigned long long)sts[i].end, sts[i].failed);
         if (!s.cells.empty()) {
             const uint8_t *c = r->cells.as<uint8_t>() + (size_t)s.cells.front().cell * 64;
             pbsgpu_record rec;

@@ -1,0 +1,145 @@
+// The page ring's host-side state (ring.cpp), shared with the payload-stream writer (stream.cpp), which is a CLIENT of an
+// engine-owned ring: pbsgpu_stream_* = staging + H2D into reserved pages + the bookkeeping of sections, tees and entries;
+// cutting, hashing, page release and record delivery are the ring's. Not part of the C ABI.
+#pragma once
+
+#include <deque>
+#include <mutex>
+#include <vector>
+
+#include "engine_internal.h"
+
+namespace pbse {
+
+constexpr uint32_t kRingInputs = 16;            // rounds whose host-written tables may be in flight
+constexpr uint32_t kPagesPerStreamRound = 48;   // < kRingPT - 2 (open chunk) with room to spare
+
+struct PageReq {                          // a committed page waiting for its round
+    uint32_t phys = 0;
+    uint64_t k = 0;                       // logical page index in its stream
+    uint32_t valid = 0;
+    bool final = false;
+    bool do_fill = false;
+    uint64_t seed = 0, fill_off = 0;
+    uint32_t kind = 0;
+    hipEvent_t dep = nullptr;             // the page's bytes are there once this event has completed (host-fed pages: the
+                                          // H2D copy, or the XXH3 tee behind it); from the ring's event pool, returned at enqueue
+};
+
+struct CellRef {
+    uint32_t cell;
+    uint32_t round_idx;                   // RoundInfo::seq of the round that produced it
+};
+
+struct StreamSlot {
+    bool open = false;
+    bool fresh = true;                    // no round has carried this stream yet (device state starts from zero)
+    bool failed = false;                  // a scan tile overflowed its candidate slots: this stream only (PBSGPU_E_DENSITY)
+    uint64_t next_k = 0;                  // next logical page
+    uint64_t bytes_committed = 0;
+    uint64_t bytes_enqueued = 0;          // stream length after the rounds enqueued so far
+    bool final_committed = false, final_enqueued = false, final_done = false;
+    bool zero_final = false;              // final commit of 0 bytes still to be carried by a round
+    int64_t reserved = -1;                // physical page handed out by reserve
+    std::deque<PageReq> ready;
+    std::deque<CellRef> cells;            // record cells in stream order (round results reaped)
+    uint64_t records_out = 0;
+    bool reported = false;                // poll_any has announced the end of this stream
+    uint64_t origin = 0;                  // payload position of the stream's byte 0 (absolute reader grid of suggested boundaries)
+    std::deque<uint64_t> sugg;            // suggested boundaries still of interest (stream offsets, ascending)
+    void *owner = nullptr;                // the stream writer's section that feeds this slot (stream.cpp)
+};
+
+struct RoundInfo {
+    uint32_t seq = 0;                     // round number + 1
+    uint32_t input = 0;
+    uint64_t cell_base = 0;               // monotonic
+    uint32_t cell_cap = 0;
+    uint32_t live_cells = 0;              // cells handed to streams and not yet polled
+    bool reaped = false;
+    std::vector<uint32_t> finals;         // slots whose stream ended with this round
+    std::vector<uint32_t> seg_slots;      // slot of every segment of the round
+    uint64_t new_bytes = 0;               // stream bytes this round added
+};
+
+enum class SvcState { Stopped, Running, Stopping };
+
+}  // namespace pbse
+
+struct pbsgpu_ring {
+    pbsgpu_engine *eng = nullptr;
+    bool holds_engine_ref = true;         // false for the engine's own ring (the engine owns it, not the reverse)
+    std::mutex mu;                        // taken by the stream writer around every use (the C ABI's ring calls are
+                                          // single-threaded by contract and do not lock)
+    // geometry
+    uint64_t page_bytes = 0, stride = 0;
+    uint32_t tile_bytes = 0, tpp = 0, npages = 0, max_streams = 0, sha_cus = 0, round_pages = 0, min_round_pages = 0, cap = 0;
+    uint32_t max_inflight = 3;
+    // backlog gate: no page is handed out while more than this many bytes wait in front of the service — committed pages
+    // not yet in a round, rounds in flight, published chunks no lane has claimed. A full arena of unhashed chunks feeds
+    // the service no faster than a short queue does; it only adds its length to every latency (and to the final drain).
+    uint64_t backlog_limit = 0;
+    uint64_t ready_bytes = 0, inflight_bytes = 0;
+    uint32_t tail_seen = 0;               // queue tail after the last reaped round
+    uint64_t pub_positions = 0, pub_bytes = 0;  // queue positions / stream bytes of all reaped rounds (average chunk size)
+    uint64_t rec_cap = 0, dense_cap = 0;
+    uint32_t qslots = 0, ncells = 0, nfree = 0;
+    // device
+    pbse::DevBuf arena, ctl, streams, pending, desc, ldesc;
+    uint32_t lslots = 0, long_bytes = 0;
+    pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
+    pbse::DevBuf seg_ecand_in, seg_ecand, seg_fail;
+    // mapped pinned
+    pbse::PinnedBuf cells, free_fifo, inputs, heartbeat;
+    pbse::PinnedBuf sugg_in[pbse::kRingInputs];  // suggested offsets of the round built in input i (grown on demand)
+    size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_segstat_off = 0, in_recbase_off = 0, in_suggidx_off = 0,
+           in_status_off = 0;
+    hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
+    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr;
+    hipEvent_t ev_fill[pbse::kRingInputs] = {};
+    std::vector<hipEvent_t> ev_pool;      // page dependency events (ring_event_get / ring_event_put)
+    pbse::SvcState svc = pbse::SvcState::Stopped;
+    uint32_t rounds_enq = 0;              // mirrored into the heartbeat block for the service's self-stop handshake
+    double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
+    double idle_since_ms = 0;
+    // host bookkeeping
+    std::vector<uint32_t> free_pages;
+    uint32_t free_read = 0;               // entries of the free FIFO consumed
+    std::vector<pbse::StreamSlot> slots;
+    std::deque<pbse::RoundInfo> rounds;   // enqueued, oldest first; popped when reaped AND all their cells were polled
+    bool input_busy[pbse::kRingInputs] = {};
+    uint32_t next_seq = 1;
+    uint64_t cell_cursor = 0;
+    int error = PBSGPU_OK;
+    pbsgpu_ring_stats st{};
+    double svc_t0 = 0;
+    uint64_t svc_bytes0 = 0;
+
+    uint8_t *in(uint32_t i) const { return inputs.as<uint8_t>() + (size_t)i * input_stride; }
+    pbsk::RingPage *in_pages(uint32_t i) const { return reinterpret_cast<pbsk::RingPage *>(in(i) + in_pages_off); }
+    pbsk::RingSeg *in_segs(uint32_t i) const { return reinterpret_cast<pbsk::RingSeg *>(in(i) + in_segs_off); }
+    uint32_t *in_segstat(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_segstat_off); }
+    uint32_t *in_recbase(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_recbase_off); }
+    uint32_t *in_suggidx(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_suggidx_off); }
+    pbsk::RingRoundStatus *in_status(uint32_t i) const {
+        return reinterpret_cast<pbsk::RingRoundStatus *>(in(i) + in_status_off);
+    }
+    pbsk::RingSource source() const;
+};
+
+namespace pbse {
+
+// ring.cpp internals the stream writer uses (caller holds ring->mu)
+int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool hold_engine_ref, pbsgpu_ring **out);
+// an event from the ring's pool; record it behind the page's last copy / tee and hand it to ring_commit_dep
+int ring_event_get(pbsgpu_ring *r, hipEvent_t *ev);
+void ring_event_put(pbsgpu_ring *r, hipEvent_t ev);
+// pbsgpu_ring_commit with a dependency: the page's bytes are there once `dep` has completed (nullptr = they are now)
+int ring_commit_dep(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final, hipEvent_t dep);
+// records of one stream that are ready, in order, appended to out[*n ..) (segment = slot)
+void ring_pop_records(pbsgpu_ring *r, uint32_t slot, pbsgpu_record *out, uint64_t cap, uint64_t *n);
+// stop the service behind everything enqueued so far WITHOUT waiting for it; the next round starts it again
+int ring_park(pbsgpu_ring *r);
+bool ring_idle(const pbsgpu_ring *r);
+
+}  // namespace pbse

@@ -4,6 +4,7 @@
 //    feeds (reference internal/pxarmount/commit_reuse.go:427-468, commit_walk.go:465-479,
 //    internal/tapeio/converter.go:827-842): bytes are appended to one continuous stream and
 //    (end, digest) records fall out in order, exactly what the module appends to the .didx.
+//    A client of the engine's page ring (ring.cpp) since round 4.
 //  * pbsgpu_chunker_* — upstream `scan(data) -> pos` compatibility (buzhash.Config's chunker).
 //  * pbsgpu_dedup_host — digest-set duplicate detection on the device.
 //  * pbsgpu_didx_*    — dynamic index encode/decode (commit_bottleneck_test.go:773-793).
@@ -16,18 +17,13 @@
 #include <mutex>
 #include <thread>
 
-#include "engine_internal.h"
+#include "ring_internal.h"
 
 using namespace pbse;
 
 // -------------------------------------------------------------------------------------
-// shared SHA-256 jobs (engine-wide)
+// caller bytes -> pinned staging, on several threads for large writes
 // -------------------------------------------------------------------------------------
-// Windows of every stream append their chunk descriptors to the engine's OPEN job; whoever finds a free hash lane
-// seals the job and launches it (one k_sha256_pair launch over all accumulated chunks, longest first). A launch
-// cannot finish before the serial chain of its longest chunk (up to ~0.43 s at 16 MiB), so with one launch per
-// window the number of concurrent kernels would grow with the ingest rate and exhaust the hardware queues; with
-// shared jobs it is bounded by the lane count while every chunk still starts within one lane-turnaround.
 namespace pbse {
 
 namespace {
@@ -110,282 +106,98 @@ void parallel_memcpy(void *dst, const void *src, size_t n) {
     pool.cv_done.wait(lk, [] { return pool.pending == 0; });
 }
 
-constexpr int kHashLanes = 6;  // + 2 copy streams + one stream per payload stream: within the 24 hardware queues for 8 writers
-
-int hd_init(pbsgpu_engine *e) {
-    HashDispatcher &hd = e->hd;
-    hd.num_cus = e->num_cus;
-    int nlanes = kHashLanes;
-    if (const char *v = getenv("PBSGPU_HASH_LANES")) nlanes = std::min(16, std::max(1, atoi(v)));
-    // + reserve lanes, taken only by a job somebody BLOCKS on (the last job of an archive, a writer whose ring is full)
-    // when every regular lane is busy: lanes do not stay evenly staggered (jobs last 0.3-0.55 s depending on their longest
-    // chunk), so without them such a job waits up to a whole job time for a lane
-    int nreserve = 0;  // (measured: no gain for one writer, -15 % for eight, profiles/r03_hostfeed_hash_job_pacing.log)
-    if (const char *v = getenv("PBSGPU_HASH_RESERVE_LANES")) nreserve = std::min(8, std::max(0, atoi(v)));
-    hd.regular_lanes = nlanes;
-    hd.lanes.assign((size_t)(nlanes + nreserve), nullptr);
-    hd.lane_job.assign((size_t)(nlanes + nreserve), nullptr);
-    // launches are SPACED by 0.8 x (chain of a max-size chunk) / lanes = 61 ms at 16 MiB chunks and 6 lanes (policy and
-    // measurements: engine_internal.h); small maximum chunk sizes make the interval vanish
-    hd.min_interval_ms = 0.8 * ((double)e->cfg.max / 64.0 * 1.75e-3) / (double)nlanes;
-    hd.t0_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (const char *v = getenv("PBSGPU_HASH_INTERVAL_MS")) hd.min_interval_ms = atof(v);
-    if (const char *v = getenv("PBSGPU_HASH_BYPASS_GIB")) hd.bypass_bytes = (uint64_t)(atof(v) * 1073741824.0);
-    for (auto &st : hd.lanes) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    return PBSGPU_OK;
-}
-
-void hd_destroy(pbsgpu_engine *e) {
-    HashDispatcher &hd = e->hd;
-    for (auto st : hd.lanes)
-        if (st) (void)hipStreamSynchronize(st);
-    for (auto &j : hd.jobs) {
-        j->d_queue.release();
-        for (PinnedBuf *b : {&j->h_desc, &j->h_order, &j->h_dig}) b->release();
-        if (j->done) (void)hipEventDestroy(j->done);
-    }
-    hd.jobs.clear();
-    for (auto st : hd.lanes)
-        if (st) (void)hipStreamDestroy(st);
-    hd.lanes.clear();
-}
-
 }  // namespace pbse
 
+// -------------------------------------------------------------------------------------
+// streaming writer — a client of the engine's page ring (ring.cpp)
+// -------------------------------------------------------------------------------------
+// Rounds 1-3 ran this seam on an engine of its own (a private ring of window buffers per stream, deferred window cuts with
+// a headroom carry, six engine-wide hash-job lanes whose launches each lasted one max-size chunk chain). Since round 4 a
+// payload stream owns nothing but its STAGING: caller bytes -> pinned staging -> H2D straight into a page reserved from
+// the engine's page ring. Cutting (rounds over the new pages of all streams), hashing (the persistent SHA-256 service: a
+// chunk starts the moment it is cut), page release (a page is free again when its last chunk has been READ) and record
+// delivery are the ring's, shared with pbsgpu_ring_* callers and by all streams of the engine. What the seam adds on top:
+//   * sections: InjectChunks (pbsgpu_stream_cut) ends the current ring stream with a forced cut and the next bytes open
+//     a new one; records carry the section as `segment` and payload positions (written + injected) as `end`;
+//   * suggested boundaries in payload coordinates, forwarded to the section they fall into;
+//   * the per-file XXH3-64 tee and the pxar payload entry headers, run on a page's bytes before the page is committed;
+//   * records and file hashes are collected by WHICHEVER stream of the engine calls next (one lock per ring), so a writer
+//     that sits in a blocking read never holds up the others.
 namespace {
 
-// hd.mu held: a job object that is neither open, running, nor still referenced by a window
-HashJob *hd_new_job(HashDispatcher &hd) {
-    for (auto &j : hd.jobs) {
-        if (j.get() == hd.open || j->refs.load() != 0) continue;
-        bool on_lane = false;
-        for (auto *lj : hd.lane_job) on_lane |= (lj == j.get());
-        if (on_lane) continue;
-        j->descs.clear();
-        j->n = 0;
-        j->lane = -1;
-        j->state = HashJob::OPEN;
-        return j.get();
-    }
-    std::unique_ptr<HashJob> j(new (std::nothrow) HashJob());
-    if (!j) return nullptr;
-    if (hipEventCreateWithFlags(&j->done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    hd.jobs.push_back(std::move(j));
-    return hd.jobs.back().get();
-}
-
-// hd.mu held. Seal the open job and launch it if a lane is free. Returns PBSGPU_OK with *launched = false when every
-// lane is still busy (the caller may wait on *busy_ev, outside the lock, and retry).
-static double hd_now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-int hd_try_launch_locked(pbsgpu_engine *e, bool *launched, hipEvent_t *busy_ev, bool force = false) {
-    HashDispatcher &hd = e->hd;
-    *launched = false;
-    if (busy_ev) *busy_ev = nullptr;
-    HashJob *j = hd.open;
-    if (!j || j->descs.empty()) return PBSGPU_OK;
-    // pacing (engine_internal.h): go at once when a good amount of work is waiting, otherwise keep launches spaced
-    if (!force && hd.open_bytes < hd.bypass_bytes && hd_now_ms() - hd.last_launch_ms < hd.min_interval_ms) return PBSGPU_OK;
-    int lane = -1;
-    const int usable = force ? (int)hd.lanes.size() : hd.regular_lanes;
-    for (int i = 0; i < usable && lane < 0; ++i) {
-        HashJob *lj = hd.lane_job[i];
-        if (!lj) {
-            lane = i;
-        } else {
-            const hipError_t q = hipEventQuery(lj->done);
-            if (q == hipSuccess) {
-                hd.lane_job[i] = nullptr;
-                lane = i;
-            } else if (q != hipErrorNotReady) {
-                g_last_hip_error.store((int)q);
-                return PBSGPU_E_HIP;
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-    }
-    if (lane < 0) {
-        if (busy_ev) {  // the job launched first is the next to finish (all last about one max-size chunk chain)
-            HashJob *oldest = hd.lane_job[0];
-            for (int i = 0; i < usable; ++i)
-                if (hd.lane_job[i]->launched_ms < oldest->launched_ms) oldest = hd.lane_job[i];
-            *busy_ev = oldest->done;
-        }
-        return PBSGPU_OK;
-    }
-    const uint32_t n = (uint32_t)j->descs.size();
-    hipStream_t st = hd.lanes[lane];
-    const size_t room = std::max<size_t>(n, 8192);  // regrowing later would wait for the whole device (hipFree)
-    CHK(j->h_desc.ensure(room * sizeof(pbsk::HashDesc)));
-    CHK(j->h_order.ensure(room * 4));
-    CHK(j->h_dig.ensure(room * 32));
-    CHK(j->d_queue.ensure(64));
-    std::memcpy(j->h_desc.p, j->descs.data(), (size_t)n * sizeof(pbsk::HashDesc));
-    // longest first (the launch lasts as long as its longest chain) + the CU budget that keeps the launch at that bound
-    uint32_t *ord = j->h_order.as<uint32_t>();
-    for (uint32_t i = 0; i < n; ++i) ord[i] = i;
-    std::sort(ord, ord + n, [&](uint32_t a, uint32_t b) { return j->descs[a].len > j->descs[b].len; });
-    uint64_t total_blocks = 0, longest = 1;
-    for (const auto &d : j->descs) {
-        const uint64_t blocks = (d.len + 8) / 64 + 1;
-        total_blocks += blocks;
-        longest = std::max(longest, blocks);
-    }
-    uint64_t lanes_needed = (total_blocks * 125 / 100 + longest - 1) / longest;
-    unsigned wgs = (unsigned)std::min<uint64_t>((lanes_needed + 127) / 128, (uint64_t)hd.num_cus);
-    HIPCHK(hipMemsetAsync(j->d_queue.p, 0, 64, st));
-    // No copy engine anywhere in a job: the kernel reads descriptors + order from, and writes the digests to, mapped
-    // pinned memory. A small H2D copy would queue behind the streams' payload pieces in the shared SDMA queues, and a
-    // D2H copy parked behind this 0.4 s kernel would block that queue for every other stream (kernels.hip, k_publish).
-    HIPCHK(pbsk::launch_sha256_descs(j->h_desc.as<pbsk::HashDesc>(), n, j->h_order.as<uint32_t>(), j->h_dig.as<uint8_t>(),
-                                     j->d_queue.as<uint32_t>(), wgs,
-                                     pbsk::sha256_dense_pays(total_blocks, longest, hd.num_cus), st));
-    HIPCHK(hipEventRecord(j->done, st));
-    j->n = n;
-    j->lane = lane;
-    j->state = HashJob::LAUNCHED;
-    hd.lane_job[lane] = j;
-    hd.open = nullptr;
-    hd.open_bytes = 0;
-    hd.last_launch_ms = hd_now_ms();
-    j->launched_ms = hd.last_launch_ms;
-    *launched = true;
-    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
-    if (trace) {
-        int busy = 0;
-        for (auto *lj : hd.lane_job) busy += lj != nullptr;
-        fprintf(stderr, "[pbsgpu] t=%.1f ms hash job: %u chunks, %.1f MiB, longest %.1f MiB, %u workgroups, lane %d (%d busy)%s\n",
-                hd.last_launch_ms - hd.t0_ms, n, total_blocks / 16384.0, longest / 16384.0, wgs, lane, busy, force ? " forced" : "");
-    }
-    return PBSGPU_OK;
-}
-
-// append `n` descriptors to the open job; returns the job and the index of the first one. Tries to launch at once.
-int hd_append(pbsgpu_engine *e, const pbsk::HashDesc *d, uint32_t n, HashJob **job, uint32_t *first) {
-    HashDispatcher &hd = e->hd;
-    std::lock_guard<std::mutex> lk(hd.mu);
-    if (!hd.open) {
-        hd.open = hd_new_job(hd);
-        if (!hd.open) return PBSGPU_E_NOMEM;
-    }
-    HashJob *j = hd.open;
-    *first = (uint32_t)j->descs.size();
-    j->descs.insert(j->descs.end(), d, d + n);
-    for (uint32_t i = 0; i < n; ++i) hd.open_bytes += d[i].len;
-    j->refs.fetch_add(1);
-    *job = j;
-    bool launched;
-    return hd_try_launch_locked(e, &launched, nullptr);
-}
-
-// make sure `j` gets launched (it may still be the open job because every lane was busy when it was filled)
-int hd_ensure_launched(pbsgpu_engine *e, HashJob *j, bool block) {
-    HashDispatcher &hd = e->hd;
-    for (;;) {
-        hipEvent_t busy = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(hd.mu);
-            if (j->state == HashJob::LAUNCHED) return PBSGPU_OK;
-            bool launched = false;
-            CHK(hd_try_launch_locked(e, &launched, &busy, block));  // someone waits for this job: no pacing
-            if (launched || j->state == HashJob::LAUNCHED) return PBSGPU_OK;
-        }
-        if (!block) return PBSGPU_OK;
-        if (busy) HIPCHK(hipEventSynchronize(busy));  // a lane frees up when its (oldest) job ends
-        else std::this_thread::sleep_for(std::chrono::milliseconds(2));  // pacing: streams finishing together share a job
-    }
-}
-
-// -------------------------------------------------------------------------------------
-// streaming writer
-// -------------------------------------------------------------------------------------
-// A stream owns everything it touches on the cut side (two private work contexts on ONE HIP stream, its window
-// buffers, pinned staging): several streams of one engine run concurrently from different threads without ever
-// taking the engine lock. The writer thread never waits for the GPU in steady state:
-//   * a full window's cut (scan + resolve + the per-file XXH3 tee) is only ENQUEUED behind its last H2D piece; the
-//     writer moves on to the next window buffer at once, writing new bytes behind a max-chunk-sized headroom;
-//   * at the NEXT flush the previous cut (long finished) is read back: its complete chunks go to the engine's shared
-//     hash jobs, its still-open tail chunk is copied into the headroom in front of the new bytes (a cut only depends
-//     on bytes before it, so re-examining the open chunk with more data reproduces the serial chunker);
-//   * digests arrive asynchronously with the shared jobs; records are delivered strictly in stream order.
-struct WindowInFlight {
-    int buf = -1;
-    HashJob *job = nullptr;
-    uint32_t first = 0;                  // index of this window's first descriptor in the job
-    std::vector<pbsgpu_record> recs;     // end (absolute) / size / section filled in; digests arrive with the job
+struct Section {                         // the bytes between two forced cuts = one stream of the ring
+    uint32_t rid = 0;                    // ring stream slot (valid until ring_done)
+    uint32_t index = 0;                  // section number: the records' `segment`
+    uint64_t base = 0;                   // payload position of its first byte
+    bool input_closed = false;           // its last page has been committed
+    bool ring_done = false;              // the ring has delivered its last record (slot closed)
+    int error = PBSGPU_OK;
+    std::deque<pbsgpu_record> recs;      // filled under ring->mu by whoever drains the ring
 };
 
 struct FileSpan {                        // a file body inside the stream (begin_file .. end_file), in WRITTEN-byte coordinates
     uint64_t index = 0, w_start = 0, w_end = 0;
     bool closed = false, started = false;
-    uint32_t state = 0;                  // which of the two streaming XXH3 states carries it across windows
+    uint32_t state = 0;                  // which of the two streaming XXH3 states carries it across pages
     uint32_t pend = 0;                   // host mirror of xxh::State::pend_len (pure arithmetic on the piece lengths)
 };
 
-struct PendingCut {                      // a window whose cut has been enqueued but not read back yet
-    bool active = false;
-    int ctx = 0, buf = -1;
-    uint64_t base = 0;                   // absolute stream offset (incl. injected bytes) of the window's first byte
-    uint64_t carry = 0, total = 0;       // the window is [headroom - carry, headroom - carry + total) of its buffer
-    uint32_t section = 0;
-    bool final = false;
-    std::vector<uint64_t> sugg_rel;      // suggested boundaries relative to the window start (for a capacity retry)
-    std::vector<pbsgpu_file_hash> files; // files whose last piece was in this window (xxh3 filled in at read-back)
-    std::vector<uint32_t> file_out;      // ... and the tee output slot of each
+struct TeeLaunch {                       // item tables of one tee launch (a small ring of them: launches overlap)
+    PinnedBuf h_items, h_out;            // mapped: item table (read by the upload kernel), hashes (written by the tee kernel)
+    DevBuf d_items;
+    hipEvent_t done = nullptr;           // recorded behind the launch; the tables are reusable once it has completed
+    bool busy = false;
+    std::vector<pbsgpu_file_hash> files; // files whose last piece is in this launch (xxh3 filled in at harvest)
+    std::vector<uint32_t> out_slot;      // ... and its index in h_out
 };
 
 constexpr size_t kStreamStage = 32u << 20;
 constexpr int kStreamStages = 3;
+constexpr int kTeeLaunches = 8;
 
 }  // namespace
 
 struct pbsgpu_stream {
     pbsgpu_engine *eng = nullptr;
-    uint64_t window = 0;           // new bytes per device window
-    uint64_t headroom = 0;         // = max chunk size: room for the carried open chunk in front of the new bytes
-    size_t devcap = 0;
-    size_t max_bufs = 0;           // ring limit (back-pressure beyond it)
-    std::vector<DevBuf> dev;       // window buffers: [headroom (carry right-aligned) | new bytes]
-    std::vector<char> dev_busy;    // held by a window whose chunks are still being hashed, or by the pending cut
-    int cur = 0;
-    uint64_t carry = 0;            // bytes of the still-open chunk in front of the new bytes of dev[cur]
-    uint64_t fill = 0;             // new bytes already copied into dev[cur]
-    Slot cut[2];                   // private cut contexts, alternating; cut[1] borrows cut[0]'s HIP stream
-    int cut_next = 0;
-    hipStream_t hs = nullptr;      // == cut[0].stream: cuts, the tee and the carry copy, in order
-    // H2D payload pieces ride the ENGINE's shared copy streams and never wait for a kernel: a copy that depends on a
-    // kernel parks at the head of the SDMA queue it shares with other copies and stalls all of them (measured: 8
-    // producers with copies on their cut streams reached 22 GiB/s, 2 producers 46). hs waits for the pieces' events.
-    hipEvent_t piece_ev[2] = {};   // last piece of the current window on each of the engine's copy streams
-    bool piece_used[2] = {false, false};
-    PendingCut pend;
+    pbsgpu_ring *ring = nullptr;         // the engine's page ring
+    uint64_t window = 0;                 // as given to create (recycling key; the ring's page size is what matters)
+    // staging: caller bytes are gathered here (cgo pointer rule) and copied H2D piecewise
     PinnedBuf stage[kStreamStages];
-    hipEvent_t stage_ev[kStreamStages] = {};
+    hipEvent_t stage_ev[kStreamStages][2] = {};   // last copy out of the buffer on each of the engine's copy streams
+    bool stage_used[kStreamStages][2] = {};
     int stage_idx = 0;
-    size_t stage_fill = 0;         // bytes gathered in stage[stage_idx] and not yet pushed (small writes are coalesced)
-    int reserved = -1;             // staging buffer handed out by pbsgpu_stream_reserve
-    uint64_t base = 0;             // absolute stream offset (incl. injected bytes) of the carry's first byte
-    uint64_t written = 0;
-    uint64_t inject_total = 0;
-    uint32_t section = 0;
-    bool finished = false;  // input closed (the final flush is enqueued)
-    bool drained = false;   // ... and every record has been delivered to `out`
-    std::deque<uint64_t> suggested;  // pending suggested boundaries (absolute offsets, ascending)
-    std::deque<WindowInFlight> inflight;
+    size_t stage_fill = 0;               // bytes gathered in stage[stage_idx] and not yet pushed (small writes are coalesced)
+    int reserved = -1;                   // staging buffer handed out by pbsgpu_stream_reserve
+    // the page being filled
+    bool have_page = false;
+    uint8_t *page_ptr = nullptr;
+    uint64_t page_fill = 0, page_cap = 0;
+    uint64_t page_w0 = 0;                // written-byte coordinate of the page's first byte
+    int page_cs = 0;                     // engine copy stream all of this page's copies ride on
+    // sections
+    std::deque<std::unique_ptr<Section>> sections;  // oldest first; the last one may be `cur`
+    Section *cur = nullptr;              // section that takes new bytes (null until the first byte behind a cut)
+    uint32_t section_index = 0;
+    uint64_t written = 0, inject_total = 0;
+    uint64_t landed = 0;                 // written bytes that have been copied into pages so far
+    bool finished = false;               // input closed
+    bool drained = false;                // ... and every record has been moved to `out`
+    int error = PBSGPU_OK;               // sticky (a failed section, a ring error)
+    std::deque<uint64_t> suggested;      // announced boundaries (payload positions, ascending) not yet behind the stream
+    size_t sugg_fwd = 0;                 // how many of them the current section's ring stream already knows
     std::deque<pbsgpu_record> out;
-    std::vector<pbsk::HashDesc> descs;
     // per-file XXH3-64 tee
-    std::deque<FileSpan> files;      // files not yet completely hashed, in stream order
+    std::deque<FileSpan> files;          // files not yet completely hashed, in stream order
     uint64_t next_file = 0;
     uint32_t n_stateful = 0;
     bool file_open = false;
-    uint64_t entry_left = 0;         // begin_entry: content bytes still expected
+    uint64_t entry_left = 0;             // begin_entry: content bytes still expected
     bool in_entry = false;
-    DevBuf tee_states, tee_queue, tee_items, tee_sums;
-    PinnedBuf h_tee_items, h_tee_out;  // mapped: read / written by the tee kernel directly
+    hipStream_t tee_stream = nullptr;    // one of the engine's (all tee launches of this stream: in order)
+    DevBuf tee_states, tee_queue, tee_sums;
+    TeeLaunch tee[kTeeLaunches];
+    uint32_t tee_next = 0;               // next launch slot
+    std::deque<int> tee_pending;         // launch slots in flight, oldest first
     std::deque<pbsgpu_file_hash> file_out;
 };
 
@@ -395,115 +207,148 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// move the oldest window's records (now with digests) to the output queue, release its buffer
-int stream_complete_oldest(pbsgpu_stream *s, bool block) {
-    WindowInFlight &w = s->inflight.front();
-    CHK(hd_ensure_launched(s->eng, w.job, block));
-    {
-        std::lock_guard<std::mutex> lk(s->eng->hd.mu);
-        if (w.job->state != HashJob::LAUNCHED) return PBSGPU_E_BUSY;  // only when !block
+// ---- the engine's ring ----------------------------------------------------------------------------------------------------
+int engine_ring_get(pbsgpu_engine *e, pbsgpu_ring **out) {
+    std::lock_guard<std::mutex> lk(e->sring_mu);
+    if (!e->sring) {
+        CHK(set_device(e));
+        pbsgpu_ring_options o{};
+        // Arena: ingest rate x residency. A host-fed engine moves <= ~55 GiB/s (PCIe) and a page stays for queue wait + the
+        // chain of the longest chunk touching it (<= 0.46 s, ~0.3 s on average): 48 GiB is generous (PBSGPU_STREAM_RING_GIB).
+        // Service: 50 GiB/s need ~12 CUs of chains (4.3 GiB/s per CU); 32 leave headroom for bursts and keep 7/8 of the chip
+        // for everything else the process runs (PBSGPU_STREAM_SHA_CUS).
+        double gib = 48.0;
+        if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) gib = std::max(0.001, atof(v));
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        uint64_t want = (uint64_t)(gib * 1073741824.0);
+        const uint64_t keep = 4ull << 30;  // tables, other allocations of the process
+        if (fr > keep && want > fr - keep) want = fr - keep;
+        o.arena_bytes = want;
+        int cus = std::max(1, std::min(32, e->num_cus / 2));
+        if (const char *v = getenv("PBSGPU_STREAM_SHA_CUS")) cus = std::max(1, std::min(atoi(v), e->num_cus - 1));
+        o.sha_cus = (uint32_t)cus;
+        o.max_streams = 256;
+        if (const char *v = getenv("PBSGPU_STREAM_RING_SLOTS")) o.max_streams = (uint32_t)std::max(4, std::min(atoi(v), 4096));
+        if (const char *v = getenv("PBSGPU_STREAM_PAGE_BYTES")) o.page_bytes = (uint64_t)std::max(0L, atol(v));
+        pbsgpu_ring *r = nullptr;
+        CHK(ring_create_internal(e, &o, false, &r));
+        // nothing in flight anywhere for 2 ms: stop the service (its CUs, and hipFree / device-wide syncs of the process, come
+        // back); the next page starts it again
+        if (r->autopark_ms == 0) r->autopark_ms = 2.0;
+        e->sring = r;
     }
-    if (block) {
-        HIPCHK(hipEventSynchronize(w.job->done));
-    } else {
-        const hipError_t q = hipEventQuery(w.job->done);
-        if (q == hipErrorNotReady) {
-            (void)hipGetLastError();
-            return PBSGPU_E_BUSY;
-        }
-        HIPCHK(q);
-    }
-    for (size_t i = 0; i < w.recs.size(); ++i) {
-        std::memcpy(w.recs[i].digest, w.job->digest(w.first + (uint32_t)i), 32);
-        s->out.push_back(w.recs[i]);
-    }
-    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
-    if (trace && w.job->refs.load() == 1)  // the job's last window: the job is over
-        fprintf(stderr, "[pbsgpu] t=%.1f ms hash job of lane %d (launched t=%.1f ms, %u chunks) delivered%s\n",
-                hd_now_ms() - s->eng->hd.t0_ms, w.job->lane, w.job->launched_ms - s->eng->hd.t0_ms, w.job->n, block ? " (waited)" : "");
-    w.job->refs.fetch_sub(1);
-    s->dev_busy[w.buf] = 0;
-    s->inflight.pop_front();
+    e->sring_users++;
+    *out = e->sring;
     return PBSGPU_OK;
 }
 
-// a window buffer of devcap bytes: from the engine's pool of returned buffers if one fits, else a fresh allocation
-int stream_buffer_ensure(pbsgpu_stream *s, DevBuf &b) {
-    if (b.cap >= s->devcap) return PBSGPU_OK;
-    {
-        std::lock_guard<std::mutex> lk(s->eng->pool_mu);
-        auto &pool = s->eng->win_pool;
-        for (size_t i = 0; i < pool.size(); ++i)
-            if (pool[i].cap >= s->devcap && pool[i].cap <= s->devcap + s->devcap / 4) {
-                b = std::move(pool[i]);
-                pool.erase(pool.begin() + (long)i);
-                return PBSGPU_OK;
-            }
-    }
-    return b.ensure(s->devcap);
+void engine_ring_put(pbsgpu_engine *e) {
+    std::lock_guard<std::mutex> lk(e->sring_mu);
+    if (e->sring_users > 0) e->sring_users--;
 }
 
-// a window buffer that is neither current nor held; grows the ring up to max_bufs, then waits for the oldest window
-int stream_free_buffer(pbsgpu_stream *s, int *out) {
-    for (;;) {
-        bool retry = false;
-        for (size_t i = 0; i < s->dev.size() && !retry; ++i)
-            if (!s->dev_busy[i] && (int)i != s->cur) {
-                const int st = stream_buffer_ensure(s, s->dev[i]);
-                if (st == PBSGPU_OK) {
-                    *out = (int)i;
-                    return PBSGPU_OK;
-                }
-                // HBM is full (other streams' rings, resident batches): that is back-pressure, not a write error, as long
-                // as this stream has windows in flight whose buffers come back. Drop the empty ring entry, stop growing,
-                // and wait for the oldest window instead. Only a ring that cannot reach its minimum (current + one
-                // more buffer) fails.
-                if (st != PBSGPU_E_NOMEM || s->dev[i].p) return st;
-                {   // buffers parked by destroyed streams are the first thing to give back
-                    std::lock_guard<std::mutex> lk(s->eng->pool_mu);
-                    if (!s->eng->win_pool.empty()) {
-                        for (auto &b : s->eng->win_pool) b.release();
-                        s->eng->win_pool.clear();
-                        retry = true;
-                        continue;
-                    }
-                }
-                if (s->inflight.empty()) return PBSGPU_E_NOMEM;
-                if ((int)i < s->cur) s->cur--;
-                for (auto &w : s->inflight)
-                    if (w.buf > (int)i) w.buf--;
-                if (s->pend.active && s->pend.buf > (int)i) s->pend.buf--;
-                s->dev.erase(s->dev.begin() + (long)i);
-                s->dev_busy.erase(s->dev_busy.begin() + (long)i);
-                s->max_bufs = std::max<size_t>(s->dev.size(), 2);
-                CHK(stream_complete_oldest(s, true));
-                retry = true;
-            }
-        if (retry) continue;
-        if (s->dev.size() < s->max_bufs) {
-            s->dev.emplace_back();
-            s->dev_busy.push_back(0);
-            continue;
+// ring->mu held: pump the ring and hand every stream of the engine what is ready for it — whoever calls collects for all
+int ring_drain(pbsgpu_ring *r) {
+    const int st = pbsgpu_ring_pump(r);
+    thread_local std::vector<pbsgpu_record> buf(4096);
+    for (uint32_t si = 0; si < r->slots.size(); ++si) {
+        StreamSlot &sl = r->slots[si];
+        if (!sl.open) continue;
+        Section *sec = static_cast<Section *>(sl.owner);  // null: its stream was destroyed in an error state — discard
+        for (;;) {
+            uint64_t n = 0;
+            ring_pop_records(r, si, buf.data(), buf.size(), &n);
+            if (sec) sec->recs.insert(sec->recs.end(), buf.begin(), buf.begin() + (long)n);
+            if (n < buf.size()) break;
         }
-        if (s->inflight.empty()) return PBSGPU_E_STATE;
-        CHK(stream_complete_oldest(s, true));  // back-pressure: the ingest outruns the hash jobs
+        if ((sl.final_done || sl.failed) && sl.cells.empty()) {
+            if (sec) {
+                if (sl.failed) sec->error = PBSGPU_E_DENSITY;
+                sec->ring_done = true;
+            }
+            sl.owner = nullptr;
+            (void)pbsgpu_ring_close(r, si);  // (E_DENSITY for a failed stream: recorded above)
+        }
+    }
+    while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
+    return st;
+}
+
+// ring->mu held: this stream's delivered records -> out (payload coordinates), finished sections retired
+void stream_collect(pbsgpu_stream *s) {
+    while (!s->sections.empty()) {
+        Section *sec = s->sections.front().get();
+        for (auto &rec : sec->recs) {
+            pbsgpu_record o = rec;
+            o.end = rec.end + sec->base;
+            o.segment = sec->index;
+            s->out.push_back(o);
+        }
+        sec->recs.clear();
+        if (sec->error != PBSGPU_OK && s->error == PBSGPU_OK) s->error = sec->error;
+        if (!sec->ring_done) break;  // records come out in stream order: later sections wait
+        if (sec == s->cur) s->cur = nullptr;
+        s->sections.pop_front();
     }
 }
 
-// queue the per-file XXH3 pieces of the current window's NEW bytes (written-byte range [w0, w0 + fill))
-int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
+int stream_pump(pbsgpu_stream *s) {
+    std::lock_guard<std::mutex> lk(s->ring->mu);
+    const int st = ring_drain(s->ring);
+    stream_collect(s);
+    if (st != PBSGPU_OK && s->error == PBSGPU_OK) s->error = st;
+    return s->error;
+}
+
+// ---- tee ---------------------------------------------------------------------------------------------------------------------
+// results of finished tee launches -> file_out (in file order); block: wait for all of them
+int stream_harvest_tees(pbsgpu_stream *s, bool block) {
+    while (!s->tee_pending.empty()) {
+        TeeLaunch &t = s->tee[s->tee_pending.front()];
+        if (block) {
+            HIPCHK(hipEventSynchronize(t.done));
+        } else {
+            const hipError_t q = hipEventQuery(t.done);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                break;
+            }
+            HIPCHK(q);
+        }
+        for (size_t i = 0; i < t.files.size(); ++i) {
+            t.files[i].xxh3 = t.h_out.as<uint64_t>()[t.out_slot[i]];
+            s->file_out.push_back(t.files[i]);
+        }
+        t.files.clear();
+        t.out_slot.clear();
+        t.busy = false;
+        s->tee_pending.pop_front();
+    }
+    return PBSGPU_OK;
+}
+
+// Queue the per-file XXH3 pieces of the written-byte range [w0, w1) that lies at `base` in device memory (the page being
+// committed; empty range: only zero-length last pieces) on the stream's tee stream, behind `after` (the page's copy).
+// *launched = the tee ran something: then `done_ev` (from the ring's pool, already fetched by the caller) has been recorded
+// behind it and the page must wait for THAT instead of its copy.
+int stream_enqueue_tee(pbsgpu_stream *s, const uint8_t *base, uint64_t w0, uint64_t w1, hipEvent_t after, hipEvent_t done_ev,
+                       bool *launched) {
+    *launched = false;
     if (s->files.empty()) return PBSGPU_OK;
     pbsgpu_engine *e = s->eng;
-    const uint64_t w0 = s->written - s->fill, w1 = s->written;
-    const uint8_t *newp = s->dev[s->cur].as<uint8_t>() + s->headroom;
+    TeeLaunch &t = s->tee[s->tee_next % kTeeLaunches];
+    if (t.busy) {  // the oldest launch still owns these tables: take its results first (launches complete in order)
+        while (t.busy) CHK(stream_harvest_tees(s, true));
+    }
     const size_t maxitems = s->files.size();
-    CHK(s->h_tee_items.ensure(std::max<size_t>(maxitems, 4096) * sizeof(pbsk::XxhItem)));
-    CHK(s->h_tee_out.ensure(std::max<size_t>(maxitems, 4096) * 8));
-    pbsk::XxhItem *items = s->h_tee_items.as<pbsk::XxhItem>();
+    CHK(t.h_items.ensure(std::max<size_t>(maxitems, 1024) * sizeof(pbsk::XxhItem)));
+    CHK(t.h_out.ensure(std::max<size_t>(maxitems, 1024) * 8));
+    pbsk::XxhItem *items = t.h_items.as<pbsk::XxhItem>();
     uint32_t n = 0;
     uint64_t total_blocks = 0;
     for (auto &f : s->files) {
-        if (f.w_start > w1 || (f.w_start == w1 && !(f.closed && f.w_end == f.w_start))) break;  // starts behind this window
+        if (f.w_start > w1 || (f.w_start == w1 && !(f.closed && f.w_end == f.w_start))) break;  // starts behind this range
         const uint64_t lo = std::max(f.w_start, w0);
         const uint64_t hi = f.closed ? std::min(f.w_end, w1) : w1;
         const uint64_t len = hi > lo ? hi - lo : 0;
@@ -511,12 +356,11 @@ int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
         const bool last = f.closed && hi == f.w_end;
         if (len == 0 && !last) continue;  // nothing of it here yet
         pbsk::XxhItem it{};
-        it.ptr = newp + (lo - w0);
+        it.ptr = base + (lo - w0);
         it.len = len;
         it.flags = (first ? 1u : 0u) | (last ? 2u : 0u);
-        if (first && !last) f.state = s->n_stateful++ & 1u;  // at most two files span a window edge at any time
+        if (first && !last) f.state = s->n_stateful++ & 1u;  // at most two files span a page edge at any time
         it.state = f.state;
-        it.out = n;
         // the plan: which 1 KiB blocks this piece completes (XXH3 keeps the final 1..1024 bytes for its tail rules)
         if (first && last) {
             it.pend = 0;
@@ -532,187 +376,168 @@ int stream_enqueue_tee(pbsgpu_stream *s, PendingCut &pc) {
         total_blocks += it.nproc;
         f.started = true;
         if (last) {
-            pc.files.push_back(pbsgpu_file_hash{f.index, f.w_end - f.w_start, 0});
-            pc.file_out.push_back(n);
+            const uint32_t slot = (uint32_t)t.files.size();
+            it.out = slot;
+            t.files.push_back(pbsgpu_file_hash{f.index, f.w_end - f.w_start, 0});
+            t.out_slot.push_back(slot);
         }
         items[n++] = it;
     }
     while (!s->files.empty() && s->files.front().closed) s->files.pop_front();  // closed => its last piece is queued now
     if (n == 0) return PBSGPU_OK;
-    CHK(s->tee_states.ensure(2 * pbsk::xxh3_state_bytes()));
-    CHK(s->tee_queue.ensure(64));
-    CHK(s->tee_items.ensure(std::max<size_t>(maxitems, 4096) * sizeof(pbsk::XxhItem)));
-    CHK(s->tee_sums.ensure((size_t)(s->window / 1024 + 64) * 64));  // presized at create: never regrown
-    HIPCHK(hipMemsetAsync(s->tee_queue.p, 0, 64, s->hs));
-    HIPCHK(pbsk::launch_publish(s->tee_items.p, items, (size_t)n * sizeof(pbsk::XxhItem), s->hs));  // host -> device by kernel
-    HIPCHK(pbsk::launch_xxh3_items(s->tee_items.as<pbsk::XxhItem>(), n, total_blocks, s->tee_states.p,
-                                   s->tee_sums.as<uint64_t>(), s->h_tee_out.as<uint64_t>(), s->tee_queue.as<uint32_t>(),
-                                   e->num_cus, s->hs));
+    CHK(t.d_items.ensure(std::max<size_t>(maxitems, 1024) * sizeof(pbsk::XxhItem)));
+    CHK(s->tee_sums.ensure((size_t)(total_blocks + 64) * 64));
+    hipStream_t ts = s->tee_stream;
+    if (after) HIPCHK(hipStreamWaitEvent(ts, after, 0));
+    HIPCHK(hipMemsetAsync(s->tee_queue.p, 0, 64, ts));
+    HIPCHK(pbsk::launch_publish(t.d_items.p, items, (size_t)n * sizeof(pbsk::XxhItem), ts));  // host -> device by kernel
+    HIPCHK(pbsk::launch_xxh3_items(t.d_items.as<pbsk::XxhItem>(), n, total_blocks, s->tee_states.p, s->tee_sums.as<uint64_t>(),
+                                   t.h_out.as<uint64_t>(), s->tee_queue.as<uint32_t>(), e->num_cus, ts));
+    HIPCHK(hipEventRecord(t.done, ts));
+    if (done_ev) HIPCHK(hipEventRecord(done_ev, ts));
+    t.busy = true;
+    s->tee_pending.push_back((int)(s->tee_next % kTeeLaunches));
+    s->tee_next++;
+    *launched = true;
     return PBSGPU_OK;
 }
 
-// read back the pending window's cut: complete chunks -> shared hash jobs, open tail chunk -> headroom of dev[cur]
-int stream_resolve_pending(pbsgpu_stream *s) {
-    PendingCut &pc = s->pend;
-    if (!pc.active) return PBSGPU_OK;
-    pbsgpu_engine *e = s->eng;
-    Slot &ctx = s->cut[pc.ctx];
-    uint64_t nrec = 0;
-    CHK(cut_finish(e, ctx, &nrec));  // waits for the cut AND the tee queued in front of it
-    pc.active = false;
-    for (size_t i = 0; i < pc.files.size(); ++i) {
-        pc.files[i].xxh3 = s->h_tee_out.as<uint64_t>()[pc.file_out[i]];
-        s->file_out.push_back(pc.files[i]);
-    }
-    pc.files.clear();
-    pc.file_out.clear();
-    uint8_t *const winp = s->dev[pc.buf].as<uint8_t>() + s->headroom - pc.carry;
-    const uint64_t nemit = pc.final ? nrec : (nrec ? nrec - 1 : 0);
-    const pbsgpu_record *hr = ctx.h_recs.as<pbsgpu_record>();
-    if (nemit) {
-        WindowInFlight w;
-        w.buf = pc.buf;
-        w.recs.resize((size_t)nemit);
-        s->descs.resize((size_t)nemit);
-        for (uint64_t i = 0; i < nemit; ++i) {
-            s->descs[(size_t)i] = pbsk::HashDesc{winp + (hr[i].end - hr[i].size), hr[i].size};
-            pbsgpu_record r{};
-            r.end = hr[i].end + pc.base;
-            r.size = hr[i].size;
-            r.segment = pc.section;
-            w.recs[(size_t)i] = r;
-        }
-        CHK(hd_append(e, s->descs.data(), (uint32_t)nemit, &w.job, &w.first));
-        s->inflight.push_back(std::move(w));  // keeps pc.buf busy until its chunks are hashed
-    } else {
-        s->dev_busy[pc.buf] = 0;  // (a carry copy below still reads it: later writes to it follow on the same HIP stream)
-    }
-    if (pc.final || nrec == 0) {
-        s->base = pc.base + pc.total;
-        s->carry = 0;
-    } else {
-        const pbsgpu_record &open = hr[nrec - 1];
-        const uint64_t open_start = open.end - open.size;
-        HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->headroom - open.size, winp + open_start, open.size,
-                              hipMemcpyDeviceToDevice, s->hs));
-        // a window without a complete chunk released its buffer above: the copy must have read it before new pieces
-        // (other HIP stream) may overwrite it. Cannot happen in steady state (a full window holds >= max bytes).
-        if (!nemit) HIPCHK(hipStreamSynchronize(s->hs));
-        s->base = pc.base + open_start;
-        s->carry = open.size;
-    }
-    return PBSGPU_OK;
-}
-
-// A window is complete (or the stream is being cut / finished): resolve the previous window, enqueue this one's cut
-// and tee, continue in a fresh buffer. `final`: the tail chunk is closed too (forced cut), resolved immediately.
-int stream_flush(pbsgpu_stream *s, bool final) {
-    pbsgpu_engine *e = s->eng;
-    CHK(set_device(e));
-    static const bool trace = getenv("PBSGPU_TRACE") != nullptr;
-    const double t0 = trace ? now_ms() : 0;
-    CHK(stream_resolve_pending(s));
-    const double t1 = trace ? now_ms() : 0;
-    const uint64_t total = s->carry + s->fill;
-    PendingCut &pc = s->pend;
-    for (int c = 0; c < 2; ++c)  // the cut and the tee read this window's pieces: device-side wait for the copy streams
-        if (s->piece_used[c]) {
-            HIPCHK(hipStreamWaitEvent(s->hs, s->piece_ev[c], 0));
-            s->piece_used[c] = false;
-        }
-    pc.sugg_rel.clear();
-    CHK(stream_enqueue_tee(s, pc));
-    if (total == 0) {
-        if (!pc.files.empty()) {  // zero-length last pieces only (end_file right after a flush): no cut to ride on
-            HIPCHK(hipStreamSynchronize(s->hs));
-            for (size_t i = 0; i < pc.files.size(); ++i) {
-                pc.files[i].xxh3 = s->h_tee_out.as<uint64_t>()[pc.file_out[i]];
-                s->file_out.push_back(pc.files[i]);
+// ---- pages -------------------------------------------------------------------------------------------------------------------
+// a page to write into: opens the section's ring stream at its first byte; waits (pumping) while the ring has no page or
+// no stream slot free — back-pressure: the ingest outruns the SHA-256 service
+int stream_acquire_page(pbsgpu_stream *s) {
+    pbsgpu_ring *r = s->ring;
+    const double t0 = now_ms();
+    for (int spin = 0;; ++spin) {
+        {
+            std::lock_guard<std::mutex> lk(r->mu);
+            const int st = ring_drain(r);
+            stream_collect(s);
+            if (st != PBSGPU_OK) return s->error = st;
+            if (s->error != PBSGPU_OK) return s->error;
+            bool ok = true;
+            if (!s->cur) {
+                uint32_t rid = 0;
+                const int so = pbsgpu_ring_open(r, &rid);
+                if (so == PBSGPU_OK) {
+                    std::unique_ptr<Section> sec(new (std::nothrow) Section());
+                    if (!sec) return PBSGPU_E_NOMEM;
+                    sec->rid = rid;
+                    sec->index = s->section_index;
+                    sec->base = s->landed + s->inject_total;  // payload position of the next byte to land
+                    r->slots[rid].owner = sec.get();
+                    r->slots[rid].origin = sec->base;
+                    s->cur = sec.get();
+                    s->sections.push_back(std::move(sec));
+                    s->sugg_fwd = 0;
+                } else if (so == PBSGPU_E_BUSY) {
+                    ok = false;  // every slot is taken by sections that are still being hashed
+                } else {
+                    return so;
+                }
             }
-            pc.files.clear();
-            pc.file_out.clear();
+            if (ok) {
+                void *dptr = nullptr;
+                uint64_t cap = 0;
+                const int sr = pbsgpu_ring_reserve(r, s->cur->rid, &dptr, &cap);
+                if (sr == PBSGPU_OK) {
+                    s->have_page = true;
+                    s->page_ptr = static_cast<uint8_t *>(dptr);
+                    s->page_cap = cap;
+                    s->page_fill = 0;
+                    s->page_w0 = s->landed;
+                    s->page_cs = (int)(s->eng->copy_rr.fetch_add(1, std::memory_order_relaxed) % s->eng->copy_streams.size());
+                    return PBSGPU_OK;
+                }
+                if (sr != PBSGPU_E_BUSY) return s->error = sr;
+            }
         }
+        (void)stream_harvest_tees(s, false);
+        if (spin < 64) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (now_ms() - t0 > 120000.0) return s->error = PBSGPU_E_STATE;  // two minutes without a page: the device is gone
+    }
+}
+
+// announced boundaries the current section's ring stream does not know yet, up to `upto` (payload position); ring->mu held
+int stream_forward_suggestions(pbsgpu_stream *s, uint64_t upto) {
+    if (!s->cur) return PBSGPU_OK;
+    while (!s->suggested.empty() && s->suggested.front() <= s->cur->base) {  // at or before the section's first byte: no cut there
+        s->suggested.pop_front();
+        if (s->sugg_fwd) s->sugg_fwd--;
+    }
+    while (s->sugg_fwd < s->suggested.size() && s->suggested[s->sugg_fwd] <= upto) {
+        CHK(pbsgpu_ring_suggest(s->ring, s->cur->rid, s->suggested[s->sugg_fwd] - s->cur->base));
+        s->sugg_fwd++;
+    }
+    return PBSGPU_OK;
+}
+
+// hand the current page (page_fill bytes; every page but a section's last is full) to the ring
+int stream_commit_page(pbsgpu_stream *s, bool final) {
+    pbsgpu_ring *r = s->ring;
+    pbsgpu_engine *e = s->eng;
+    hipEvent_t ev_copy = nullptr, ev_tee = nullptr;
+    const bool bytes = s->have_page && s->page_fill > 0;
+    const bool tee = !s->files.empty();
+    {
+        std::lock_guard<std::mutex> lk(r->mu);
+        if (bytes) CHK(ring_event_get(r, &ev_copy));
+        if (tee) CHK(ring_event_get(r, &ev_tee));
+    }
+    if (bytes) HIPCHK(hipEventRecord(ev_copy, e->copy_streams[(size_t)s->page_cs]));  // behind the page's last copy
+    hipEvent_t dep = ev_copy;
+    if (tee) {
+        bool launched = false;
+        const uint8_t *base = bytes ? s->page_ptr : s->tee_states.as<uint8_t>();
+        const uint64_t w0 = bytes ? s->page_w0 : s->landed, w1 = bytes ? s->page_w0 + s->page_fill : s->landed;
+        CHK(stream_enqueue_tee(s, base, w0, w1, ev_copy, ev_tee, &launched));
+        if (launched && bytes) dep = ev_tee;  // the tee reads the page: the cut (and with it the page's release) waits for it
+    }
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (dep != ev_copy && ev_copy) ring_event_put(r, ev_copy);  // (the tee stream's wait has captured it)
+    if (dep != ev_tee && ev_tee) ring_event_put(r, ev_tee);
+    if (!s->cur) {  // nothing was ever written behind the last cut: there is no ring stream to end
+        if (dep) ring_event_put(r, dep);
         return PBSGPU_OK;
     }
-    // suggested boundaries that can still matter: behind the open chunk's start, inside this window
-    while (!s->suggested.empty() && s->suggested.front() <= s->base) s->suggested.pop_front();
-    // (with a reader-buffer rule in force — pbsgpu_engine_set_suggested_feed — also the announced boundaries up to one
-    // max chunk BEYOND the window: one of them may pre-empt a hash cut inside the window, see Suggested::open_end)
+    const uint64_t end_pos = s->landed + s->inject_total;  // payload position behind the committed bytes
     const uint64_t look = e->sugg_feed.load(std::memory_order_relaxed) > 1 ? (uint64_t)e->cfg.max : 0;
-    for (uint64_t b : s->suggested) {
-        if (b > s->base + total + look) break;
-        pc.sugg_rel.push_back(b - s->base);
+    CHK(stream_forward_suggestions(s, end_pos + look));
+    const int st = ring_commit_dep(r, s->cur->rid, bytes ? s->page_fill : 0, final ? 1 : 0, bytes ? dep : nullptr);
+    if (!bytes && dep) ring_event_put(r, dep);
+    if (st != PBSGPU_OK) return s->error = st;
+    s->have_page = false;
+    s->page_fill = 0;
+    if (final) {
+        s->cur->input_closed = true;
+        s->cur = nullptr;  // (the section stays in `sections` until its last record is out)
     }
-    const uint32_t sidx[2] = {0u, (uint32_t)pc.sugg_rel.size()};
-    SuggestedHost sg{pc.sugg_rel.data(), sidx, s->base, !final};
-    pbsgpu_segment seg{0, total};
-    pc.ctx = s->cut_next;
-    s->cut_next ^= 1;
-    pc.buf = s->cur;
-    pc.base = s->base;
-    pc.carry = s->carry;
-    pc.total = total;
-    pc.section = s->section;
-    pc.final = final;
-    CHK(cut_enqueue(e, s->cut[pc.ctx], s->dev[s->cur].as<uint8_t>() + s->headroom - s->carry, total, &seg, 1,
-                    pc.sugg_rel.empty() ? nullptr : &sg));
-    pc.active = true;
-    s->dev_busy[s->cur] = 1;  // until the cut has been read back (then: until its chunks are hashed, or free)
-    int nb = -1;
-    CHK(stream_free_buffer(s, &nb));
-    s->cur = nb;
-    s->carry = 0;  // known again once the pending cut is resolved
-    s->fill = 0;
-    if (final) CHK(stream_resolve_pending(s));
-    if (trace)
-        fprintf(stderr, "[pbsgpu] stream %p window %.1f MiB: previous cut read back in %.2f ms, enqueue %.2f ms; %zu windows "
-                        "in flight, ring %zu\n", (void *)s, total / 1048576.0, t1 - t0, now_ms() - t1, s->inflight.size(),
-                s->dev.size());
+    const int sd = ring_drain(r);
+    stream_collect(s);
+    if (sd != PBSGPU_OK) return s->error = sd;
     return PBSGPU_OK;
 }
 
-// non-blocking: deliver windows whose hash job has finished
-int stream_reap(pbsgpu_stream *s) {
-    CHK(set_device(s->eng));
-    if (s->pend.active) {  // read the previous window's cut back early if it is done (never wait here)
-        const hipError_t q = hipEventQuery(s->cut[s->pend.ctx].ev[EV_SHA1]);
-        if (q == hipSuccess) CHK(stream_resolve_pending(s));
-        else if (q == hipErrorNotReady) (void)hipGetLastError();
-        else HIPCHK(q);
-    }
-    while (!s->inflight.empty()) {
-        const int st = stream_complete_oldest(s, false);
-        if (st == PBSGPU_E_BUSY) break;
-        CHK(st);
-    }
-    return PBSGPU_OK;
-}
-
-int stream_drain(pbsgpu_stream *s) {
-    CHK(set_device(s->eng));
-    CHK(stream_resolve_pending(s));
-    // The NEWEST window's job first: it is usually still the open job, and nothing launches it while this thread sits in
-    // the older jobs' events below — it then started only after the last of them (traced: +0.34 s on every finish). Now it
-    // takes the first lane that frees up and runs beside the older jobs.
-    if (!s->inflight.empty()) CHK(hd_ensure_launched(s->eng, s->inflight.back().job, true));
-    while (!s->inflight.empty()) CHK(stream_complete_oldest(s, true));
-    return PBSGPU_OK;
-}
-
-// H2D of one staged piece of n bytes (stage[k][0..n)) behind the window's current fill. `written` was advanced when the
-// bytes were accepted; `fill` advances here.
+// H2D of one staged piece of n bytes (stage[k][0..n)) into the stream's pages. `written` was advanced when the bytes were
+// accepted.
 int stream_push_piece(pbsgpu_stream *s, int k, size_t n) {
     pbsgpu_engine *e = s->eng;
-    const int c = (int)(e->copy_rr.fetch_add(1, std::memory_order_relaxed) % e->copy_streams.size());
-    hipStream_t cs = e->copy_streams[(size_t)c];
-    HIPCHK(hipMemcpyAsync(s->dev[s->cur].as<uint8_t>() + s->headroom + s->fill, s->stage[k].p, n, hipMemcpyHostToDevice,
-                          cs));
-    HIPCHK(hipEventRecord(s->stage_ev[k], cs));   // the staging buffer is reusable after this
-    HIPCHK(hipEventRecord(s->piece_ev[c], cs));   // ... and the window's cut waits for the last piece per copy stream
-    s->piece_used[c] = true;
+    const uint8_t *src = s->stage[k].as<uint8_t>();
+    size_t off = 0;
     s->stage_idx = (k + 1) % kStreamStages;
-    s->fill += n;
-    if (s->fill == s->window) CHK(stream_flush(s, false));
+    while (off < n) {
+        if (!s->have_page) CHK(stream_acquire_page(s));
+        const size_t m = (size_t)std::min<uint64_t>(n - off, s->page_cap - s->page_fill);
+        hipStream_t cs = e->copy_streams[(size_t)s->page_cs];
+        HIPCHK(hipMemcpyAsync(s->page_ptr + s->page_fill, src + off, m, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipEventRecord(s->stage_ev[k][s->page_cs], cs));  // the staging buffer is reusable after this
+        s->stage_used[k][s->page_cs] = true;
+        s->page_fill += m;
+        s->landed += m;
+        off += m;
+        if (s->page_fill == s->page_cap) CHK(stream_commit_page(s, false));
+    }
     return PBSGPU_OK;
 }
 
@@ -722,6 +547,40 @@ int stream_push_staged(pbsgpu_stream *s) {
     const size_t n = s->stage_fill;
     s->stage_fill = 0;
     return stream_push_piece(s, s->stage_idx, n);
+}
+
+// staging buffer k is about to be written by the host: its previous H2D copies have drained
+int stream_stage_ready(pbsgpu_stream *s, int k) {
+    CHK(s->stage[k].ensure(kStreamStage));
+    for (int c = 0; c < 2; ++c)
+        if (s->stage_used[k][c]) {
+            HIPCHK(hipEventSynchronize(s->stage_ev[k][c]));
+            s->stage_used[k][c] = false;
+        }
+    return PBSGPU_OK;
+}
+
+// forced cut / end of input: the section's last (short) page goes out with the final flag
+int stream_end_section(pbsgpu_stream *s) {
+    CHK(stream_push_staged(s));
+    if (!s->cur && !s->have_page && s->files.empty()) return PBSGPU_OK;
+    return stream_commit_page(s, true);
+}
+
+bool stream_all_delivered(const pbsgpu_stream *s) { return s->sections.empty(); }
+
+// wait until every record of every section is in `out` (the serial SHA-256 chain of the last chunks: up to ~0.46 s)
+int stream_drain(pbsgpu_stream *s) {
+    const double t0 = now_ms();
+    for (int spin = 0;; ++spin) {
+        const int st = stream_pump(s);
+        if (st != PBSGPU_OK) return st;
+        if (stream_all_delivered(s)) break;
+        if (spin < 64) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (now_ms() - t0 > 120000.0) return s->error = PBSGPU_E_STATE;
+    }
+    return stream_harvest_tees(s, true);
 }
 
 }  // namespace
@@ -758,80 +617,45 @@ void chunker_push_tail(pbsgpu_chunker *c, const uint8_t *p, size_t n) {
 
 }  // namespace
 
+
 extern "C" {
 
 static pbsgpu_stream *stream_unpark(pbsgpu_engine *e, uint64_t window_bytes);  // contexts of closed streams are recycled, see below
-
-static size_t stream_ring_limit(size_t devcap) {  // window buffers per stream (PBSGPU_STREAM_RING_GIB, default 32 GiB)
-    size_t budget_gib = 32;
-    if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) budget_gib = (size_t)std::max(1L, atol(v));
-    const size_t nb = (size_t)((budget_gib << 30) / devcap);
-    return std::min<size_t>(std::max<size_t>(nb, 4), 256);
-}
+void pbsgpu_stream_destroy(pbsgpu_stream *s);
 
 int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream **out) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = nullptr;
-    if (window_bytes == 0) window_bytes = 256ull << 20;
-    if (window_bytes < e->cfg.max) window_bytes = e->cfg.max;
-    if (pbsgpu_stream *parked = stream_unpark(e, window_bytes)) {
-        parked->max_bufs = stream_ring_limit(parked->devcap);  // (a previous life under memory pressure may have lowered it)
-        int st = set_device(e);
-        if (st == PBSGPU_OK) st = stream_buffer_ensure(parked, parked->dev[0]);
-        if (st != PBSGPU_OK) {
-            pbsgpu_stream_destroy(parked);
-            return st;
-        }
+    (void)window_bytes;  // (rounds 1-3: bytes per device window; the engine's page ring has ONE page size for all its streams)
+    pbsgpu_ring *ring = nullptr;
+    CHK(engine_ring_get(e, &ring));
+    if (pbsgpu_stream *parked = stream_unpark(e, 0)) {
+        parked->ring = ring;
         *out = parked;
         return PBSGPU_OK;
     }
     pbsgpu_stream *s = new (std::nothrow) pbsgpu_stream();
-    if (!s) return PBSGPU_E_NOMEM;
+    if (!s) {
+        engine_ring_put(e);
+        return PBSGPU_E_NOMEM;
+    }
     engine_ref(e);
     s->eng = e;
-    s->window = window_bytes;
-    s->headroom = ((uint64_t)e->cfg.max + 255) & ~255ull;
-    s->devcap = (size_t)window_bytes + (size_t)s->headroom + 256;
-    // Ring limit. Chunks of up to 16 MiB hash for ~0.45 s, so a stream needs (ingest rate x ~0.6 s) of windows in
-    // flight: 32 GiB carries ~50 GiB/s, the H2D rate (16 GiB held one fast writer at 26 GiB/s). Buffers are allocated on
-    // demand — a slow producer never grows its ring — and a failed allocation is back-pressure, not an error.
-    s->max_bufs = stream_ring_limit(s->devcap);
+    s->ring = ring;
     int st = set_device(e);
-    hipStream_t shared = nullptr;
-    if (st == PBSGPU_OK) {  // opt-in: engine-wide cut streams (engine_internal.h, cut_streams)
-        static const int nshared = []() {
-            const char *v = getenv("PBSGPU_SHARED_CUT_STREAMS");
-            return v ? std::min(16, std::max(0, atoi(v))) : 0;
-        }();
-        if (nshared > 0) {
-            std::lock_guard<std::mutex> lk(e->pool_mu);
-            while ((int)e->cut_streams.size() < nshared && st == PBSGPU_OK) {
-                hipStream_t cs = nullptr;
-                if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
-                else e->cut_streams.push_back(cs);
-            }
-            if (st == PBSGPU_OK) shared = e->cut_streams[e->cut_rr++ % e->cut_streams.size()];
-        }
-    }
-    if (st == PBSGPU_OK) st = s->cut[0].init(shared);
-    if (st == PBSGPU_OK) st = s->cut[1].init(s->cut[0].stream);
-    s->hs = s->cut[0].stream;
-    for (auto &ev : s->piece_ev)
-        if (st == PBSGPU_OK && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
-    // everything a window can need is allocated here: a regrow later (hipFree / hipHostFree) would wait for the whole
-    // device, i.e. for other windows' running hash jobs
-    for (auto &c : s->cut) {
-        c.mapped_ctrl = true;
-        if (st == PBSGPU_OK) st = presize_cut(e, c, s->devcap);
-    }
-    if (st == PBSGPU_OK) {
-        s->dev.resize(2);
-        s->dev_busy.assign(2, 0);
-        st = stream_buffer_ensure(s, s->dev[0]);
-    }
-    for (int i = 0; i < kStreamStages && st == PBSGPU_OK; ++i)
-        if (hipEventCreateWithFlags(&s->stage_ev[i], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
+    // everything a stream can need is allocated here or grows by doubling: a free later (hipFree / hipHostFree) would
+    // wait for the whole device, and is parked anyway while the ring's service runs (engine_internal.h: dev_free)
+    for (int k = 0; k < kStreamStages && st == PBSGPU_OK; ++k)
+        for (int c = 0; c < 2 && st == PBSGPU_OK; ++c)
+            if (hipEventCreateWithFlags(&s->stage_ev[k][c], hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
+    for (auto &t : s->tee)
+        if (st == PBSGPU_OK && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) st = PBSGPU_E_HIP;
+    if (st == PBSGPU_OK) st = s->tee_states.ensure(2 * pbsk::xxh3_state_bytes() + 256);
+    if (st == PBSGPU_OK) st = s->tee_queue.ensure(64);
+    if (st == PBSGPU_OK) st = s->tee_sums.ensure((size_t)(ring->page_bytes / 1024 + 64) * 64);
+    s->tee_stream = e->tee_streams[e->tee_rr.fetch_add(1, std::memory_order_relaxed) % e->tee_streams.size()];
     if (st != PBSGPU_OK) {
+        s->error = st;  // (never parked: see pbsgpu_stream_destroy)
         pbsgpu_stream_destroy(s);
         return st;
     }
@@ -840,58 +664,57 @@ int pbsgpu_stream_create(pbsgpu_engine *e, uint64_t window_bytes, pbsgpu_stream 
 }
 
 // ---- stream contexts are recycled --------------------------------------------------------------------------------
-// Everything a stream owns besides its window buffers (two cut contexts with their device tables and mapped pinned
-// result buffers, 3 x 32 MiB pinned staging, the tee's buffers, events, one HIP stream) is parked in the engine when the
-// stream closes and handed to the engine's next stream of the same window size. Freeing it (hipFree / hipHostFree) waits
-// for the whole device — for a writer that closes archive k while archive k+1 is already being hashed that is a stall
-// of up to one chunk chain (0.45 s) on the thread that should be writing.
+// What a stream owns (3 x 32 MiB pinned staging, the tee's buffers, a dozen events) is parked in the engine when the
+// stream closes and handed to the engine's next stream: allocating 100 MB of pinned memory costs tens of milliseconds per
+// archive, and freeing it (hipFree / hipHostFree wait for the whole device) would stall a writer that closes archive k
+// while archive k+1 is already being hashed. Only contexts that were fully created and never saw an error are parked.
 static void stream_free_context(pbsgpu_stream *s) {
-    for (auto &ev : s->piece_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    s->cut[1].destroy();
-    s->cut[0].destroy();
-    for (auto &b : s->dev) b.release();
     for (auto &b : s->stage) b.release();
+    for (auto &row : s->stage_ev)
+        for (auto &ev : row)
+            if (ev) (void)hipEventDestroy(ev);
+    for (auto &t : s->tee) {
+        t.h_items.release();
+        t.h_out.release();
+        t.d_items.release();
+        if (t.done) (void)hipEventDestroy(t.done);
+    }
     s->tee_states.release();
     s->tee_queue.release();
-    s->tee_items.release();
     s->tee_sums.release();
-    s->h_tee_items.release();
-    s->h_tee_out.release();
-    for (auto &ev : s->stage_ev)
-        if (ev) (void)hipEventDestroy(ev);
 }
 
 // back to the state pbsgpu_stream_create leaves a stream in (the resources stay)
 static void stream_reset_state(pbsgpu_stream *s) {
-    s->dev.clear();
-    s->dev.resize(2);
-    s->dev_busy.assign(2, 0);
-    s->cur = 0;
-    s->carry = 0;
-    s->fill = 0;
-    s->cut_next = 0;
-    s->piece_used[0] = s->piece_used[1] = false;
-    s->pend = PendingCut{};
+    for (auto &row : s->stage_used)
+        for (auto &u : row) u = false;
     s->stage_idx = 0;
     s->stage_fill = 0;
     s->reserved = -1;
-    s->base = 0;
-    s->written = 0;
-    s->inject_total = 0;
-    s->section = 0;
-    s->finished = false;
-    s->drained = false;
+    s->have_page = false;
+    s->page_ptr = nullptr;
+    s->page_fill = s->page_cap = s->page_w0 = 0;
+    s->sections.clear();
+    s->cur = nullptr;
+    s->section_index = 0;
+    s->written = s->inject_total = s->landed = 0;
+    s->finished = s->drained = false;
+    s->error = PBSGPU_OK;
     s->suggested.clear();
-    s->inflight.clear();
+    s->sugg_fwd = 0;
     s->out.clear();
-    s->descs.clear();
     s->files.clear();
     s->next_file = 0;
     s->n_stateful = 0;
     s->file_open = false;
     s->entry_left = 0;
     s->in_entry = false;
+    s->tee_pending.clear();
+    for (auto &t : s->tee) {
+        t.busy = false;
+        t.files.clear();
+        t.out_slot.clear();
+    }
     s->file_out.clear();
 }
 
@@ -902,22 +725,21 @@ static bool stream_park(pbsgpu_engine *e, pbsgpu_stream *s) {
     }();
     stream_reset_state(s);
     s->eng = nullptr;  // (a parked context holds no reference: the engine owns it)
+    s->ring = nullptr;
     std::lock_guard<std::mutex> lk(e->pool_mu);
     if (e->destroyed || e->stream_pool.size() >= limit) return false;
     e->stream_pool.push_back(s);
     return true;
 }
 
-static pbsgpu_stream *stream_unpark(pbsgpu_engine *e, uint64_t window_bytes) {
+static pbsgpu_stream *stream_unpark(pbsgpu_engine *e, uint64_t) {
     pbsgpu_stream *s = nullptr;
     {
         std::lock_guard<std::mutex> lk(e->pool_mu);
-        for (size_t i = 0; i < e->stream_pool.size(); ++i)
-            if (e->stream_pool[i]->window == window_bytes) {
-                s = e->stream_pool[i];
-                e->stream_pool.erase(e->stream_pool.begin() + (long)i);
-                break;
-            }
+        if (!e->stream_pool.empty()) {
+            s = e->stream_pool.back();
+            e->stream_pool.pop_back();
+        }
     }
     if (!s) return nullptr;
     engine_ref(e);
@@ -938,6 +760,14 @@ void stream_pool_release(pbsgpu_engine *e) {
         delete s;
     }
 }
+
+// caller holds e->sring_mu, or is the engine's teardown
+void engine_ring_release(pbsgpu_engine *e) {
+    if (e->sring) {
+        pbsgpu_ring_destroy(e->sring);
+        e->sring = nullptr;
+    }
+}
 }  // namespace pbse
 extern "C" {
 
@@ -946,33 +776,40 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
     pbsgpu_engine *e = s->eng;
     if (e) {
         (void)hipSetDevice(e->device);
-        (void)stream_drain(s);
-        while (!s->inflight.empty()) {  // drain failed (HIP error): drop the references so the jobs can be reused
-            s->inflight.front().job->refs.fetch_sub(1);
-            s->inflight.pop_front();
+        bool healthy = s->error == PBSGPU_OK;
+        if (s->ring) {
+            // An unfinished stream still has to END its ring streams (their pages and slots only come back through a final
+            // round), and every section has to hand out its last record before its slot is free: the same wait as finish.
+            if (healthy && !s->finished) {
+                s->file_open = false;
+                s->in_entry = false;
+                s->reserved = -1;
+                healthy = stream_end_section(s) == PBSGPU_OK;
+                s->finished = true;
+            }
+            if (healthy) healthy = stream_drain(s) == PBSGPU_OK;
+            if (!healthy) {  // a failed section / ring: drop what the ring still routes to this stream
+                std::lock_guard<std::mutex> lk(s->ring->mu);
+                for (auto &sec : s->sections)
+                    if (!sec->ring_done && sec->rid < s->ring->slots.size() && s->ring->slots[sec->rid].owner == sec.get()) {
+                        StreamSlot &sl = s->ring->slots[sec->rid];
+                        sl.owner = nullptr;
+                        if (!sl.final_committed && !sl.failed) (void)ring_commit_dep(s->ring, sec->rid, 0, 1, nullptr);
+                        // (the slot stays open until its ring stream has ended; the next drain by any stream of the
+                        // engine discards what it still delivers and closes it — ring_drain)
+                    }
+            }
+            for (int k = 0; k < kStreamStages; ++k)
+                for (int c = 0; c < 2; ++c)
+                    if (s->stage_used[k][c] && s->stage_ev[k][c]) (void)hipEventSynchronize(s->stage_ev[k][c]);  // copies out of our staging
+            (void)stream_harvest_tees(s, true);
+            {   // the last stream of the engine has gone idle: stop the ring's service now rather than after the idle timer
+                std::lock_guard<std::mutex> lk(s->ring->mu);
+                if (ring_idle(s->ring)) (void)ring_park(s->ring);
+            }
+            engine_ring_put(e);
         }
-        for (int k = 0; k < kStreamStages; ++k)
-            if (s->stage_ev[k]) (void)hipEventSynchronize(s->stage_ev[k]);  // pieces still copying from our staging
-        if (s->hs) (void)hipStreamSynchronize(s->hs);
-        {   // window buffers go back to the engine for the next stream (hipFree waits for the whole device, i.e. for other
-            // streams' running hash jobs). The pool is bounded in BYTES (one default ring, PBSGPU_STREAM_POOL_GIB): a
-            // long-lived engine that opens one stream per backup job must not pin tens of GiB of HBM for ever; what does
-            // not fit is freed below. pbsgpu_engine_trim() empties the pool on request.
-            static const uint64_t pool_limit = []() -> uint64_t {
-                const char *v = getenv("PBSGPU_STREAM_POOL_GIB");
-                return (uint64_t)(v ? std::max(0L, atol(v)) : 32L) << 30;
-            }();
-            std::lock_guard<std::mutex> lk(e->pool_mu);
-            uint64_t held = 0;
-            for (auto &b : e->win_pool) held += b.cap;
-            for (auto &b : s->dev)
-                if (b.p && held + b.cap <= pool_limit) {
-                    held += b.cap;
-                    e->win_pool.push_back(std::move(b));
-                }
-        }
-        for (auto &b : s->dev) b.release();
-        if (stream_park(e, s)) {  // the context waits for the engine's next stream: nothing else is freed, nothing waits
+        if (healthy && stream_park(e, s)) {  // the context waits for the engine's next stream: nothing is freed, nothing waits
             engine_unref(e);
             return;
         }
@@ -985,28 +822,24 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
 int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
     if (!s || (!data && len)) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
+    if (s->error != PBSGPU_OK) return s->error;
     if (s->in_entry && len > s->entry_left) return PBSGPU_E_INVALID;  // more bytes than the entry header announced
     if (len) CHK(set_device(s->eng));
     const uint8_t *p = static_cast<const uint8_t *>(data);
     while (len) {
-        // caller bytes -> library-owned pinned staging -> device window (async). Writes are COALESCED in the staging
-        // buffer (an io.Copy feeds 32 KiB at a time, a payload header is 16 bytes): one H2D piece per 32 MiB or per
-        // window edge, not per call. The memcpy runs on the caller's thread with no lock held, so several streams copy
-        // in parallel.
+        // caller bytes -> library-owned pinned staging -> device page (async). Writes are COALESCED in the staging
+        // buffer (an io.Copy feeds 32 KiB at a time, a payload header is 16 bytes): one H2D piece per 32 MiB, not per
+        // call. The memcpy runs on the caller's thread with no lock held, so several streams copy in parallel.
         const int k = s->stage_idx;
-        if (s->stage_fill == 0) {
-            CHK(s->stage[k].ensure(kStreamStage));
-            HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
-        }
-        size_t n = std::min(len, kStreamStage - s->stage_fill);
-        n = (size_t)std::min<uint64_t>(n, s->window - s->fill - s->stage_fill);
+        if (s->stage_fill == 0) CHK(stream_stage_ready(s, k));
+        const size_t n = std::min(len, kStreamStage - s->stage_fill);
         parallel_memcpy(s->stage[k].as<uint8_t>() + s->stage_fill, p, n);
         s->stage_fill += n;
         s->written += n;
         if (s->in_entry) s->entry_left -= std::min<uint64_t>(s->entry_left, n);
         p += n;
         len -= n;
-        if (s->stage_fill == kStreamStage || s->fill + s->stage_fill == s->window) CHK(stream_push_staged(s));
+        if (s->stage_fill == kStreamStage) CHK(stream_push_staged(s));
     }
     return PBSGPU_OK;
 }
@@ -1014,14 +847,14 @@ int pbsgpu_stream_write(pbsgpu_stream *s, const void *data, size_t len) {
 int pbsgpu_stream_reserve(pbsgpu_stream *s, void **buf, size_t *cap) {
     if (!s || !buf || !cap) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0) return PBSGPU_E_STATE;
+    if (s->error != PBSGPU_OK) return s->error;
     CHK(set_device(s->eng));
     CHK(stream_push_staged(s));  // bytes gathered by earlier small writes go first; the reserved buffer starts empty
     const int k = s->stage_idx;
-    CHK(s->stage[k].ensure(kStreamStage));
-    HIPCHK(hipEventSynchronize(s->stage_ev[k]));  // its previous H2D copy has drained
+    CHK(stream_stage_ready(s, k));
     s->reserved = k;
     *buf = s->stage[k].p;
-    uint64_t room = std::min<uint64_t>(kStreamStage, s->window - s->fill);
+    uint64_t room = kStreamStage;
     if (s->in_entry) room = std::min(room, s->entry_left);
     *cap = (size_t)room;
     return PBSGPU_OK;
@@ -1031,7 +864,7 @@ int pbsgpu_stream_commit(pbsgpu_stream *s, size_t len) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->reserved < 0) return PBSGPU_E_STATE;
     const int k = s->reserved;
-    if (len > (size_t)std::min<uint64_t>(kStreamStage, s->window - s->fill)) return PBSGPU_E_INVALID;
+    if (len > kStreamStage) return PBSGPU_E_INVALID;
     if (s->in_entry && len > s->entry_left) return PBSGPU_E_INVALID;
     s->reserved = -1;
     if (len == 0) return PBSGPU_OK;
@@ -1045,7 +878,7 @@ int pbsgpu_stream_suggest(pbsgpu_stream *s, uint64_t offset) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished) return PBSGPU_E_STATE;
     if (!s->suggested.empty() && offset < s->suggested.back()) return PBSGPU_E_INVALID;  // ascending, like the channel
-    s->suggested.push_back(offset);  // boundaries at or before the open chunk's start are dropped at the next flush
+    s->suggested.push_back(offset);  // forwarded to the section it falls into when that section's next page is committed
     return PBSGPU_OK;
 }
 
@@ -1074,6 +907,10 @@ int pbsgpu_stream_end_file(pbsgpu_stream *s, uint64_t *index) {
 
 int pbsgpu_stream_poll_files(pbsgpu_stream *s, pbsgpu_file_hash *out, uint64_t cap, uint64_t *n) {
     if (!s || !n || (!out && cap)) return PBSGPU_E_INVALID;
+    if (s->eng) {
+        CHK(set_device(s->eng));
+        CHK(stream_harvest_tees(s, false));
+    }
     uint64_t k = 0;
     while (k < cap && !s->file_out.empty()) {
         out[k++] = s->file_out.front();
@@ -1126,22 +963,21 @@ int pbsgpu_stream_end_entry(pbsgpu_stream *s, uint64_t *file_index) {
 int pbsgpu_stream_cut(pbsgpu_stream *s, uint64_t inject_bytes) {
     if (!s) return PBSGPU_E_INVALID;
     if (s->finished || s->reserved >= 0 || s->in_entry) return PBSGPU_E_STATE;
+    if (s->error != PBSGPU_OK) return s->error;
     CHK(set_device(s->eng));
-    CHK(stream_push_staged(s));
-    CHK(stream_flush(s, true));
-    s->base += inject_bytes;
+    CHK(stream_end_section(s));  // the open chunk is closed where the stream stands; the next byte opens a new ring stream
     s->inject_total += inject_bytes;
-    s->section++;
+    s->section_index++;
     return PBSGPU_OK;
 }
 
-// close the input: the tail chunk is cut, every chunk is with the hash jobs; nothing here waits for a hash
+// close the input: the tail chunk is cut, every chunk is with the SHA-256 service; nothing here waits for a hash
 static int stream_close_input(pbsgpu_stream *s) {
     if (s->finished) return PBSGPU_OK;
     if (s->reserved >= 0 || s->file_open) return PBSGPU_E_STATE;
+    if (s->error != PBSGPU_OK) return s->error;
     CHK(set_device(s->eng));
-    CHK(stream_push_staged(s));
-    CHK(stream_flush(s, true));
+    CHK(stream_end_section(s));
     s->finished = true;
     return PBSGPU_OK;
 }
@@ -1165,8 +1001,10 @@ int pbsgpu_stream_done(pbsgpu_stream *s, int *done) {
     *done = 0;
     if (!s->finished) return PBSGPU_OK;
     if (!s->drained) {
-        CHK(stream_reap(s));
-        s->drained = !s->pend.active && s->inflight.empty();
+        CHK(set_device(s->eng));
+        CHK(stream_pump(s));
+        CHK(stream_harvest_tees(s, false));
+        s->drained = stream_all_delivered(s) && s->tee_pending.empty();
     }
     *done = s->drained ? 1 : 0;
     return PBSGPU_OK;
@@ -1174,14 +1012,18 @@ int pbsgpu_stream_done(pbsgpu_stream *s, int *done) {
 
 int pbsgpu_stream_poll(pbsgpu_stream *s, pbsgpu_record *out, uint64_t cap, uint64_t *n) {
     if (!s || !n || (!out && cap)) return PBSGPU_E_INVALID;
-    CHK(stream_reap(s));
+    int st = PBSGPU_OK;
+    if (s->eng && s->ring && !s->drained) {
+        CHK(set_device(s->eng));
+        st = stream_pump(s);
+    }
     uint64_t k = 0;
     while (k < cap && !s->out.empty()) {
         out[k++] = s->out.front();
         s->out.pop_front();
     }
     *n = k;
-    return PBSGPU_OK;
+    return (k == 0) ? st : PBSGPU_OK;  // what was cut before a failure is still delivered; the error follows
 }
 
 int pbsgpu_stream_position(const pbsgpu_stream *s, uint64_t *position) {

@@ -514,6 +514,14 @@ class PageRing:
     def quiesce(self) -> None:
         check(self._L.pbsgpu_ring_quiesce(self._h), "ring_quiesce")
 
+    def park(self) -> None:
+        """Stop the service behind everything enqueued WITHOUT waiting for it (the next pump starts a new one)."""
+        check(self._L.pbsgpu_ring_park(self._h), "ring_park")
+
+    def suggest(self, stream: int, offset: int) -> None:
+        """Suggested boundary at `offset` bytes from the stream's start (ascending, ahead of the bytes around it)."""
+        check(self._L.pbsgpu_ring_suggest(self._h, stream, int(offset)), "ring_suggest")
+
     def stats(self) -> dict:
         st = _lib.RingStats()
         check(self._L.pbsgpu_ring_get_stats(self._h, C.byref(st)), "ring_get_stats")
