@@ -432,7 +432,7 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.pending = pending.as<uint32_t>();
     q.free_fifo = free_fifo.as<unsigned long long>();
     q.free_mask = nfree - 1;
-    double idle_s = 20.0;
+    double idle_s = idle_timeout_s > 0 ? idle_timeout_s : 20.0;
     if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.05, atof(v));
     q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
     q.heartbeat = heartbeat.as<uint32_t>();

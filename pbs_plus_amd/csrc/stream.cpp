@@ -236,6 +236,8 @@ int engine_ring_get(pbsgpu_engine *e, pbsgpu_ring **out) {
         // nothing in flight anywhere for 2 ms: stop the service (its CUs, and hipFree / device-wide syncs of the process, come
         // back); the next page starts it again
         if (r->autopark_ms == 0) r->autopark_ms = 2.0;
+        // ... and a writer that simply stops calling (a blocking read) gives them back after 2 s without any call at all
+        r->idle_timeout_s = 2.0;
         e->sring = r;
     }
     e->sring_users++;
@@ -466,6 +468,12 @@ int stream_forward_suggestions(pbsgpu_stream *s, uint64_t upto) {
         s->suggested.pop_front();
         if (s->sugg_fwd) s->sugg_fwd--;
     }
+    // ... and what the ring already knows and the stream has left more than a maximum chunk behind
+    const uint64_t behind = s->landed + s->inject_total;
+    while (s->sugg_fwd > 0 && !s->suggested.empty() && s->suggested.front() + s->eng->cfg.max < behind) {
+        s->suggested.pop_front();
+        s->sugg_fwd--;
+    }
     while (s->sugg_fwd < s->suggested.size() && s->suggested[s->sugg_fwd] <= upto) {
         CHK(pbsgpu_ring_suggest(s->ring, s->cur->rid, s->suggested[s->sugg_fwd] - s->cur->base));
         s->sugg_fwd++;
@@ -569,6 +577,14 @@ int stream_end_section(pbsgpu_stream *s) {
 
 bool stream_all_delivered(const pbsgpu_stream *s) { return s->sections.empty(); }
 
+// this stream has nothing in the ring any more: if nobody else has either, stop the ring's service NOW (not after the idle
+// timer) — a caller that synchronises the device or frees memory right after finish() must not wait for a kernel that
+// only ends on request
+void stream_maybe_park(pbsgpu_stream *s) {
+    std::lock_guard<std::mutex> lk(s->ring->mu);
+    if (ring_idle(s->ring)) (void)ring_park(s->ring);
+}
+
 // wait until every record of every section is in `out` (the serial SHA-256 chain of the last chunks: up to ~0.46 s)
 int stream_drain(pbsgpu_stream *s) {
     const double t0 = now_ms();
@@ -580,7 +596,9 @@ int stream_drain(pbsgpu_stream *s) {
         else std::this_thread::sleep_for(std::chrono::microseconds(50));
         if (now_ms() - t0 > 120000.0) return s->error = PBSGPU_E_STATE;
     }
-    return stream_harvest_tees(s, true);
+    CHK(stream_harvest_tees(s, true));
+    stream_maybe_park(s);
+    return PBSGPU_OK;
 }
 
 }  // namespace
@@ -803,10 +821,7 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
                 for (int c = 0; c < 2; ++c)
                     if (s->stage_used[k][c] && s->stage_ev[k][c]) (void)hipEventSynchronize(s->stage_ev[k][c]);  // copies out of our staging
             (void)stream_harvest_tees(s, true);
-            {   // the last stream of the engine has gone idle: stop the ring's service now rather than after the idle timer
-                std::lock_guard<std::mutex> lk(s->ring->mu);
-                if (ring_idle(s->ring)) (void)ring_park(s->ring);
-            }
+            stream_maybe_park(s);
             engine_ring_put(e);
         }
         if (healthy && stream_park(e, s)) {  // the context waits for the engine's next stream: nothing is freed, nothing waits
@@ -1005,6 +1020,7 @@ int pbsgpu_stream_done(pbsgpu_stream *s, int *done) {
         CHK(stream_pump(s));
         CHK(stream_harvest_tees(s, false));
         s->drained = stream_all_delivered(s) && s->tee_pending.empty();
+        if (s->drained) stream_maybe_park(s);
     }
     *done = s->drained ? 1 : 0;
     return PBSGPU_OK;

@@ -183,15 +183,19 @@ def test_ring_reserve_commit_external_producer_and_service_restart(gpu_lib, O):
     eng.close()
 
 
-def test_ring_dense_candidates_fail_loudly_not_silently(gpu_lib, O):
+def test_ring_dense_candidates_fail_their_own_stream_only(gpu_lib, O):
     """64-byte periodic bytes make every position of a scan tile a candidate: more than the ring's per-tile capacity.
     The batch path re-runs such a batch with a larger capacity; a ring round cannot be re-run (later rounds already
-    depend on its result), so the ring must report PBSGPU_E_DENSITY — never hand out a wrong or partial record list."""
+    depend on its result). The stream that owns the overflowing page fails — PBSGPU_E_DENSITY from its own calls, never a
+    wrong or partial record list passed off as complete — and NOTHING else does: three ordinary streams that share the
+    ring (and the rounds) with it come out bit-exact, all pages come back, and the slot can be reused."""
+    import time
+
     from pbs_plus_amd import PageRing, PbsGpuError, _lib
 
     avg = 4096
     eng = _engine(avg)
-    ring = PageRing(eng, arena_bytes=24 * (65536 + 256), **SMALL)
+    ring = PageRing(eng, arena_bytes=40 * (65536 + 256), **dict(SMALL, max_streams=6))
     cfg = O.new_config(avg)
     pat = None
     rng = np.random.default_rng(5)
@@ -202,24 +206,53 @@ def test_ring_dense_candidates_fail_loudly_not_silently(gpu_lib, O):
             break
     if pat is None:
         pytest.skip("no dense pattern found")
-    data = np.tile(pat, 2 * 65536 // 64)
-    sid = ring.open()
+    good = [O.fill(5 * 65536 + 1234 * i, 70 + i, i % 4) for i in range(3)]
+    bad = np.concatenate([O.fill(65536, 9, 0), np.tile(pat, 3 * 65536 // 64)])   # an ordinary first page, then the crafted period
+    datas = good + [bad]
+    sids = [ring.open() for _ in datas]
+    offs = [0] * len(datas)
+    got = [[] for _ in datas]
+    done = [False] * len(datas)
+    failed = [False] * len(datas)
     L = eng._L
+    t0 = time.time()
+    while not all(done) and time.time() - t0 < 60:
+        for i, (sid, d) in enumerate(zip(sids, datas)):
+            if done[i]:
+                continue
+            try:
+                if offs[i] < d.size:
+                    r = ring.reserve(sid)
+                    if r is not None:
+                        n = min(65536, d.size - offs[i])
+                        assert L.pbsgpu_memcpy_h2d(eng._h, r[0], d[offs[i]:offs[i] + n].ctypes.data, n) == 0
+                        offs[i] += n
+                        ring.commit(sid, n, final=(offs[i] == d.size))
+                recs, fin = ring.poll(sid)
+                got[i].append(recs.copy())
+                done[i] = fin
+            except PbsGpuError as exc:
+                assert exc.status == _lib.E_DENSITY and i == 3, (i, exc)
+                failed[i] = done[i] = True
+        ring.pump()
+    assert all(done) and failed == [False, False, False, True], (done, failed)
+    for i in range(3):
+        _assert_same(np.concatenate(got[i]), O.chunk_and_digest(cfg, good[i], [(0, good[i].size)]), i)
+        ring.close_stream(sids[i])
+    # what the failed stream delivered before its failure is a correct PREFIX of its record list
+    pre = np.concatenate(got[3]) if got[3] else np.zeros(0, dtype=_lib.RECORD_DTYPE)
+    want = O.chunk_and_digest(cfg, bad, [(0, bad.size)])
+    assert pre.size < want.size and np.array_equal(pre["end"], want["end"][:pre.size])
+    assert np.array_equal(pre["digest"], want["digest"][:pre.size])
     with pytest.raises(PbsGpuError) as ei:
-        import time
-        t0 = time.time()
-        off = 0
-        while time.time() - t0 < 30:
-            if off < data.size:
-                r = ring.reserve(sid)
-                if r is not None:
-                    assert L.pbsgpu_memcpy_h2d(eng._h, r[0], data[off:off + 65536].ctypes.data, 65536) == 0
-                    off += 65536
-                    ring.commit(sid, 65536, final=(off == data.size))
-            ring.pump()
-            recs, fin = ring.poll(sid)
-            assert not fin, "a stream whose round overflowed must not complete"
+        ring.close_stream(sids[3])                            # releases the slot, reports the incomplete list
     assert ei.value.status == _lib.E_DENSITY
+    # the ring is healthy: the slot and the pages serve the next stream
+    res = ring.ingest_synthetic([(123, 0, 4 * 65536 + 99)], timeout_s=30.0)
+    _assert_same(res[0], _oracle_records(O, avg, [(123, 0, 4 * 65536 + 99)])[0], "after the failure")
+    ring.quiesce()
+    st = ring.stats()
+    assert st["pages_free"] == st["pages_total"], st
     ring.close()
     eng.close()
 
@@ -297,13 +330,16 @@ def test_ring_randomized_programs(gpu_lib, O, seed, monkeypatch):
     eng.close()
 
 
-def test_ring_service_gives_up_without_a_heartbeat_and_the_ring_fails_loudly(gpu_lib, O, monkeypatch):
-    """The service is a kernel that only ends on request: if the host stops calling the ring (died, or paused without
-    quiesce) its idle waves give up after PBSGPU_RING_IDLE_TIMEOUT_S — and the ring must then REPORT it (PBSGPU_E_STATE)
-    instead of waiting forever for chunks nobody hashes. A host that keeps calling while it has nothing to feed is fine."""
+def test_ring_survives_a_silent_host(gpu_lib, O, monkeypatch):
+    """The service is a kernel that only ends on request, and the goroutine that drives a ring may sit in a blocking tape
+    read for as long as it likes (internal/tapeio/converter.go:672-680). A host that keeps calling while it has nothing
+    to feed keeps the service; a host that does not call AT ALL for PBSGPU_RING_IDLE_TIMEOUT_S finds the service gone —
+    it stopped on its own after a handshake that guarantees no chunk is left behind — and the ring healthy: the next pump
+    starts the service again and the stream finishes bit-exact. Twice in a row, once with pages of the stream waiting in
+    an open chunk across the silence, and parking by hand in between."""
     import time
 
-    from pbs_plus_amd import PageRing, PbsGpuError, _lib
+    from pbs_plus_amd import PageRing
 
     monkeypatch.setenv("PBSGPU_RING_IDLE_TIMEOUT_S", "1")
     eng = _engine(4096)
@@ -316,27 +352,36 @@ def test_ring_service_gives_up_without_a_heartbeat_and_the_ring_fails_loudly(gpu
         ring.pump()
         got.append(ring.poll(sid)[0].copy())
         time.sleep(0.01)
+    assert ring.stats()["service_launches"] == 1
+    total = 3 * 65536
+    for rep in range(2):
+        time.sleep(4.0)                     # silence: no ring call at all (the service stops after 1-2 timeouts)
+        n = 2 * 65536
+        assert ring.fill(sid, 5, 0, n, final=False) == n
+        total += n
+        t0 = time.time()
+        while time.time() - t0 < 2.0:
+            ring.pump()
+            got.append(ring.poll(sid)[0].copy())
+            time.sleep(0.005)
+        assert ring.stats()["service_launches"] == 2 + rep, ring.stats()
+    ring.park()                             # by hand, without waiting; the next round starts a new service behind the old one
     assert ring.fill(sid, 5, 0, 65536 + 17, final=True) == 65536 + 17
+    total += 65536 + 17
     t0 = time.time()
-    while time.time() - t0 < 20:
+    fin = False
+    while not fin and time.time() - t0 < 20:
         ring.pump()
         recs, fin = ring.poll(sid)
         got.append(recs.copy())
-        if fin:
-            break
-    want = O.chunk_and_digest(O.new_config(4096), O.fill(4 * 65536 + 17, 5, 0), [(0, 4 * 65536 + 17)])
-    _assert_same(np.concatenate(got), want, "slow producer")
+    assert fin
+    want = O.chunk_and_digest(O.new_config(4096), O.fill(total, 5, 0), [(0, total)])
+    _assert_same(np.concatenate(got), want, "silent host")
+    assert ring.stats()["service_launches"] == 4
     ring.close_stream(sid)
-    sid = ring.open()
-    ring.fill(sid, 6, 0, 2 * 65536, final=False)
-    ring.pump()
-    time.sleep(4.0)                         # silence: no ring call at all (the service gives up after 1-2 timeouts)
-    with pytest.raises(PbsGpuError) as ei:
-        for _ in range(2000):
-            ring.pump()
-            ring.poll(sid)
-            time.sleep(0.001)
-    assert ei.value.status == _lib.E_STATE
+    ring.quiesce()
+    st = ring.stats()
+    assert st["pages_free"] == st["pages_total"], st
     ring.close()
     eng.close()
 
