@@ -509,13 +509,60 @@ class Ctx:
     dist = None
     comm_dev = None
     rec_cap = 0
+    cabi = None        # result of the C-ABI digest-set reduce check (N > 1, RCCL)
+    hard_exit = False  # a watchdog gave up on a collective: leave with os._exit once the line is out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (what `python -m torch.distributed.run
+    --nproc-per-node N` would do), one per GPU, rendezvous on 127.0.0.1. Rank 0 inherits stdout (its ONE JSON line is this
+    command's output), a rank that dies takes the others down, the exit code is the first non-zero one."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = json.loads(os.environ["PBS_BENCH_SPAWN_CMD"]) if os.environ.get("PBS_BENCH_SPAWN_CMD") else [sys.executable] + sys.argv
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in alive:      # our own children, by PID
+                        q.send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and not (world == 1 and a.gpus <= 1):
+        # the launcher's world size and --gpus disagree: a line that says n_gpus = WORLD_SIZE while the caller asked for
+        # --gpus N would be scored against the wrong N
+        print(f"bench: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     ctx = Ctx()
     backend = os.environ.get("PBS_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; gloo only for CPU tests / 1-GPU debugging
     # PBS_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, collectives, FIFO collection) even
@@ -569,6 +616,9 @@ def main():
                     and (a.gib is None or a.extras_gib is not None)):
                 out["workloads"] = extras(a, rank, local_rank, world, ctx)
             print(json.dumps(out), flush=True)
+    if ctx.hard_exit:
+        sys.stdout.flush()
+        os._exit(0)
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()
 
@@ -655,6 +705,37 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
         except BaseException as exc:  # noqa: BLE001
             res[label] = {"error": repr(exc)}
     res["total_seconds"] = round(time.perf_counter() - t_all, 1)
+    return res
+
+
+def cabi_reduce_check(eng, recs, ctx):
+    """pbsgpu_comm_create + pbsgpu_digest_allgather_dedup over all ranks (collective) vs the torch.distributed path."""
+    from pbs_plus_amd.dist import comm_dedup, global_dedup, make_comm
+
+    res = {"ok": False}
+
+    def work():
+        try:
+            _, ref, _ = global_dedup(eng, recs, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
+            comm = make_comm(eng, device=ctx.comm_dev)
+            comm_dedup(comm, recs, ctx.rec_cap)                       # first contact (RCCL channel set-up)
+            t0 = time.perf_counter()
+            _, st = comm_dedup(comm, recs, ctx.rec_cap)
+            res.update(ok=True, ms=round((time.perf_counter() - t0) * 1e3, 3), stats={k: int(v) for k, v in st.items()},
+                       equals_torch_path=bool(all(int(st[k]) == int(ref[k]) for k in ("nrecords", "nunique", "total_bytes",
+                                                                                        "unique_bytes"))),
+                       path="pbsgpu_comm_create + pbsgpu_digest_allgather_dedup (libpbsgpu dlopens RCCL: one ncclAllGather "
+                            "of [count | records] slots + device dedup)")
+            comm.close()
+        except BaseException as exc:  # noqa: BLE001
+            res["error"] = repr(exc)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(120)
+    if th.is_alive():
+        res["error"] = "timeout after 120 s"
+        ctx.hard_exit = True
     return res
 
 
@@ -783,6 +864,11 @@ def ring_run(a, rank, local_rank, world, ctx):
         ctx.dist.all_reduce(tb, op=ctx.dist.ReduceOp.SUM)
         total_bytes = float(tb.item())
     state["timed"] = False
+    if ctx.dist is not None and ctx.comm_dev is not None and ctx.comm_dev.type == "cuda" and not os.environ.get("PBS_BENCH_NO_CABI_REDUCE"):
+        # the same digest-set reduce through the C ABI's own communicator (what a Go host binds: no torch in it), outside the
+        # timed region, on the last timed file of every rank; must agree with the torch path. A watchdog keeps a communicator
+        # that does not come up from taking the line down.
+        ctx.cabi = cabi_reduce_check(eng, kept[max(kept)], ctx)
     # one file alone through an idle ring: single-file latency (outside the timed region)
     ts0 = time.perf_counter()
     s_saved, state["S"] = state["S"], 1
@@ -854,6 +940,25 @@ def ring_run(a, rank, local_rank, world, ctx):
             out["results"] = extra
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = ring_cpu_baseline(a, kept, single, file_bytes, kind, seed_of)
+    if not a.no_cpu_baseline and world > 1:
+        # N ranks: EVERY rank checks its own files against the oracle (prefix + restart points, regenerated from the files'
+        # seeds), the verdicts meet on rank 0 — an N-GPU line carries parity evidence for all N GPUs' records. The one-core
+        # CPU figure is rank 0's (the contract times it at N = 1; here it is context only).
+        mine = ring_cpu_baseline(_copy_args(a, brief=True, spread_points=max(8, a.spread_points // 2)), kept, single, file_bytes,
+                                 kind, seed_of)
+        v = torch.tensor([1 if mine["records_match_gpu"] else 0, -int(mine["records_checked"]),
+                          -int(mine["whole_file_restart_points"]["files"])], dtype=torch.int64, device=ctx.comm_dev)
+        lo = v.clone()
+        ctx.dist.all_reduce(lo, op=ctx.dist.ReduceOp.MIN)          # all ranks matched <=> the minimum is 1
+        ctx.dist.all_reduce(v, op=ctx.dist.ReduceOp.SUM)
+        if rank == 0:
+            mine["all_ranks"] = {"ranks": world, "records_match_gpu": bool(int(lo[0].item()) == 1),
+                                 "records_checked": int(-v[1].item()), "files_checked": int(-v[2].item())}
+            mine["records_match_gpu"] = mine["all_ranks"]["records_match_gpu"]
+            mine["records_checked"] = mine["all_ranks"]["records_checked"]
+            out["cpu_baseline"] = mine
+    if ctx.dist is not None and rank == 0 and ctx.cabi is not None:
+        out.setdefault("results", {})["c_abi_digest_reduce"] = ctx.cabi
     ring.close()
     eng.close()
     return out

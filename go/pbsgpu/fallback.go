@@ -20,6 +20,9 @@ var (
 	ErrHostFaster = errors.New("pbsgpu: too few files in flight for the GPU to beat host SHA-256; hash on the host")
 )
 
+// CommIDBytes mirrors PBSGPU_COMM_ID_BYTES.
+const CommIDBytes = 128
+
 type (
 	Config struct {
 		AvgSize, MinSize, MaxSize, WindowSize int
@@ -35,6 +38,7 @@ type (
 	Stream     struct{}
 	Chunker    struct{}
 	Ring       struct{}
+	Comm       struct{}
 	Ticket     uint64
 	DedupStats struct{ Records, Unique, TotalBytes, UniqueBytes uint64 }
 	ReuseChunk struct {
@@ -74,6 +78,7 @@ func (e *Engine) EncodeDynamicIndex([]ChunkInfo, [16]byte, int64) ([]byte, error
 func (e *Engine) NewStream(uint64) (*Stream, error)                               { return nil, ErrNotBuilt }
 func (e *Engine) NewChunker() (*Chunker, error)                                   { return nil, ErrNotBuilt }
 func (e *Engine) NewRing(RingOptions) (*Ring, error)                              { return nil, ErrNotBuilt }
+func (e *Engine) NewComm([CommIDBytes]byte, int, int) (*Comm, error)              { return nil, ErrNotBuilt }
 func (e *Engine) HashFiles([]byte, []uint64, []uint64) ([][32]byte, error)        { return nil, ErrNotBuilt }
 func (e *Engine) HashFilesForced([]byte, []uint64, []uint64) ([][32]byte, error)  { return nil, ErrNotBuilt }
 func (e *Engine) XXH3Files([]byte, []uint64, []uint64) ([]uint64, error)          { return nil, ErrNotBuilt }
@@ -99,6 +104,9 @@ func (c *Chunker) Scan([]byte) (int, error) { return 0, ErrNotBuilt }
 func (c *Chunker) Reset() error             { return ErrNotBuilt }
 func (c *Chunker) Close()                   {}
 
+func NewCommID() ([CommIDBytes]byte, error)                                      { return [CommIDBytes]byte{}, ErrNotBuilt }
+func (c *Comm) Dedup([]ChunkInfo, uint64) ([]bool, DedupStats, error)            { return nil, DedupStats{}, ErrNotBuilt }
+func (c *Comm) Close()                                                           {}
 func (r *Ring) Open() (uint32, error)                                            { return 0, ErrNotBuilt }
 func (r *Ring) Reserve(uint32) (uintptr, uint64, error)                          { return 0, 0, ErrNotBuilt }
 func (r *Ring) Commit(uint32, uint64, bool) error                                { return ErrNotBuilt }

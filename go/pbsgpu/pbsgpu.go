@@ -801,6 +801,69 @@ func (r *Ring) Close() {
 	r.eng = nil
 }
 
+// ---- multi-GPU digest-set reduce (RCCL over xGMI, behind the C ABI) ---------------------------------------------------
+
+// CommIDBytes is the size of the opaque id rank 0 creates and ships to the other ranks (over the agent's own RPC).
+const CommIDBytes = C.PBSGPU_COMM_ID_BYTES
+
+// Comm is one rank's end of the cross-GPU digest-set reduce (pbsgpu_comm_*): the path shards at archive granularity with
+// no data-path collective — one Engine per GPU ingests its own streams (internal/tapeio/converter.go:396-439: one session
+// per process) — and the (digest, size) records of all ranks meet in ONE all-gather + device dedup for cross-file
+// duplicate detection. Every method is collective: all ranks call it, in the same order.
+type Comm struct {
+	h   *C.pbsgpu_comm
+	eng *Engine
+}
+
+// NewCommID is called on rank 0 only.
+func NewCommID() ([CommIDBytes]byte, error) {
+	var id [CommIDBytes]byte
+	err := check(C.pbsgpu_comm_unique_id((*C.uint8_t)(unsafe.Pointer(&id[0]))), "comm_unique_id")
+	return id, err
+}
+
+func (e *Engine) NewComm(id [CommIDBytes]byte, rank, world int) (*Comm, error) {
+	defer runtime.KeepAlive(e)
+	c := &Comm{eng: e}
+	if err := check(C.pbsgpu_comm_create(e.h, (*C.uint8_t)(unsafe.Pointer(&id[0])), C.int(rank), C.int(world), &c.h), "comm_create"); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(c, (*Comm).Close)
+	return c, nil
+}
+
+// Dedup contributes this rank's records (at most capRecords, the same bound on every rank: bytes per rank / minimum chunk
+// size) and returns, for each of them, whether an earlier record of the union carries the same digest, plus the statistics
+// of the union (identical on every rank).
+func (c *Comm) Dedup(recs []ChunkInfo, capRecords uint64) ([]bool, DedupStats, error) {
+	defer runtime.KeepAlive(c)
+	var st C.pbsgpu_dedup_stats
+	var rp *C.pbsgpu_record
+	var dp *C.uint8_t
+	cr := toRecords(recs)
+	dup := make([]C.uint8_t, len(recs))
+	if len(recs) > 0 {
+		rp, dp = &cr[0], &dup[0]
+	}
+	if err := check(C.pbsgpu_digest_allgather_dedup(c.h, rp, C.uint64_t(len(recs)), C.uint64_t(capRecords), dp, &st), "digest_allgather_dedup"); err != nil {
+		return nil, DedupStats{}, err
+	}
+	out := make([]bool, len(recs))
+	for i := range out {
+		out[i] = dup[i] != 0
+	}
+	return out, DedupStats{uint64(st.nrecords), uint64(st.nunique), uint64(st.total_bytes), uint64(st.unique_bytes)}, nil
+}
+
+func (c *Comm) Close() {
+	runtime.SetFinalizer(c, nil)
+	if c.h != nil {
+		C.pbsgpu_comm_destroy(c.h)
+		c.h = nil
+	}
+	c.eng = nil
+}
+
 // DedupDevice flags duplicates among n records that already are in device memory (the receive buffer of an RCCL
 // all-gather): the digest-set reduce without a host round trip of the set.
 func (e *Engine) DedupDevice(drecs uintptr, n uint64) ([]bool, DedupStats, error) {

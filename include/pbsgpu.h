@@ -405,6 +405,28 @@ int pbsgpu_dedup_host(pbsgpu_engine *eng, const pbsgpu_record *recs, uint64_t n,
 int pbsgpu_dedup_device(pbsgpu_engine *eng, const void *drecs, uint64_t n, uint8_t *dup /* n, may be NULL */,
                         pbsgpu_dedup_stats *stats);
 
+/* ---- multi-GPU digest-set reduce (RCCL over xGMI) ----------------------------------
+ * The path shards at file / archive granularity with no data-path collective: one engine per GPU (one process per GPU, or
+ * several engines in one process) ingests its own streams. The one exchange step is the digest-set reduce for cross-file
+ * duplicate detection: ONE RCCL all-gather of fixed-size slots [count | records] + the device dedup.
+ * A Go host (one session per process, pure Go: internal/tapeio/converter.go:396-439) binds this directly — no Python, no
+ * torch: rank 0 asks for a unique id, ships its 128 bytes to the other ranks over the channel it already has (the
+ * agent's aRPC session), every rank creates its communicator, and every rank calls the reduce in the same order.
+ * RCCL is resolved at run time (dlopen): a single-GPU host never loads it; PBSGPU_E_NO_DEVICE when it is not installed. */
+#define PBSGPU_COMM_ID_BYTES 128
+typedef struct pbsgpu_comm pbsgpu_comm;
+int pbsgpu_comm_unique_id(uint8_t id[PBSGPU_COMM_ID_BYTES]);
+/* Collective over `world` ranks (blocks until all of them have called it). The communicator keeps its engine alive. */
+int pbsgpu_comm_create(pbsgpu_engine *eng, const uint8_t id[PBSGPU_COMM_ID_BYTES], int rank, int world, pbsgpu_comm **out);
+void pbsgpu_comm_destroy(pbsgpu_comm *comm);
+int pbsgpu_comm_rank(const pbsgpu_comm *comm, int *rank, int *world);
+/* Collective. recs[0..n) (host memory, n <= cap_records) = this rank's records; cap_records must be the SAME on every
+ * rank (bytes per rank / minimum chunk size is a bound every rank can compute). *stats describes the union over all
+ * ranks and is identical on every rank; dup_own[i] (may be NULL) = 1 when an earlier record of the union — a lower rank's,
+ * or this rank's with a lower index — carries the same digest. ~48 B per chunk travel: 12 MB per TiB of corpus. */
+int pbsgpu_digest_allgather_dedup(pbsgpu_comm *comm, const pbsgpu_record *recs, uint64_t n, uint64_t cap_records,
+                                  uint8_t *dup_own /* n, may be NULL */, pbsgpu_dedup_stats *stats);
+
 /* ---- dynamic index (.didx) encoding ------------------------------------------
  * On-disk form of the record list: datastore.NewDynamicIndexWriter(ctime)
  * .Add(end, digest).Finish() / datastore.ParseDynamicIndex

@@ -434,4 +434,51 @@ class PageRing {
 };
 
 }  // namespace transfer
+
+// The cross-GPU digest-set reduce (pbsgpu_comm_*): one Engine per GPU ingests its own archives (the reference runs one
+// session per process, internal/tapeio/converter.go:396-439), the (digest, size) records of all ranks meet in ONE RCCL
+// all-gather + device dedup. Every call is collective: all ranks, same order.
+namespace distributed {
+
+using CommID = std::array<uint8_t, PBSGPU_COMM_ID_BYTES>;
+
+inline Result<CommID> NewCommID() {  // rank 0 only; ship the bytes to the other ranks
+    Result<CommID> r;
+    const int st = pbsgpu_comm_unique_id(r.value.data());
+    if (st != PBSGPU_OK) r.err = errorf("comm unique id", st);
+    return r;
+}
+
+class Comm {
+  public:
+    static Result<std::unique_ptr<Comm>> New(std::shared_ptr<Engine> eng, const CommID &id, int rank, int world) {
+        Result<std::unique_ptr<Comm>> r;
+        pbsgpu_comm *h = nullptr;
+        const int st = pbsgpu_comm_create(eng->handle(), id.data(), rank, world, &h);
+        if (st != PBSGPU_OK) {
+            r.err = errorf("comm create", st);
+            return r;
+        }
+        r.value.reset(new Comm(std::move(eng), h));
+        return r;
+    }
+    ~Comm() { pbsgpu_comm_destroy(c_); }
+    // this rank's records in, the statistics of the union out; dup[i] = an earlier record of the union has recs[i]'s digest
+    Result<pbsgpu_dedup_stats> Dedup(const std::vector<pbsgpu_record> &recs, uint64_t cap_records, std::vector<uint8_t> *dup = nullptr) {
+        Result<pbsgpu_dedup_stats> r;
+        if (dup) dup->assign(recs.size(), 0);
+        const int st = pbsgpu_digest_allgather_dedup(c_, recs.empty() ? nullptr : recs.data(), recs.size(), cap_records,
+                                                     dup && !recs.empty() ? dup->data() : nullptr, &r.value);
+        if (st != PBSGPU_OK) r.err = errorf("digest all-gather + dedup", st);
+        return r;
+    }
+
+  private:
+    Comm(std::shared_ptr<Engine> eng, pbsgpu_comm *c) : eng_(std::move(eng)), c_(c) {}
+    Comm(const Comm &) = delete;
+    std::shared_ptr<Engine> eng_;
+    pbsgpu_comm *c_;
+};
+
+}  // namespace distributed
 }  // namespace pbsgpu

@@ -9,7 +9,7 @@ pbs-plus reference uses for its pxar stream path:
 * ``PayloadStream`` — the payload-stream writer seam (``transfer.ArchiveWriter``)
 * ``PageRing`` — many streams, page-granular memory release, persistent SHA-256 service
 * ``Chunker`` — upstream-style ``scan`` compatibility
-* ``didx`` / ``dedup`` — dynamic index records and the cross-GPU digest-set reduce
+* ``didx`` / ``dedup`` / ``Comm`` — dynamic index records and the cross-GPU digest-set reduce (RCCL, behind the C ABI)
 
 Everything executes in the gfx950 kernels of ``lib/libpbsgpu.so``; there is no CPU path.
 """
@@ -23,6 +23,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 from . import buzhash  # noqa: F401,E402
 from ._lib import RECORD_DTYPE, PbsGpuError  # noqa: F401,E402
-from .engine import Chunker, Engine, PageRing, PayloadStream  # noqa: F401,E402
+from .engine import Chunker, Comm, Engine, PageRing, PayloadStream  # noqa: F401,E402
 
-__all__ = ["buzhash", "Engine", "PayloadStream", "PageRing", "Chunker", "RECORD_DTYPE", "PbsGpuError"]
+__all__ = ["buzhash", "Engine", "PayloadStream", "PageRing", "Chunker", "Comm", "RECORD_DTYPE", "PbsGpuError"]

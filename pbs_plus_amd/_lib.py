@@ -174,6 +174,11 @@ SYMBOLS = {
     "pbsgpu_xxh3_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_dedup_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(DedupStats)]),
     "pbsgpu_dedup_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(DedupStats)]),
+    "pbsgpu_comm_unique_id": (C.c_int, [_P]),
+    "pbsgpu_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pbsgpu_comm_destroy": (None, [_P]),
+    "pbsgpu_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pbsgpu_digest_allgather_dedup": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(DedupStats)]),
     "pbsgpu_didx_size": (C.c_int, [C.c_uint64, _U64P]),
     "pbsgpu_didx_encode": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int64, _P, C.c_uint64]),
     "pbsgpu_didx_decode": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P, C.POINTER(C.c_int64), _P]),

@@ -1,0 +1,195 @@
+// libpbsgpu host side, part 4: the multi-GPU digest-set reduce behind the C ABI (pbsgpu_comm_*).
+//
+// The path shards at file / archive granularity with no data-path collective: one process (or one engine)
+// per GPU ingests its own streams. The ONE exchange step is the digest-set reduce for cross-file duplicate detection:
+// every rank contributes the (digest, size) records of its chunks, all ranks receive the union and flag duplicates on the
+// device. Rounds 1-3 had this only as torch.distributed calls in pbs_plus_amd/dist.py — nothing a Go host (one session
+// per process, pure Go: /root/reference internal/tapeio/converter.go:396-439) could bind. Here it is one RCCL all-gather
+// of fixed-size slots [count | records] over xGMI + the device dedup, with RCCL resolved at run time (dlopen): a
+// single-GPU host never loads it, and the library carries no link-time dependency on it.
+//   rank 0: pbsgpu_comm_unique_id(id)  -> the host ships the 128 bytes to the other ranks over whatever it already talks
+//   (the Go agent: its aRPC session), every rank: pbsgpu_comm_create(engine, id, rank, world, &comm), then any number of
+//   pbsgpu_digest_allgather_dedup(comm, ...) — collective: every rank calls it, in the same order.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "engine_internal.h"
+
+using namespace pbse;
+
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl r = []() {
+        Rccl x;
+        // a process that already has an RCCL (PyTorch bundles one) keeps using THAT instance
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (x.h) break;
+        }
+        if (!x.h)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (x.h) break;
+            }
+        if (!x.h) return x;
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.h, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.h, "ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.h, "ncclCommDestroy"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.h, "ncclAllGather"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.h, "ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather;
+        return x;
+    }();
+    return r;
+}
+
+constexpr uint64_t kSlotHeader = 64;  // [count u64 | pad] in front of a rank's records: keeps the records 64-byte aligned
+
+}  // namespace
+
+struct pbsgpu_comm {
+    pbsgpu_engine *eng = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t st = nullptr;
+    DevBuf send, recv, dense;
+    PinnedBuf h_send, h_counts, h_items;
+    std::mutex mu;  // one collective at a time per communicator
+};
+
+extern "C" {
+
+int pbsgpu_comm_unique_id(uint8_t id[PBSGPU_COMM_ID_BYTES]) {
+    if (!id) return PBSGPU_E_INVALID;
+    static_assert(PBSGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    Rccl &r = rccl();
+    if (!r.ok) return PBSGPU_E_NO_DEVICE;  // no RCCL in this process / on this box
+    ncclUniqueId u;
+    if (r.GetUniqueId(&u) != ncclSuccess) return PBSGPU_E_HIP;
+    std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return PBSGPU_OK;
+}
+
+void pbsgpu_comm_destroy(pbsgpu_comm *c) {
+    if (!c) return;
+    pbsgpu_engine *e = c->eng;
+    if (e) (void)hipSetDevice(e->device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    c->send.release();
+    c->recv.release();
+    c->dense.release();
+    c->h_send.release();
+    c->h_counts.release();
+    c->h_items.release();
+    delete c;
+    if (e) engine_unref(e);
+}
+
+int pbsgpu_comm_create(pbsgpu_engine *e, const uint8_t id[PBSGPU_COMM_ID_BYTES], int rank, int world, pbsgpu_comm **out) {
+    if (!e || !id || !out || world < 1 || rank < 0 || rank >= world) return PBSGPU_E_INVALID;
+    *out = nullptr;
+    Rccl &r = rccl();
+    if (!r.ok) return PBSGPU_E_NO_DEVICE;
+    CHK(set_device(e));
+    pbsgpu_comm *c = new (std::nothrow) pbsgpu_comm();
+    if (!c) return PBSGPU_E_NOMEM;
+    engine_ref(e);
+    c->eng = e;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    int st = PBSGPU_OK;
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+    if (st == PBSGPU_OK && r.CommInitRank(&c->comm, world, u, rank) != ncclSuccess) st = PBSGPU_E_HIP;
+    if (st != PBSGPU_OK) {
+        c->comm = nullptr;
+        pbsgpu_comm_destroy(c);
+        return st;
+    }
+    *out = c;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_comm_rank(const pbsgpu_comm *c, int *rank, int *world) {
+    if (!c) return PBSGPU_E_INVALID;
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return PBSGPU_OK;
+}
+
+// The digest-set reduce. Collective. `recs` (host, n <= cap_records) = this rank's records; cap_records must be the SAME on
+// every rank (the all-gather moves fixed-size slots; bytes / min chunk size is a bound every rank can compute). On return
+// `stats` describes the union over all ranks (identical on every rank); dup_own[i] = 1 when an EARLIER record of the union
+// — lower rank, or same rank and lower index — carries the same digest (may be NULL).
+int pbsgpu_digest_allgather_dedup(pbsgpu_comm *c, const pbsgpu_record *recs, uint64_t n, uint64_t cap_records,
+                                  uint8_t *dup_own, pbsgpu_dedup_stats *stats) {
+    if (!c || !stats || (!recs && n) || n > cap_records || cap_records == 0) return PBSGPU_E_INVALID;
+    pbsgpu_engine *e = c->eng;
+    std::lock_guard<std::mutex> lk(c->mu);
+    CHK(set_device(e));
+    const uint64_t slot = kSlotHeader + cap_records * sizeof(pbsgpu_record);
+    if (slot * (uint64_t)c->world >= (1ull << 40)) return PBSGPU_E_INVALID;
+    CHK(c->send.ensure(slot));
+    CHK(c->recv.ensure(slot * (uint64_t)c->world));
+    CHK(c->h_send.ensure(slot));
+    CHK(c->h_counts.ensure((size_t)c->world * 8));
+    // only the bytes that exist travel to the device: header + n records
+    uint8_t *hs = c->h_send.as<uint8_t>();
+    std::memset(hs, 0, kSlotHeader);
+    std::memcpy(hs, &n, 8);
+    if (n) std::memcpy(hs + kSlotHeader, recs, n * sizeof(pbsgpu_record));
+    HIPCHK(hipMemcpyAsync(c->send.p, hs, kSlotHeader + n * sizeof(pbsgpu_record), hipMemcpyHostToDevice, c->st));
+    if (rccl().AllGather(c->send.p, c->recv.p, slot, ncclUint8, c->comm, c->st) != ncclSuccess) return PBSGPU_E_HIP;
+    // the counts of all ranks (8 bytes each) decide the compaction
+    uint64_t *hc = c->h_counts.as<uint64_t>();
+    for (int r = 0; r < c->world; ++r)
+        HIPCHK(hipMemcpyAsync(hc + r, c->recv.as<uint8_t>() + (uint64_t)r * slot, 8, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    uint64_t total = 0, own_first = 0;
+    for (int r = 0; r < c->world; ++r) {
+        if (hc[r] > cap_records) return PBSGPU_E_INVALID;  // a rank used another capacity: the slots do not line up
+        if (r == c->rank) own_first = total;
+        total += hc[r];
+    }
+    std::memset(stats, 0, sizeof(*stats));
+    if (total == 0) return PBSGPU_OK;
+    if (total >= (1ull << 32)) return PBSGPU_E_INVALID;
+    // compact the slots' records into one dense array (piece-table copy on the device), then the ordinary device dedup
+    CHK(c->dense.ensure(total * sizeof(pbsgpu_record)));
+    constexpr uint64_t kPiece = 4ull << 20;
+    std::vector<pbsk::PackItem> items;
+    uint64_t dst = 0;
+    for (int r = 0; r < c->world; ++r) {
+        const uint64_t bytes = hc[r] * sizeof(pbsgpu_record), src = (uint64_t)r * slot + kSlotHeader;
+        for (uint64_t o = 0; o < bytes; o += kPiece)
+            items.push_back(pbsk::PackItem{src + o, dst + o, std::min<uint64_t>(kPiece, bytes - o), 0u, 0u});
+        dst += bytes;
+    }
+    CHK(c->h_items.ensure(items.size() * sizeof(pbsk::PackItem)));
+    std::memcpy(c->h_items.p, items.data(), items.size() * sizeof(pbsk::PackItem));
+    // (mapped pinned memory: the kernel reads the item table in place — no second staging copy)
+    HIPCHK(pbsk::launch_pack(c->recv.as<uint8_t>(), c->dense.as<uint8_t>(), c->h_items.as<pbsk::PackItem>(), (uint32_t)items.size(),
+                             c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    std::vector<uint8_t> dup;
+    if (dup_own && n) dup.resize((size_t)total);
+    CHK(pbsgpu_dedup_device(e, c->dense.p, total, dup.empty() ? nullptr : dup.data(), stats));
+    if (dup_own && n) std::memcpy(dup_own, dup.data() + own_first, (size_t)n);
+    return PBSGPU_OK;
+}
+
+}  // extern "C"

@@ -138,6 +138,7 @@ struct Section {                         // the bytes between two forced cuts = 
 struct FileSpan {                        // a file body inside the stream (begin_file .. end_file), in WRITTEN-byte coordinates
     uint64_t index = 0, w_start = 0, w_end = 0;
     bool closed = false, started = false;
+    bool done = false;                   // its last piece has been queued
     uint32_t state = 0;                  // which of the two streaming XXH3 states carries it across pages
     uint32_t pend = 0;                   // host mirror of xxh::State::pend_len (pure arithmetic on the piece lengths)
 };
@@ -235,6 +236,9 @@ int engine_ring_get(pbsgpu_engine *e, pbsgpu_ring **out) {
         CHK(ring_create_internal(e, &o, false, &r));
         // nothing in flight anywhere for 2 ms: stop the service (its CUs, and hipFree / device-wide syncs of the process, come
         // back); the next page starts it again
+        // host-fed pages trickle in (3 per millisecond at 50 GiB/s) and a round is three launches: cut every 8 pages instead of
+        // waiting for a quarter of a full round (64 pages = 20 ms more latency for every chunk, and for the archive's drain)
+        if (!getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = std::min<uint32_t>(r->min_round_pages, 8);
         if (r->autopark_ms == 0) r->autopark_ms = 2.0;
         // ... and a writer that simply stops calling (a blocking read) gives them back after 2 s without any call at all
         r->idle_timeout_s = 2.0;
@@ -378,6 +382,7 @@ int stream_enqueue_tee(pbsgpu_stream *s, const uint8_t *base, uint64_t w0, uint6
         total_blocks += it.nproc;
         f.started = true;
         if (last) {
+            f.done = true;
             const uint32_t slot = (uint32_t)t.files.size();
             it.out = slot;
             t.files.push_back(pbsgpu_file_hash{f.index, f.w_end - f.w_start, 0});
@@ -385,7 +390,8 @@ int stream_enqueue_tee(pbsgpu_stream *s, const uint8_t *base, uint64_t w0, uint6
         }
         items[n++] = it;
     }
-    while (!s->files.empty() && s->files.front().closed) s->files.pop_front();  // closed => its last piece is queued now
+    // (a CLOSED file may still have bytes in staging, beyond the page that is being committed: only `done` retires it)
+    while (!s->files.empty() && s->files.front().done) s->files.pop_front();
     if (n == 0) return PBSGPU_OK;
     CHK(t.d_items.ensure(std::max<size_t>(maxitems, 1024) * sizeof(pbsk::XxhItem)));
     CHK(s->tee_sums.ensure((size_t)(total_blocks + 64) * 64));

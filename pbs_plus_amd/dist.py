@@ -7,6 +7,10 @@ granularity with no data-path communication.
 ``torch.distributed`` is plumbing here (RCCL over xGMI with backend "nccl" on the GPU box,
 gloo in the CPU tests); the records are ~48 B per ~4 MiB chunk (≈12 MB per TiB), so the
 exchange is latency-bound and a single all_gather of padded record arrays is enough.
+
+The same reduce exists BEHIND THE C ABI (pbsgpu_comm_* / pbsgpu_digest_allgather_dedup, csrc/comm.cpp: libpbsgpu
+resolves RCCL itself) for hosts without Python — ``make_comm`` / ``comm_dedup`` drive it from here; the torch path
+stays because gloo (CPU tests, world size > 1 without GPUs) cannot run RCCL.
 """
 from __future__ import annotations
 
@@ -110,6 +114,29 @@ def global_dedup(engine, local_records: np.ndarray, device=None, group=None, cap
     dup, stats = engine.dedup_device(packed.data_ptr(), total)
     allrecs = packed.cpu().numpy().view(RECORD_DTYPE).copy() if want_records else None
     return dup, stats, allrecs
+
+
+def make_comm(engine, device=None, group=None):
+    """The C ABI's own communicator for the digest-set reduce (pbsgpu_comm_*, engine.Comm): libpbsgpu resolves RCCL itself
+    and moves the records with ONE ncclAllGather — the path a Go host binds, with no torch in it. torch.distributed only
+    carries the 128-byte id from rank 0 to the others here (a Go host ships it over its own RPC). Collective."""
+    import torch
+    import torch.distributed as dist
+
+    from .engine import Comm
+
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    idt = torch.zeros(Comm.ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt = torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8).to(dev)
+    dist.broadcast(idt, src=0, group=group)
+    return Comm(engine, bytes(idt.cpu().numpy().tobytes()), rank, ws)
+
+
+def comm_dedup(comm, local_records: np.ndarray, cap_records: int, want_flags: bool = False):
+    """global_dedup through the C ABI: (dup flags of THIS rank's records or None, stats of the union)."""
+    return comm.dedup(local_records, cap_records, want_flags=want_flags)
 
 
 def ingest_corpus(engine, lengths, make_batch, device=None, group=None, max_batch_bytes: int = 64 << 30):

@@ -417,6 +417,52 @@ class PayloadStream:
             pass
 
 
+class Comm:
+    """The multi-GPU digest-set reduce through the C ABI (pbsgpu_comm_*): ONE RCCL all-gather of the ranks' (digest, size)
+    records over xGMI + the device dedup — what a Go host binds directly (go/pbsgpu: Comm), no torch involved.
+    ``Comm.unique_id()`` on rank 0, ship the 128 bytes to the other ranks, ``Comm(engine, id, rank, world)`` on every rank
+    (collective), then ``dedup(records, cap_records)`` on every rank in the same order."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * Comm.ID_BYTES)()
+        check(_lib.lib().pbsgpu_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, eng: Engine, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == Comm.ID_BYTES
+        self._eng = eng
+        self._L = eng._L
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        idb = (C.c_uint8 * Comm.ID_BYTES).from_buffer_copy(unique_id)
+        check(self._L.pbsgpu_comm_create(eng._h, idb, self.rank, self.world, C.byref(h)), "comm_create")
+        self._h = h
+
+    def dedup(self, records: np.ndarray, cap_records: int, want_flags: bool = True):
+        """(dup flags of THIS rank's records, stats of the union over all ranks). cap_records: the same on every rank."""
+        recs = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        dup = np.zeros(max(recs.size, 1), dtype=np.uint8) if want_flags else None
+        st = _lib.DedupStats()
+        check(self._L.pbsgpu_digest_allgather_dedup(self._h, recs.ctypes.data if recs.size else None, recs.size,
+                                                    int(cap_records), dup.ctypes.data if want_flags else None,
+                                                    C.byref(st)), "digest_allgather_dedup")
+        return (dup[: recs.size] if want_flags else None), {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pbsgpu_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Chunker:
     """Upstream-style streaming chunker: ``scan(data) -> pos`` (0 = no boundary yet)."""
 

@@ -447,3 +447,33 @@ def test_bench_many_files_through_the_ring(monkeypatch, mode):
     if mode == "ring_corpus_dup":
         dd = d["results"]["dedup"]
         assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and dd["expected_duplicate_frac"] > 0.15
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks_and_every_rank_is_checked():
+    """`bench.py --gpus N` used to be parsed and ignored — without torchrun it ran ONE rank and printed
+    n_gpus: 1. Now it starts the N ranks itself (rendezvous on 127.0.0.1); the line says n_gpus = N, and rank 0's
+    cpu_baseline carries the oracle's verdict over EVERY rank's files (an N-rank record without parity evidence is
+    worth nothing). Over gloo on CPU here; the driver's torchrun launch takes the other branch (WORLD_SIZE set)."""
+    import subprocess
+
+    args = ["--gpus", "2", "--gib", str(12 / 1024), "--avg", "65536", "--steps", "3", "--warmup", "1", "--ring-streams", "2",
+            "--cpu-sample-gib", str(4 / 1024)]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_bench_contract import _patched_main\n"
+            "_patched_main(%r)\n" % (ROOT, os.path.join(ROOT, "tests"), args))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(PBS_BENCH_BACKEND="gloo", PBS_BENCH_SPAWN_CMD=json.dumps([sys.executable, "-c", code]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    c = d["cpu_baseline"]
+    assert c["records_match_gpu"] is True and c["all_ranks"]["ranks"] == 2 and c["all_ranks"]["records_match_gpu"] is True
+    assert c["all_ranks"]["files_checked"] == 2 * (3 + 1)            # every timed file + the single-file pass, on both ranks
+    assert c["all_ranks"]["records_checked"] > c["front_of_file"]["records_checked"]
+    # a launcher whose world size disagrees with --gpus is refused, not silently re-labelled
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "WORLD_SIZE=3" in bad.stderr
