@@ -374,7 +374,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.sugg_abs = e->sugg_feed_abs.load(std::memory_order_relaxed);
     rr.seg_rec_base = recbase;
     std::atomic_thread_fence(std::memory_order_release);
-    {
+    if (!r->defer_service) {
         const int st = ring_start_service(r);
         if (st != PBSGPU_OK) return fail(st);
     }
@@ -588,6 +588,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (const char *v = getenv("PBSGPU_RING_BACKLOG_MIB")) r->backlog_limit = (uint64_t)(std::max(0.0, atof(v)) * 1048576.0);
         if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kRingInputs);
         if (const char *v = getenv("PBSGPU_RING_AUTOPARK_MS")) r->autopark_ms = std::max(0.0, atof(v));
+        if (const char *v = getenv("PBSGPU_RING_DEFER_SERVICE")) r->defer_service = atoi(v) != 0;
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
@@ -705,6 +706,31 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
     if (!r) return PBSGPU_E_INVALID;
     CHK(set_device(r->eng));
     ring_heartbeat(r);
+    if (r->defer_service && r->svc == SvcState::Stopped) {
+        // Profiling mode (PBSGPU_RING_DEFER_SERVICE=1; scripts/r4_ring_pmc.py): the rounds have only filled the queue. Now
+        // the service runs ALONE over everything published, `stop` already raised, and ends — one ordinary dispatch that
+        // rocprofv3's counter passes (which serialise dispatches) can measure: k_sha256_pair<RingSource,false> with every
+        // lane busy, reading chunks that cross pages, releasing pages. (The arena must hold what was fed: no page comes
+        // back before this point.)
+        HIPCHK(hipStreamSynchronize(r->cs));
+        HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
+        HIPCHK(hipEventRecord(r->ev_reset, r->cs));
+        HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));
+        HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
+        HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
+        HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
+        g_services.fetch_add(1, std::memory_order_acq_rel);
+        r->svc = SvcState::Running;
+        r->st.service_launches++;
+        HIPCHK(hipStreamSynchronize(r->ss));
+        ring_service_ended(r);
+        HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));  // head := tail, stop := 0 for the next batch of rounds
+        HIPCHK(hipStreamSynchronize(r->cs));
+        r->svc_bytes0 = r->st.bytes_enqueued;
+        ring_reap_free(r);
+        ring_reap_rounds(r);
+        return r->error;
+    }
     if (r->svc == SvcState::Running) {
         CHK(ring_service_check(r, false));  // (it may have stopped on its own in the meantime)
         if (r->svc == SvcState::Running) HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));

@@ -102,6 +102,7 @@ struct pbsgpu_ring {
     uint32_t rounds_enq = 0;              // mirrored into the heartbeat block for the service's self-stop handshake
     double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
     double idle_since_ms = 0;
+    bool defer_service = false;           // PBSGPU_RING_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
     double idle_timeout_s = 0;            // > 0: the service's own idle stop (default 20 s; PBSGPU_RING_IDLE_TIMEOUT_S overrides)
     // host bookkeeping
     std::vector<uint32_t> free_pages;
