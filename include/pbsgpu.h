@@ -335,6 +335,18 @@ int pbsgpu_ring_commit(pbsgpu_ring *ring, uint32_t stream, uint64_t nbytes, int 
  * pages as are free: *taken bytes were accepted, call again with the rest after a pump. */
 int pbsgpu_ring_fill(pbsgpu_ring *ring, uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, int final,
                      uint64_t *taken);
+/* Synthetic producer for EDITED streams (benchmarks: BASELINE.json configs[4], the re-chunk after byte edits, through the
+ * ring): the stream's bytes are a piece table over generator 4 of pbsgpu_fill_device — kept extents of a base file and
+ * newly written extents in stream order, pieces contiguous from 0, every offset and length a multiple of 16. The first
+ * call hands the table over (copied), later calls pass NULL / 0 and continue; nbytes / final / *taken as pbsgpu_ring_fill. */
+typedef struct pbsgpu_fill_piece {
+    uint64_t dst_off; /* offset in the stream */
+    uint64_t len;
+    uint64_t src_off; /* generator offset the piece's first byte comes from */
+    uint64_t seed;    /* generator seed (the base file's, or the new bytes') */
+} pbsgpu_fill_piece;
+int pbsgpu_ring_fill_pieces(pbsgpu_ring *ring, uint32_t stream, const pbsgpu_fill_piece *pieces, uint32_t npieces,
+                            uint64_t nbytes, int final, uint64_t *taken);
 /* Enqueue the committed pages as cut rounds, collect finished rounds and freed pages. Never blocks. */
 int pbsgpu_ring_pump(pbsgpu_ring *ring);
 /* Up to cap finished records of the stream, in stream order; *finished = 1 once the stream has ended and every record

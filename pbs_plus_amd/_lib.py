@@ -165,6 +165,7 @@ SYMBOLS = {
     "pbsgpu_ring_close": (C.c_int, [_P, C.c_uint32]),
     "pbsgpu_ring_quiesce": (C.c_int, [_P]),
     "pbsgpu_ring_park": (C.c_int, [_P]),
+    "pbsgpu_ring_fill_pieces": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.c_uint64, C.c_int, _U64P]),
     "pbsgpu_ring_suggest": (C.c_int, [_P, C.c_uint32, C.c_uint64]),
     "pbsgpu_ring_get_stats": (C.c_int, [_P, C.POINTER(RingStats)]),
     "pbsgpu_ring_debug": (C.c_int, [_P, C.c_char_p, C.c_uint64]),

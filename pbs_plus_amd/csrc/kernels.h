@@ -241,8 +241,17 @@ struct RingPage {
     uint32_t seg;          // index of the stream's segment entry in this round
     uint64_t fill_seed;    // synthetic producer (bench / tests): generator seed, kind and stream offset
     uint64_t fill_off;
-    uint32_t fill_kind;
+    uint32_t fill_kind;    // 0..4: pbsgpu_fill_device's generators; 5: piece table (fill_tab) over generator 4
     uint32_t do_fill;
+    const struct FillPiece *fill_tab;  // kind 5: the stream's piece table (mapped pinned), ascending dst_off, contiguous
+    uint32_t fill_ntab;
+    uint32_t pad;
+};
+// One piece of a synthetic EDITED stream (BASELINE.json configs[4] through the ring): stream bytes [dst_off, dst_off + len)
+// are generator 4's bytes (seed) at [src_off, src_off + len) — a kept extent of the base file, or newly written bytes.
+// All three offsets / lengths are multiples of 16 (the generator's block).
+struct FillPiece {
+    uint64_t dst_off, len, src_off, seed;
 };
 // One stream of a round.
 struct RingSeg {

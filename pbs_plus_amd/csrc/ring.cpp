@@ -251,6 +251,8 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
             p.fill_seed = q.seed;
             p.fill_off = q.fill_off;
             p.fill_kind = q.kind;
+            p.fill_tab = q.tab;
+            p.fill_ntab = q.ntab;
             pg[np++] = p;
             if (q.dep) deps.push_back(q.dep);
             end += q.valid;
@@ -676,6 +678,8 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         HIPCHK(hipEventCreate(&r->ev_svc0));
         HIPCHK(hipEventCreate(&r->ev_svc1));
         r->slots.resize(r->max_streams);
+        r->piece_tab.resize(r->max_streams);
+        r->piece_n.assign(r->max_streams, 0);
         r->free_pages.reserve(r->npages);
         for (uint32_t p = r->npages; p-- > 0;) r->free_pages.push_back(p);  // page 0 is handed out first
         r->st.pages_total = r->npages;
@@ -784,6 +788,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         r->free_fifo.release();
         r->inputs.release();
         for (auto &b : r->sugg_in) b.release();
+        for (auto &b : r->piece_tab) b.release();
     }
     const bool unref = r->holds_engine_ref;
     delete r;
@@ -796,6 +801,7 @@ int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
         if (!r->slots[i].open) {
             r->slots[i] = StreamSlot{};
             r->slots[i].open = true;
+            if (i < r->piece_n.size()) r->piece_n[i] = 0;  // (a piece table left behind by the slot's previous stream is not this one's)
             *stream = i;
             r->st.streams_opened++;
             return PBSGPU_OK;
@@ -884,6 +890,68 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
         q.seed = seed;
         q.kind = kind;
         q.fill_off = s.bytes_committed;  // the generator's stream offset = the page's offset in its stream
+        s.ready.push_back(q);
+        r->ready_bytes += n;
+        s.bytes_committed += n;
+        *taken += n;
+        if (q.final) s.final_committed = true;
+    }
+    return PBSGPU_OK;
+}
+
+// Synthetic producer for EDITED streams (BASELINE.json configs[4] through the ring): the stream's bytes are defined by a
+// piece table over generator 4 — kept extents of a base file and newly written extents, in stream order. The first call
+// hands the table over (it is copied; pieces ascending and contiguous from 0, offsets and lengths multiples of 16), later
+// calls pass NULL / 0 and continue. Otherwise like pbsgpu_ring_fill.
+int pbsgpu_ring_fill_pieces(pbsgpu_ring *r, uint32_t stream, const pbsgpu_fill_piece *pieces, uint32_t npieces, uint64_t nbytes,
+                            int final, uint64_t *taken) {
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    static_assert(sizeof(pbsgpu_fill_piece) == sizeof(pbsk::FillPiece), "piece layout");
+    StreamSlot &s = r->slots[stream];
+    *taken = 0;
+    if (s.failed) return PBSGPU_E_DENSITY;
+    if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
+    if (r->error != PBSGPU_OK) return r->error;
+    if (pieces) {
+        if (npieces == 0 || s.bytes_committed != 0) return PBSGPU_E_INVALID;  // the table comes with the stream's first bytes
+        uint64_t pos = 0;
+        for (uint32_t i = 0; i < npieces; ++i) {
+            if (pieces[i].dst_off != pos || pieces[i].len == 0 || ((pieces[i].dst_off | pieces[i].len | pieces[i].src_off) & 15u))
+                return PBSGPU_E_INVALID;
+            pos += pieces[i].len;
+        }
+        CHK(r->piece_tab[stream].ensure(std::max<size_t>((size_t)npieces * sizeof(pbsk::FillPiece), 4096)));
+        std::memcpy(r->piece_tab[stream].p, pieces, (size_t)npieces * sizeof(pbsk::FillPiece));
+        r->piece_n[stream] = npieces;
+    }
+    const uint32_t nt = r->piece_n[stream];
+    if (nt == 0) return PBSGPU_E_STATE;
+    const pbsk::FillPiece *tab = r->piece_tab[stream].as<pbsk::FillPiece>();
+    const uint64_t total = tab[nt - 1].dst_off + tab[nt - 1].len;
+    if (s.bytes_committed + nbytes > total || s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;
+    if (nbytes == 0) {
+        if (final) {
+            s.zero_final = true;
+            s.final_committed = true;
+        }
+        return PBSGPU_OK;
+    }
+    while (*taken < nbytes) {
+        const uint64_t n = std::min<uint64_t>(r->page_bytes, nbytes - *taken);
+        const bool last = (*taken + n == nbytes);
+        if (n < r->page_bytes && !(last && final)) break;
+        uint32_t phys = 0;
+        if (ring_take_page(r, &phys) != PBSGPU_OK) break;
+        PageReq q;
+        q.phys = phys;
+        q.k = s.next_k++;
+        q.valid = (uint32_t)n;
+        q.final = last && final;
+        q.do_fill = true;
+        q.kind = 5;
+        q.tab = tab;
+        q.ntab = nt;
+        q.fill_off = s.bytes_committed;
         s.ready.push_back(q);
         r->ready_bytes += n;
         s.bytes_committed += n;

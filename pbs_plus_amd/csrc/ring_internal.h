@@ -22,6 +22,8 @@ struct PageReq {                          // a committed page waiting for its ro
     bool do_fill = false;
     uint64_t seed = 0, fill_off = 0;
     uint32_t kind = 0;
+    const pbsk::FillPiece *tab = nullptr;  // kind 5: the stream's piece table
+    uint32_t ntab = 0;
     hipEvent_t dep = nullptr;             // the page's bytes are there once this event has completed (host-fed pages: the
                                           // H2D copy, or the XXH3 tee behind it); from the ring's event pool, returned at enqueue
 };
@@ -91,6 +93,8 @@ struct pbsgpu_ring {
     pbse::DevBuf seg_ecand_in, seg_ecand, seg_fail;
     // mapped pinned
     pbse::PinnedBuf cells, free_fifo, inputs, heartbeat;
+    std::vector<pbse::PinnedBuf> piece_tab;      // per stream slot: the piece table of a synthetic edited stream (fill_pieces)
+    std::vector<uint32_t> piece_n;
     pbse::PinnedBuf sugg_in[pbse::kRingInputs];  // suggested offsets of the round built in input i (grown on demand)
     size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_segstat_off = 0, in_recbase_off = 0, in_suggidx_off = 0,
            in_status_off = 0;

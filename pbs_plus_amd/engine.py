@@ -534,6 +534,18 @@ class PageRing:
               "ring_fill")
         return t.value
 
+    def fill_pieces(self, stream: int, pieces, nbytes: int, final: bool = False) -> int:
+        """Synthetic producer for an EDITED stream: `pieces` = (n, 4) uint64 rows (dst_off, len, src_off, seed) over
+        generator 4 with the stream's first call, None afterwards. Bytes accepted, as fill()."""
+        t = C.c_uint64()
+        if pieces is not None:
+            a = np.ascontiguousarray(pieces, dtype=np.uint64).reshape(-1, 4)
+            ptr, n = a.ctypes.data, a.shape[0]
+        else:
+            ptr, n = None, 0
+        check(self._L.pbsgpu_ring_fill_pieces(self._h, stream, ptr, n, int(nbytes), int(final), C.byref(t)), "ring_fill_pieces")
+        return t.value
+
     def pump(self) -> None:
         check(self._L.pbsgpu_ring_pump(self._h), "ring_pump")
 

@@ -158,6 +158,26 @@ class _FakeRing:
         self.bytes += take
         return take
 
+    def fill_pieces(self, sid, pieces, nbytes, final=False):
+        st = self.streams[sid]
+        if pieces is not None:
+            st["table"] = np.asarray(pieces, dtype=np.uint64).reshape(-1, 4)
+            assert int(st["table"][0, 0]) == 0 and not (st["table"][:, :3] & 15).any()
+        take = min(nbytes, 3 * self.PAGE)
+        if take < nbytes:
+            take -= take % self.PAGE
+        off = sum(p.size for p in st["parts"])
+        out = np.empty(take, dtype=np.uint8)
+        for dst, ln, so, seed in st["table"]:                 # the stand-in's "device generator": the oracle's twin, piece by piece
+            lo, hi = max(int(dst), off), min(int(dst + ln), off + take)
+            if lo < hi:
+                self.eng.O.fill(hi - lo, int(seed), 4, stream_off=int(so) + lo - int(dst), out=out[lo - off:hi - off])
+        st["parts"].append(out)
+        if take == nbytes and final:
+            st["final"] = True
+        self.bytes += take
+        return take
+
     def pump(self):
         if not self.running:
             self.running = True
@@ -434,7 +454,7 @@ def test_bench_ring_two_ranks_gloo_reduces_in_step_order():
     assert st["nrecords"] > 0 and st["nunique"] == st["nrecords"]        # two different files: no shared chunks
 
 
-@pytest.mark.parametrize("mode", ["ring_manyfiles", "ring_corpus_dup"])
+@pytest.mark.parametrize("mode", ["ring_manyfiles", "ring_corpus_dup", "ring_rechunk"])
 def test_bench_many_files_through_the_ring(monkeypatch, mode):
     """configs[2] / configs[3] with one ring stream per file (poll_any): whole sampled files vs the oracle, every file tiled
     by its records, planted duplicates found exactly."""
@@ -447,6 +467,10 @@ def test_bench_many_files_through_the_ring(monkeypatch, mode):
     if mode == "ring_corpus_dup":
         dd = d["results"]["dedup"]
         assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9 and dd["expected_duplicate_frac"] > 0.15
+    if mode == "ring_rechunk":                # configs[4]: the edited corpus re-uses most chunks of the snapshot ingested before
+        rr = d["results"]
+        assert 0.3 < rr["reused_chunk_bytes_frac"] < 1.0 and rr["base_snapshot_chunks"] > 50
+        assert abs(rr["edited_bytes"] - 3 * 24 * (512 << 10)) < 0.05 * 3 * 24 * (512 << 10)
 
 
 def test_bench_gpus_flag_spawns_its_own_ranks_and_every_rank_is_checked():

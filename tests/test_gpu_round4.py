@@ -147,13 +147,13 @@ def test_a_dense_payload_stream_fails_alone_and_the_device_is_free_after_finish(
     finish() of the last stream the ring's persistent service has been parked: a device-wide synchronisation (what a
     host does before freeing memory or handing the GPU to someone else) returns at once instead of waiting for a kernel
     that only ends on request."""
-    import torch
+    import ctypes as C
 
     from pbs_plus_amd import PayloadStream, PbsGpuError, _lib
 
-    torch.zeros(1, device="cuda")
-    torch.cuda.synchronize()                                      # (torch's own context is up: the timing below is the ring's)
     eng = _engine(4096)
+    hip = C.CDLL("libamdhip64.so.7", mode=os.RTLD_NOLOAD)         # the runtime instance libpbsgpu.so is linked against
+    hip.hipDeviceSynchronize.restype = C.c_int
     cfg = O.new_config(4096)
     pat = None
     rng = np.random.default_rng(5)
@@ -185,7 +185,7 @@ def test_a_dense_payload_stream_fails_alone_and_the_device_is_free_after_finish(
     want = O.chunk_and_digest(cfg, good, [(0, good.size)])
     assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
     t0 = time.time()
-    torch.cuda.synchronize()
+    assert hip.hipDeviceSynchronize() == 0
     assert time.time() - t0 < 1.0, "a device-wide synchronisation after finish() waited for the ring's service"
     ko.close()
     ok.close()
@@ -240,3 +240,48 @@ def test_bench_ring_forced_dist_runs_the_c_abi_reduce_beside_torch(gpu_lib):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     c = d["results"]["c_abi_digest_reduce"]
     assert c["ok"] is True and c["equals_torch_path"] is True and c["stats"]["nrecords"] > 0, c
+
+
+def test_ring_piece_table_producer_matches_the_host_rebuild(gpu_lib, O):
+    """pbsgpu_ring_fill_pieces (the synthetic producer of BASELINE configs[4] through the ring): a stream defined by a piece
+    table over generator 4 — kept extents of a base file interleaved with new bytes, pieces crossing page edges, a short
+    last page — is cut and hashed exactly like the same bytes rebuilt on the host from the oracle's generator twin."""
+    from pbs_plus_amd import PageRing
+
+    eng = _engine(4096)
+    cfg = O.new_config(4096)
+    rng = np.random.default_rng(3)
+    rows, pos, npos, src = [], 0, 0, 0
+    for i in range(60):
+        ln = int(rng.integers(1, 6000)) * 16
+        if i % 3 == 1:                                   # new bytes
+            rows.append((pos, ln, npos, 777))
+            npos += ln
+        else:                                            # kept extent (an occasional deletion in between)
+            src += int(rng.integers(0, 300)) * 16 * (i % 2)
+            rows.append((pos, ln, src, 555))
+            src += ln
+        pos += ln
+    host = np.empty(pos, dtype=np.uint8)
+    for dst, ln, so, seed in rows:
+        O.fill(ln, seed, 4, stream_off=so, out=host[dst:dst + ln])
+    want = O.chunk_and_digest(cfg, host, [(0, pos)])
+    ring = PageRing(eng, arena_bytes=64 * (65536 + 256), page_bytes=65536, max_streams=4, sha_cus=4, round_pages=6)
+    sid = ring.open()
+    left, first, got, fin = pos, True, [], False
+    t0 = time.time()
+    while not fin and time.time() - t0 < 60:
+        if left:
+            want_n = min(left, 5 * 65536)
+            left -= ring.fill_pieces(sid, np.array(rows, dtype=np.uint64) if first else None, want_n, final=(want_n == left))
+            first = False
+        ring.pump()
+        recs, fin = ring.poll(sid)
+        got.append(recs.copy())
+    assert fin
+    got = np.concatenate(got)
+    assert np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+    ring.close_stream(sid)
+    ring.quiesce()
+    ring.close()
+    eng.close()
