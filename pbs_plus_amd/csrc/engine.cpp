@@ -524,98 +524,6 @@ int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nby
     return PBSGPU_OK;
 }
 
-int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes) {
-    const uint32_t tile_bytes = std::min(pbsk::scan_tile_bytes(max_bytes), pbsk::scan_tile_bytes(1));
-    const uint64_t ntiles = (max_bytes + 256) / tile_bytes + 2;
-    const uint32_t cap = std::max(default_cap(e, max_bytes), default_cap(e, 1)) * 2;
-    const uint64_t rec_cap = max_bytes / std::min(e->effmin, e->cfg.min) + 4;
-    CHK(s.tile_cnt.ensure((size_t)ntiles * 4 + 16));
-    CHK(s.tile_off.ensure((size_t)ntiles * 4 + 16));
-    CHK(s.tile_slots.ensure((size_t)ntiles * cap * 4 + 16));
-    CHK(s.dense.ensure((size_t)ntiles * cap * 8 + 16));
-    CHK(s.scan_tmp.ensure(pbsk::scan_tmp_words(ntiles) * 4));
-    CHK(s.scalars.ensure(SC_COUNT * 4));
-    CHK(s.segs.ensure(4 * sizeof(pbsgpu_segment)));
-    CHK(s.seg_cnt.ensure(64));
-    CHK(s.seg_off.ensure(64));
-    CHK(s.recs.ensure((size_t)rec_cap * sizeof(pbsgpu_record) + 64));
-    CHK(s.order.ensure((size_t)rec_cap * pbsk::kQueueDescBytes + 64));
-    CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
-    CHK(s.h_segs.ensure(4 * sizeof(pbsgpu_segment)));
-    CHK(s.h_sugg.ensure(64 << 10));
-    CHK(s.h_recs.ensure((size_t)rec_cap * sizeof(pbsgpu_record) + 64));
-    return PBSGPU_OK;
-}
-
-int cut_enqueue(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
-                uint32_t nseg, const SuggestedHost *sg) {
-    CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
-    CHK(stage_segments(e, s, segs, nseg, nbytes, sg));
-    CHK(s.h_recs.ensure((size_t)s.rec_cap * sizeof(pbsgpu_record) + 64));
-    s.dptr = dptr;
-    s.nbytes = nbytes;
-    s.host_submit = false;
-    s.retries = 0;
-    s.synced = false;
-    CHK(enqueue_cut(e, s, default_cap(e, nbytes)));
-    HIPCHK(pbsk::launch_publish(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, s.stream));
-    HIPCHK(pbsk::launch_publish_records(s.h_recs.as<pbsgpu_record>(), s.recs.as<pbsgpu_record>(),
-                                        s.scalars.as<uint32_t>() + SC_NREC, s.rec_cap, s.stream));
-    HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
-    return PBSGPU_OK;
-}
-
-int cut_finish(pbsgpu_engine *e, Slot &s, uint64_t *nrec) {
-    HIPCHK(hipEventSynchronize(s.ev[EV_SHA1]));
-    uint32_t cap = s.cap;
-    for (;;) {
-        const uint32_t *hs = s.h_scalars.as<uint32_t>();
-        if (hs[SC_MAXCNT] <= cap) break;
-        while (cap < hs[SC_MAXCNT]) cap <<= 1;
-        if (cap > pbsk::scan_tile_bytes(s.nbytes)) cap = pbsk::scan_tile_bytes(s.nbytes);
-        s.retries++;
-        CHK(enqueue_cut(e, s, cap));
-        HIPCHK(pbsk::launch_publish(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, s.stream));
-        HIPCHK(pbsk::launch_publish_records(s.h_recs.as<pbsgpu_record>(), s.recs.as<pbsgpu_record>(),
-                                            s.scalars.as<uint32_t>() + SC_NREC, s.rec_cap, s.stream));
-        HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
-        HIPCHK(hipEventSynchronize(s.ev[EV_SHA1]));
-    }
-    s.nrec = s.h_scalars.as<uint32_t>()[SC_NREC];
-    s.ncand = s.h_scalars.as<uint32_t>()[SC_NCAND];
-    if (s.nrec > s.rec_cap) return PBSGPU_E_STATE;
-    *nrec = s.nrec;
-    return PBSGPU_OK;
-}
-
-// phase 1 only, synchronous (streaming writer): records WITHOUT digests stay in s.recs
-int cut_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
-             uint32_t nseg, const SuggestedHost *sg, uint64_t *nrec) {
-    CHK(s.h_scalars.ensure(SC_COUNT * 4 + 64));
-    CHK(stage_segments(e, s, segs, nseg, nbytes, sg));
-    s.dptr = dptr;
-    s.nbytes = nbytes;
-    s.host_submit = false;
-    s.retries = 0;
-    s.synced = false;
-    uint32_t cap = default_cap(e, nbytes);
-    for (;;) {
-        CHK(enqueue_cut(e, s, cap));
-        HIPCHK(pbsk::launch_publish(s.h_scalars.p, s.scalars.p, SC_COUNT * 4, s.stream));
-        HIPCHK(hipStreamSynchronize(s.stream));
-        const uint32_t *hs = s.h_scalars.as<uint32_t>();
-        if (hs[SC_MAXCNT] <= cap) break;
-        while (cap < hs[SC_MAXCNT]) cap <<= 1;
-        if (cap > pbsk::scan_tile_bytes(nbytes)) cap = pbsk::scan_tile_bytes(nbytes);
-        s.retries++;
-    }
-    s.nrec = s.h_scalars.as<uint32_t>()[SC_NREC];
-    s.ncand = s.h_scalars.as<uint32_t>()[SC_NCAND];
-    if (s.nrec > s.rec_cap) return PBSGPU_E_STATE;
-    *nrec = s.nrec;
-    return PBSGPU_OK;
-}
-
 }  // namespace pbse
 
 // =====================================================================================

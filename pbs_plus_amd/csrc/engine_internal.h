@@ -269,20 +269,8 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
 int staged_h2d(Slot &s, void *dst, const void *src, uint64_t nbytes, hipStream_t st);
 int stage_segments(pbsgpu_engine *e, Slot &s, const pbsgpu_segment *segs, uint32_t nseg, uint64_t nbytes,
                    const SuggestedHost *sg);
-// synchronous helpers for the streaming front ends (the caller owns the slot)
+// synchronous helper for the upstream-style chunker (the caller owns the slot)
 int candidates_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, uint64_t *count);
-int cut_sync(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
-             uint32_t nseg, const SuggestedHost *sg, uint64_t *nrec);
-// asynchronous pair for the streaming writer: cut_enqueue queues the cut plus the publication of its scalars and
-// records into the slot's mapped pinned buffers (h_scalars, h_recs) and returns; cut_finish waits for exactly that
-// work (an event, not the stream: the stream already carries the next window's copies) and re-runs the cut
-// synchronously in the rare case that a scan tile overflowed its candidate capacity
-int cut_enqueue(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t nbytes, const pbsgpu_segment *segs,
-                uint32_t nseg, const SuggestedHost *sg);
-int cut_finish(pbsgpu_engine *e, Slot &s, uint64_t *nrec);
-// size every buffer a single-segment cut of up to max_bytes can touch, so that steady-state windows never reallocate
-int presize_cut(pbsgpu_engine *e, Slot &s, uint64_t max_bytes);
-
 // Caller bytes -> pinned staging. One thread copies ~12 GB/s, the H2D engine moves 57 GB/s: a single writer (the
 // reference drives ONE goroutine per archive, internal/tapeio/converter.go:672-680) was memcpy-bound at 24-28 GiB/s.
 // Large copies are therefore split over a few helper threads of a process-wide pool (started at the first large

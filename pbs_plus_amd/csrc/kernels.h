@@ -129,15 +129,6 @@ constexpr size_t kQueueDescBytes = 16;
 hipError_t launch_order(const uint8_t *data, const pbsgpu_segment *segs, const pbsgpu_record *recs, const uint32_t *nrec,
                         uint32_t max_chunk, uint4 *qdesc, uint32_t *wg_limit, int num_cus, const uint32_t *maxcnt, uint32_t cap, uint32_t slack_pct,
                         hipStream_t st);
-// SHA-256 of explicit (pointer, length) descriptors — the shared hash jobs of the streaming writers. digests[32*i]
-// for descs[i]; `order` = longest-first permutation (may be null); `workgroups` = CU budget of the launch.
-struct HashDesc {
-    const uint8_t *ptr;
-    uint64_t len;
-};
-// `dense` = run four producer/consumer pairs per CU instead of two (sha256_dense_pays() decides; kernels.hip)
-hipError_t launch_sha256_descs(const HashDesc *descs, uint32_t n, const uint32_t *order, uint8_t *digests,
-                               uint32_t *queue, unsigned workgroups, bool dense, hipStream_t st);
 // true when a hash launch of `total_blocks` 64-byte blocks whose longest item has `longest_blocks` is bound by issue
 // slots rather than by that longest chain (the device-side twin of this test lives in k_order)
 bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus);

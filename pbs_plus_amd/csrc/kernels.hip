@@ -1472,21 +1472,6 @@ struct SegmentSource {
     }
 };
 
-// explicit (pointer, length) descriptors: the shared hash jobs of the streaming writers (chunks of many windows and
-// many streams in one launch); digest i lands at digests + 32 * i
-struct DescSource {
-    static constexpr bool kRing = false;
-    const HashDesc *d;
-    uint8_t *digests;
-    const uint32_t *order;  // queue position -> descriptor index (longest first), may be null
-    __device__ __forceinline__ void get(uint32_t i, const uint8_t *&ptr, uint64_t &len, uint8_t *&dst) const {
-        if (order) i = order[i];
-        ptr = d[i].ptr;
-        len = d[i].len;
-        dst = digests + (uint64_t)i * 32;
-    }
-};
-
 // The page ring's SHA-256 SERVICE (ring.cpp): one persistent launch whose lanes pull chunk descriptors from a
 // device-resident FIFO that the cut rounds of ALL streams append to (k_ring_order / k_ring_publish), so a chunk starts
 // hashing the moment it has been cut, whichever round, stream or page it came from, and every lane that finishes a chunk
@@ -2232,17 +2217,6 @@ hipError_t launch_sha256_records(pbsgpu_record *recs, const uint32_t *nrec, uint
         hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u), dim3(64), pad, st, src, nrec, 0u,
                            queue, wg_limit, 0u);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_sha256_descs(const HashDesc *descs, uint32_t n, const uint32_t *order, uint8_t *digests,
-                               uint32_t *queue, unsigned workgroups, bool dense, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    DescSource src{descs, digests, order};
-    const unsigned need = (n + (dense ? 255u : 127u)) / (dense ? 256u : 128u);
-    if (workgroups > need) workgroups = need;
-    if (workgroups < 1) workgroups = 1;
-    return launch_pair(workgroups, dense, st, src, n, queue);
     return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ def test_sha256_pair_forms_keep_their_cu_residency(usage):
         assert 2 * r["lds"] > LDS_PER_CU and r["lds"] <= LDS_PER_CU, r   # one 8-wave workgroup per CU, no padding needed
         assert r["vgprs"] <= 256 and r["occupancy"] >= 2, r              # two waves per SIMD must fit
     # every source type has both forms
-    for src in ("RecordSource", "DescSource", "SegmentSource"):
+    for src in ("RecordSource", "SegmentSource"):
         assert _find(usage, "k_sha256_pair", src, "Lb0E") and _find(usage, "k_sha256_pair", src, "Lb1E")
 
 
