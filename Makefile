@@ -1,5 +1,5 @@
 # Convenience targets (the driver uses __graft_entry__.py / pytest / bench.py directly).
-.PHONY: build test gpu-test bench clean
+.PHONY: build test gpu-test bench clean golden-go
 build:
 	python -c "import __graft_entry__ as g; g.build()"
 test: build
@@ -11,3 +11,10 @@ bench: build             # needs an MI355X
 clean:
 	$(MAKE) -C pbs_plus_amd/csrc clean
 	$(MAKE) -C oracle clean
+
+# Golden vectors from the REAL Go module (github.com/pbs-plus/pxar v0.34.0) — needs Go + module access, neither of which the
+# build image has (tools/golden/README.md). The fixture tests pick tests/golden/chunks_go.json up automatically.
+golden-go:
+	cd tools/golden && go mod tidy && go run . > ../../tests/golden/chunks_go.json.tmp
+	mv tests/golden/chunks_go.json.tmp tests/golden/chunks_go.json
+	@echo "wrote tests/golden/chunks_go.json - now: python -m pytest tests/test_oracle_buzhash.py -k golden -q"

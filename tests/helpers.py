@@ -72,6 +72,33 @@ def load_golden(name):
         return json.load(f)
 
 
+def golden_files():
+    """every tests/golden/chunks_*.json: the committed fixture (the oracle's own output) and — once a maintainer has run
+    `make golden-go` — chunks_go.json from the REAL Go module (tools/golden/README.md), picked up automatically"""
+    return sorted(f for f in os.listdir(GOLDEN_DIR) if f.startswith("chunks_") and f.endswith(".json"))
+
+
+def golden_case_data(O, case):
+    """(bytes, segment table) of one golden case, rebuilt from its generator description"""
+    if case["segments"] == "le_u32_counter_262144":
+        data = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
+        return data, [(0, data.size)]
+    parts, table, off = [], [], 0
+    for s in case["segments"]:
+        parts.append(O.fill(s["length"], s["seed"], s["kind"]))
+        table.append((off, s["length"]))
+        off += s["length"]
+    return np.concatenate(parts), table
+
+
+def golden_suggested_data(O, case):
+    """bytes of a `suggested` case of schema v2 (tools/golden/main.go): the LE-u32 counter buffer or a splitmix64 stream"""
+    n = int(case["length"])
+    if case["name"].startswith("counter"):
+        return np.arange(n // 4, dtype="<u4").view(np.uint8)
+    return O.fill(n, int(case["seed"]), 0)
+
+
 def golden_records(case, dtype):
     out = np.zeros(len(case["records"]), dtype=dtype)
     for i, (seg, end, size, dig) in enumerate(case["records"]):

@@ -8,7 +8,8 @@ import hashlib
 import numpy as np
 import pytest
 
-from helpers import describe_mismatch, golden_records, load_golden, records_equal
+from helpers import (describe_mismatch, golden_case_data, golden_files, golden_records, golden_suggested_data, load_golden,
+                     records_equal)
 
 pytestmark = pytest.mark.gpu
 
@@ -138,26 +139,29 @@ def test_misaligned_chunk_starts_hash_correctly(engines):
         assert start == data.size
 
 
-def test_golden_fixture_on_gpu(engines, O):
-    g = load_golden("chunks_v1.json")
+@pytest.mark.parametrize("fixture", golden_files())
+def test_golden_fixture_on_gpu(engines, O, fixture):
+    """every tests/golden/chunks_*.json through the C ABI: the committed fixture, and the REAL Go module's vectors
+    (chunks_go.json, `make golden-go`) as soon as a maintainer has produced them — records and, for schema v2, the
+    suggested-boundary cuts at every reader-buffer size"""
+    g = load_golden(fixture)
     from pbs_plus_amd import RECORD_DTYPE
 
     for case in g["cases"]:
         eng = engines(case["avg"])
-        if case["segments"] == "le_u32_counter_262144":
-            data = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
-            got = eng.chunk_and_digest(data)
-        else:
-            segs = [(s["seed"], s["kind"], s["length"]) for s in case["segments"]]
-            # golden segments are packed back to back (no alignment padding): build on the host
-            parts, table, off = [], [], 0
-            for seed, kind, n in segs:
-                parts.append(O.fill(n, seed, kind))
-                table.append((off, n))
-                off += n
-            got = eng.chunk_and_digest(np.concatenate(parts), table)
+        data, table = golden_case_data(O, case)   # golden segments are packed back to back (no alignment padding): built on the host
+        got = eng.chunk_and_digest(data, table if len(table) > 1 else None)
         want = golden_records(case, RECORD_DTYPE)
-        assert records_equal(got, want), case["name"] + "\n" + describe_mismatch(got, want)
+        assert records_equal(got, want), fixture + " " + case["name"] + "\n" + describe_mismatch(got, want)
+    for case in g.get("suggested", []):
+        eng = engines(case["avg"])
+        data = golden_suggested_data(O, case)
+        eng.set_suggested_feed(int(case["feed"]), False)
+        try:
+            got = eng.chunk_and_digest(data, [(0, data.size)], suggested=[sorted(case["suggested"])])
+        finally:
+            eng.set_suggested_feed(1, False)
+        assert got["end"].tolist() == [int(e) for e in case["ends"]], (fixture, case["name"], case["feed"])
 
 
 def test_sha256_many_all_padding_lengths(engines):

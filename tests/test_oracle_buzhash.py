@@ -14,7 +14,8 @@ reference's own tests pin no boundary — SURVEY.md §8c). What is checked here:
 import numpy as np
 import pytest
 
-from helpers import golden_records, load_golden, records_equal, resolve_model
+from helpers import (golden_case_data, golden_files, golden_records, golden_suggested_data, load_golden, records_equal,
+                     resolve_model)
 
 
 def test_config_derivation(O):
@@ -191,26 +192,32 @@ def test_segments_are_independent_streams(O):
     assert int(recs["size"].sum()) == both.size
 
 
-def test_golden_fixture(O):
-    """tests/golden/chunks_v1.json was produced by tests/golden/make_golden.py; the oracle
-    must keep reproducing it (and the GPU engine is compared with the same file)."""
-    g = load_golden("chunks_v1.json")
-    assert g["schema"] == "pbsgpu-golden-v1"
+@pytest.mark.parametrize("fixture", golden_files())
+def test_golden_fixture(O, fixture):
+    """tests/golden/chunks_v1.json was produced by tests/golden/make_golden.py (the oracle's own output: a regression
+    pin, not a parity pin); tests/golden/chunks_go.json — when a maintainer has run `make golden-go` — comes from the REAL
+    github.com/pbs-plus/pxar module and IS the parity pin: the oracle must reproduce every record of it, the suggested-
+    boundary cuts at every reader-buffer size, and its Config derivation is compared with the module's field dump."""
+    g = load_golden(fixture)
+    assert g["schema"] in ("pbsgpu-golden-v1", "pbsgpu-golden-v2")
     for case in g["cases"]:
         cfg = O.new_config(case["avg"])
-        if case["segments"] == "le_u32_counter_262144":
-            data = np.arange(256 * 1024, dtype="<u4").view(np.uint8)
-            table = [(0, data.size)]
-        else:
-            parts, table, off = [], [], 0
-            for s in case["segments"]:
-                parts.append(O.fill(s["length"], s["seed"], s["kind"]))
-                table.append((off, s["length"]))
-                off += s["length"]
-            data = np.concatenate(parts)
+        data, table = golden_case_data(O, case)
         got = O.chunk_and_digest(cfg, data, table, impl=1)
         want = golden_records(case, O.RECORD_DTYPE)
-        assert records_equal(got, want), case["name"]
+        assert records_equal(got, want), (fixture, case["name"])
+    for case in g.get("suggested", []):
+        cfg = O.new_config(case["avg"])
+        data = golden_suggested_data(O, case)
+        ends = O.chunk_stream_suggested(cfg, data, sorted(case["suggested"]), feed=int(case["feed"]))
+        assert ends.tolist() == [int(e) for e in case["ends"]], (fixture, case["name"], case["feed"])
+    for avg, fields in (g.get("config") or {}).items():   # the module's Config, as reflection saw it: name what differs
+        cfg = O.new_config(int(avg))
+        ours = {"min": cfg.min, "max": cfg.max, "avg": cfg.avg, "window": cfg.window, "mask": cfg.mask, "break_min": cfg.break_min}
+        flat = {str(k).lower().replace("_", ""): v for k, v in fields.items() if isinstance(v, (int, float))}
+        for key, val in ours.items():
+            hits = [v for k, v in flat.items() if key.replace("_", "") in k]
+            assert not hits or int(val) in [int(h) for h in hits], (fixture, avg, key, val, fields)
 
 
 def test_fill_is_offset_consistent(O):
