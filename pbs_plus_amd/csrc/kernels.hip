@@ -1855,14 +1855,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
                 dstv[s] = dst;
-                if constexpr (Source::kRing) {
-                    pagesv[s] = pages;
-                    // bit 2: the LAST block that starts in the chunk's first page (it reads on into that page's tail pad):
-                    // with it in registers the first page is done with — released then, not when the whole chunk has been
-                    // read (a 16 MiB chunk spans two pages and hashes for 0.46 s: its first page comes back after its own
-                    // share of that, which is what mixed-entropy corpora — half their bytes in max-size chunks — wait for)
-                    if ((pages >> 16) != 0xffffu && off < len1 && off + 64 >= len1) c |= 4u;
-                }
+                if constexpr (Source::kRing) pagesv[s] = pages;
                 if (++blk == nblk) have = false;
             }
             cflag[s] = c;
@@ -1883,20 +1876,18 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     const uint32_t c = cflag[s];
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
-                        // The chunk's LAST block (or the last block of its first page) has arrived in registers: nothing of
-                        // the chunk (of that page) will be read from HBM again. Drop the page reference (release: all
-                        // earlier loads of this lane have completed); whoever brings a page to zero hands it back to the
-                        // host, which may refill it at once.
-                        if (c & 6u) {
+                        // The chunk's LAST block has arrived in registers: nothing of the chunk will be read from HBM
+                        // again. Drop its page references (release: all earlier loads of this lane have completed);
+                        // whoever brings a page to zero hands it back to the host, which may refill it at once.
+                        // (Round 4 tried letting go of a two-page chunk's FIRST page as soon as its last block there was
+                        // in: no gain — a max-size chunk lives almost entirely in ONE 16.2 MiB page, which it holds for
+                        // its whole 0.46 s either way; configs[2] through the ring 412 vs 422 GiB/s. Removed again.)
+                        if (c & 2u) {
                             const uint32_t pg = pagesv[s];
-                            const bool two = (pg >> 16) != 0xffffu;
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
-                                // first page: when its last block is in (two-page chunk) or with the chunk's last block
-                                // (one page); second page: with the chunk's last block
-                                const bool now = h ? ((c & 2u) != 0u && two) : ((c & 4u) != 0u || ((c & 2u) != 0u && !two));
-                                if (pi != 0xffffu && now) {
+                                if (pi != 0xffffu) {
                                     const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
                                                                                 __HIP_MEMORY_SCOPE_AGENT);
                                     if (old == 1u) {

@@ -62,6 +62,13 @@ void ring_service_ended(pbsgpu_ring *r) {
     volatile uint32_t *hb = hb_words(r);
     hb[pbsk::kHbIntent] = 0;
     hb[pbsk::kHbCommitted] = 0;
+    // head := tail, stop := 0 — NOW, while nothing is published behind the service's back: its lanes may have left holding
+    // claims beyond the tail, and rounds enqueued from here on (even before the next service starts: a lone stream's rounds
+    // are cut ahead at full chip width, ring_enqueue_round) must find the queue ready to be served from exactly this point
+    if (r->cs) {
+        (void)pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs);
+        (void)hipEventRecord(r->ev_reset, r->cs);
+    }
     if (g_services.fetch_sub(1, std::memory_order_acq_rel) == 1) graveyard_flush();
 }
 
@@ -162,20 +169,25 @@ void ring_reap_rounds(pbsgpu_ring *r) {
 
 int ring_start_service(pbsgpu_ring *r) {
     if (r->svc == SvcState::Running) return PBSGPU_OK;
-    // head := tail, stop := 0 behind everything on the control stream — and behind the END of a service that is still
-    // stopping (park): its lanes may hold claims beyond the tail that the reset hands out again
-    if (r->svc == SvcState::Stopping) HIPCHK(hipStreamWaitEvent(r->cs, r->ev_svc1, 0));
-    else g_services.fetch_add(1, std::memory_order_acq_rel);
+    if (r->svc == SvcState::Stopping) {
+        // parked, its end not yet observed: the new service goes behind the old one's END and a reset (its lanes may hold
+        // claims beyond the tail that the reset hands out again) — all on the device, nobody waits here
+        HIPCHK(hipStreamWaitEvent(r->cs, r->ev_svc1, 0));
+        HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));
+        HIPCHK(hipEventRecord(r->ev_reset, r->cs));
+    } else {
+        g_services.fetch_add(1, std::memory_order_acq_rel);  // (Stopped: the queue was reset when the last service ended)
+    }
     r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
-    hb_words(r)[pbsk::kHbClaim] = r->tail_seen;  // (k_ring_reset: head := tail; every round was reaped or is behind us on cs)
-    HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));
-    HIPCHK(hipEventRecord(r->ev_reset, r->cs));
-    HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));
+    r->defer_t0 = 0;
+    hb_words(r)[pbsk::kHbClaim] = r->tail_seen;
+    HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));  // (never recorded before the first launch: no wait)
     HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
     HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
     HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
     r->svc_t0 = now_ms();
-    r->svc_bytes0 = r->st.bytes_enqueued;
+    r->svc_bytes0 = r->st.bytes_enqueued - r->deferred_bytes;  // (bytes cut ahead of this launch are its work too)
+    r->deferred_bytes = 0;
     r->st.service_launches++;
     return PBSGPU_OK;
 }
@@ -376,10 +388,29 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.sugg_abs = e->sugg_feed_abs.load(std::memory_order_relaxed);
     rr.seg_rec_base = recbase;
     std::atomic_thread_fence(std::memory_order_release);
-    if (!r->defer_service) {
+    // Start the service with this round — unless it is worth cutting AHEAD of it: a LONE stream that delivers pages in bulk
+    // (bytes already in device memory) cannot keep the service's lanes busy anyway (a 64 GiB file is 17 k chunks for 24 k
+    // lanes: it is bound by the chain of its longest chunk), but its scan can use the WHOLE chip while no service holds
+    // three quarters of it: 64 GiB are cut in ~20 ms at full width instead of ~75 ms on the cut side's quarter. The
+    // service starts when the stream's bytes are all in, when another stream shows up, or after lone_defer_ms — and
+    // finds every chunk queued (the queue was reset when the previous service ended, not now).
+    bool defer = r->defer_service;
+    if (!defer && r->svc == SvcState::Stopped && r->lone_defer_ms > 0 && !any_final) {
+        uint32_t open_streams = 0;
+        for (auto &s : r->slots) open_streams += s.open ? 1u : 0u;
+        if (open_streams == 1 && np >= std::max<uint32_t>(1, r->round_pages / 2)) {
+            const double t = now_ms();
+            if (r->defer_t0 == 0) r->defer_t0 = t;
+            defer = t - r->defer_t0 < r->lone_defer_ms;
+        }
+    }
+    if (!defer) {
         const int st = ring_start_service(r);
         if (st != PBSGPU_OK) return fail(st);
+    } else {
+        r->deferred_bytes += new_bytes;
     }
+    if (r->svc == SvcState::Stopped) rr.scan_blocks = (uint32_t)std::max(1, e->num_cus);  // nobody else on the chip: full width
     for (hipEvent_t ev : deps)  // host-fed pages: the cut waits for their copies (device-side wait; the copies never wait for a kernel)
         if (hipStreamWaitEvent(r->cs, ev, 0) != hipSuccess) return fail(PBSGPU_E_HIP);
     for (hipEvent_t ev : deps) ring_event_put(r, ev);
@@ -591,6 +622,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kRingInputs);
         if (const char *v = getenv("PBSGPU_RING_AUTOPARK_MS")) r->autopark_ms = std::max(0.0, atof(v));
         if (const char *v = getenv("PBSGPU_RING_DEFER_SERVICE")) r->defer_service = atoi(v) != 0;
+        if (const char *v = getenv("PBSGPU_RING_LONE_DEFER_MS")) r->lone_defer_ms = std::max(0.0, atof(v));
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
@@ -727,8 +759,7 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
         r->svc = SvcState::Running;
         r->st.service_launches++;
         HIPCHK(hipStreamSynchronize(r->ss));
-        ring_service_ended(r);
-        HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));  // head := tail, stop := 0 for the next batch of rounds
+        ring_service_ended(r);  // (head := tail, stop := 0 for the next batch of rounds)
         HIPCHK(hipStreamSynchronize(r->cs));
         r->svc_bytes0 = r->st.bytes_enqueued;
         ring_reap_free(r);
@@ -973,10 +1004,19 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
     }
     ring_reap_free(r);
     ring_reap_rounds(r);
+    bool any_round = false;
     for (int i = 0; i < 4; ++i) {
         bool did = false;
         CHK(ring_enqueue_round(r, &did));
         if (!did) break;
+        any_round = true;
+    }
+    if (!r->defer_service && r->svc == SvcState::Stopped && r->deferred_bytes > 0) {
+        // rounds were cut ahead of the service (lone stream): start it once nothing more is waiting to be cut right now, or
+        // the deferral has lasted long enough
+        bool waiting = false;
+        for (auto &s : r->slots) waiting |= s.open && !s.ready.empty();
+        if ((!any_round && !waiting) || now_ms() - r->defer_t0 >= r->lone_defer_ms) CHK(ring_start_service(r));
     }
     if (r->autopark_ms > 0 && r->svc == SvcState::Running) {  // nothing anywhere in the ring: give the CUs (and hipFree) back
         if (ring_idle(r)) {

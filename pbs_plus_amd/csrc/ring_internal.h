@@ -107,6 +107,9 @@ struct pbsgpu_ring {
     double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
     double idle_since_ms = 0;
     bool defer_service = false;           // PBSGPU_RING_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
+    double lone_defer_ms = 25.0;          // a lone bulk stream's rounds are cut ahead of the service start for at most this long (0 = off)
+    double defer_t0 = 0;                  // when the current deferral began (0 = none)
+    uint64_t deferred_bytes = 0;          // bytes cut while no service was running (they are the next launch's work)
     double idle_timeout_s = 0;            // > 0: the service's own idle stop (default 20 s; PBSGPU_RING_IDLE_TIMEOUT_S overrides)
     // host bookkeeping
     std::vector<uint32_t> free_pages;
