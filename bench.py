@@ -801,9 +801,12 @@ def ring_run(a, rank, local_rank, world, ctx):
                 opened += 1
             # free pages are dealt out evenly: a stream gets at most `quota` pages per turn, so every round carries pages
             # of all the files in flight (one stream taking every free page would feed the files one after the other)
+            # (a file that is ALONE gets a whole round's worth per turn: with 16 pages per turn one 64 GiB file went through
+            # 253 small rounds and ~100 ms of per-round latency — and never qualified for the ring's lone-stream cut-ahead)
+            q_turn = quota if (state["S"] > 1 or len(active) > 1) else 256 * int(ring.page_bytes)
             for sid, st in active.items():
                 if st[1]:
-                    want = min(st[1], quota)
+                    want = min(st[1], q_turn)
                     st[1] -= ring.fill(sid, seed_of(st[0]), kind, want, final=(want == st[1]))
             ring.pump()
             if (opened == nfiles and "t_fed" not in marks and not any(st[1] for st in active.values())
@@ -1050,9 +1053,12 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
                 fed["bytes"] += active[sid][1]
                 nxt += 1
                 nfeed += 1
+            # (a file that is ALONE gets a whole round's worth per turn: with 16 pages per turn one 64 GiB file went through
+            # 253 small rounds and ~100 ms of per-round latency — and never qualified for the ring's lone-stream cut-ahead)
+            q_turn = quota if (state["S"] > 1 or len(active) > 1) else 256 * int(ring.page_bytes)
             for sid, st in active.items():
                 if st[1]:
-                    want = min(st[1], quota)
+                    want = min(st[1], q_turn)
                     if edited["on"]:
                         st[1] -= ring.fill_pieces(sid, plan_of(st[0])[0] if st[3] else None, want, final=(want == st[1]))
                         st[3] = False

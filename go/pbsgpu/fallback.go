@@ -107,6 +107,7 @@ func (c *Chunker) Close()                   {}
 func NewCommID() ([CommIDBytes]byte, error)                                      { return [CommIDBytes]byte{}, ErrNotBuilt }
 func (c *Comm) Dedup([]ChunkInfo, uint64) ([]bool, DedupStats, error)            { return nil, DedupStats{}, ErrNotBuilt }
 func (c *Comm) Close()                                                           {}
+func CommLastError() string                                                      { return "" }
 func (r *Ring) Open() (uint32, error)                                            { return 0, ErrNotBuilt }
 func (r *Ring) Reserve(uint32) (uintptr, uint64, error)                          { return 0, 0, ErrNotBuilt }
 func (r *Ring) Commit(uint32, uint64, bool) error                                { return ErrNotBuilt }

@@ -855,6 +855,10 @@ func (c *Comm) Dedup(recs []ChunkInfo, capRecords uint64) ([]bool, DedupStats, e
 	return out, DedupStats{uint64(st.nrecords), uint64(st.nunique), uint64(st.total_bytes), uint64(st.unique_bytes)}, nil
 }
 
+// CommLastError is what RCCL reported when a communicator call of this process last failed ("" = nothing yet): a
+// PBSGPU_E_HIP from NewComm / Dedup does not say whether the bootstrap found no network interface or the device faulted.
+func CommLastError() string { return C.GoString(C.pbsgpu_comm_last_error()) }
+
 func (c *Comm) Close() {
 	runtime.SetFinalizer(c, nil)
 	if c.h != nil {

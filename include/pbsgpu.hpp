@@ -449,6 +449,8 @@ inline Result<CommID> NewCommID() {  // rank 0 only; ship the bytes to the other
     return r;
 }
 
+inline std::string CommLastError() { return pbsgpu_comm_last_error(); }  // RCCL's own words for the last failure
+
 class Comm {
   public:
     static Result<std::unique_ptr<Comm>> New(std::shared_ptr<Engine> eng, const CommID &id, int rank, int world) {

@@ -25,7 +25,12 @@ class PbsGpuError(RuntimeError):
         self.status = status
         msg = lib().pbsgpu_strerror(status).decode() if _lib is not None else str(status)
         hip = lib().pbsgpu_last_hip_error() if _lib is not None else 0
-        super().__init__(f"{what}: {msg} (status {status}, hipError {hip})")
+        extra = ""
+        if _lib is not None and ("comm" in what or "allgather" in what):
+            txt = lib().pbsgpu_comm_last_error()
+            if txt:
+                extra = f"; RCCL: {txt.decode(errors='replace')}"
+        super().__init__(f"{what}: {msg} (status {status}, hipError {hip}{extra})")
 
 
 class Config(C.Structure):
@@ -179,6 +184,7 @@ SYMBOLS = {
     "pbsgpu_comm_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "pbsgpu_comm_destroy": (None, [_P]),
     "pbsgpu_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pbsgpu_comm_last_error": (C.c_char_p, []),
     "pbsgpu_digest_allgather_dedup": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(DedupStats)]),
     "pbsgpu_didx_size": (C.c_int, [C.c_uint64, _U64P]),
     "pbsgpu_didx_encode": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int64, _P, C.c_uint64]),

@@ -10,6 +10,8 @@
 //   rank 0: pbsgpu_comm_unique_id(id)  -> the host ships the 128 bytes to the other ranks over whatever it already talks
 //   (the Go agent: its aRPC session), every rank: pbsgpu_comm_create(engine, id, rank, world, &comm), then any number of
 //   pbsgpu_digest_allgather_dedup(comm, ...) — collective: every rank calls it, in the same order.
+#include <cstdio>
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -54,6 +56,19 @@ Rccl &rccl() {
     return r;
 }
 
+// What RCCL said when a pbsgpu_comm_* call last failed (pbsgpu_comm_last_error): "ncclCommInitRank: unhandled system
+// error (2)" tells a missing network interface from a HIP fault; PBSGPU_E_HIP alone does not.
+std::mutex g_comm_err_mu;
+char g_comm_err[256] = "";
+
+int comm_fail(const char *what, ncclResult_t rc) {
+    std::lock_guard<std::mutex> lk(g_comm_err_mu);
+    const char *txt = rccl().GetErrorString ? rccl().GetErrorString(rc) : "?";
+    std::snprintf(g_comm_err, sizeof(g_comm_err), "%s: %s (ncclResult %d)", what, txt ? txt : "?", (int)rc);
+    if (getenv("PBSGPU_TRACE")) std::fprintf(stderr, "[pbsgpu] %s\n", g_comm_err);
+    return PBSGPU_E_HIP;
+}
+
 constexpr uint64_t kSlotHeader = 64;  // [count u64 | pad] in front of a rank's records: keeps the records 64-byte aligned
 
 }  // namespace
@@ -76,7 +91,7 @@ int pbsgpu_comm_unique_id(uint8_t id[PBSGPU_COMM_ID_BYTES]) {
     Rccl &r = rccl();
     if (!r.ok) return PBSGPU_E_NO_DEVICE;  // no RCCL in this process / on this box
     ncclUniqueId u;
-    if (r.GetUniqueId(&u) != ncclSuccess) return PBSGPU_E_HIP;
+    if (const ncclResult_t rc = r.GetUniqueId(&u); rc != ncclSuccess) return comm_fail("ncclGetUniqueId", rc);
     std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return PBSGPU_OK;
 }
@@ -114,7 +129,22 @@ int pbsgpu_comm_create(pbsgpu_engine *e, const uint8_t id[PBSGPU_COMM_ID_BYTES],
     std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     int st = PBSGPU_OK;
     if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
-    if (st == PBSGPU_OK && r.CommInitRank(&c->comm, world, u, rank) != ncclSuccess) st = PBSGPU_E_HIP;
+    if (st == PBSGPU_OK) {
+        ncclResult_t rc = r.CommInitRank(&c->comm, world, u, rank);
+        if (rc != ncclSuccess && world == 1) {
+            // RCCL takes ~0.6 GB of device memory for its channels and kernels: when the engine's parked resources (the
+            // page ring of its payload streams, closed streams' contexts) hold the last of the HBM, give them back and try
+            // once more. Only with ONE rank: with more, a retry would have to be agreed between the ranks (the id is
+            // consumed by the failed attempt on the others) — there the caller trims first (pbsgpu_engine_trim).
+            (void)hipGetLastError();
+            uint64_t freed = 0;
+            (void)pbsgpu_engine_trim(e, &freed);
+            c->comm = nullptr;
+            ncclUniqueId u2;
+            if (r.GetUniqueId(&u2) == ncclSuccess) rc = r.CommInitRank(&c->comm, world, u2, rank);
+        }
+        if (rc != ncclSuccess) st = comm_fail("ncclCommInitRank", rc);
+    }
     if (st != PBSGPU_OK) {
         c->comm = nullptr;
         pbsgpu_comm_destroy(c);
@@ -122,6 +152,14 @@ int pbsgpu_comm_create(pbsgpu_engine *e, const uint8_t id[PBSGPU_COMM_ID_BYTES],
     }
     *out = c;
     return PBSGPU_OK;
+}
+
+const char *pbsgpu_comm_last_error(void) {
+    // (a copy per calling thread: the text may be rewritten by another thread's failure)
+    static thread_local char copy[sizeof(g_comm_err)];
+    std::lock_guard<std::mutex> lk(g_comm_err_mu);
+    std::memcpy(copy, g_comm_err, sizeof(copy));
+    return copy;
 }
 
 int pbsgpu_comm_rank(const pbsgpu_comm *c, int *rank, int *world) {
@@ -153,7 +191,8 @@ int pbsgpu_digest_allgather_dedup(pbsgpu_comm *c, const pbsgpu_record *recs, uin
     std::memcpy(hs, &n, 8);
     if (n) std::memcpy(hs + kSlotHeader, recs, n * sizeof(pbsgpu_record));
     HIPCHK(hipMemcpyAsync(c->send.p, hs, kSlotHeader + n * sizeof(pbsgpu_record), hipMemcpyHostToDevice, c->st));
-    if (rccl().AllGather(c->send.p, c->recv.p, slot, ncclUint8, c->comm, c->st) != ncclSuccess) return PBSGPU_E_HIP;
+    if (const ncclResult_t rc = rccl().AllGather(c->send.p, c->recv.p, slot, ncclUint8, c->comm, c->st); rc != ncclSuccess)
+        return comm_fail("ncclAllGather", rc);
     // the counts of all ranks (8 bytes each) decide the compaction
     uint64_t *hc = c->h_counts.as<uint64_t>();
     for (int r = 0; r < c->world; ++r)

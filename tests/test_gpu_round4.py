@@ -205,8 +205,11 @@ def test_comm_digest_set_reduce_behind_the_c_abi_one_rank(gpu_lib, O):
     libpbsgpu dlopens RCCL, builds the communicator, runs ncclAllGather of the [count | records] slot and the device dedup;
     flags and statistics equal pbsgpu_dedup_host on the same records. (N > 1 over xGMI is the driver's to run: bench.py
     repeats this reduce over all ranks beside the torch.distributed path and reports whether they agree.)"""
+    import gc
+
     from pbs_plus_amd import Comm, RECORD_DTYPE
 
+    gc.collect()   # engines of earlier tests that are only waiting for the collector still hold their page rings (48 GiB each)
     eng = _engine(4096)
     rng = np.random.default_rng(11)
     n = 30_000
