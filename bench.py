@@ -764,7 +764,10 @@ def ring_run(a, rank, local_rank, world, ctx):
     ring = pbs_plus_amd.PageRing(eng, arena_bytes=arena, max_streams=max(8, a.ring_streams) * 4, sha_cus=a.ring_sha_cus,
                                  round_pages=a.ring_round_pages)
     state = {"S": max(1, a.ring_streams), "next_file": 0, "timed": False, "first_timed": 0, "next_reduce": 0}
-    quota = 16 * int(ring.page_bytes)
+    # pages a stream may take per turn: a quarter of a round with 4 files in flight (steady state is bounded by the pages that
+    # come back, not by this; at the start of a region it lets the first rounds be full ones, which the ring cuts ahead of the
+    # service at full chip width)
+    quota = max(16, 256 // max(1, a.ring_streams)) * int(ring.page_bytes)
     max_open = max(8, a.ring_streams) * 4
     kind = a.ring_kind
     pending_reduce, extra, marks = {}, {}, {}
@@ -886,6 +889,7 @@ def ring_run(a, rank, local_rank, world, ctx):
     ts0 = time.perf_counter()
     s_saved, state["S"] = state["S"], 1
     single = run_files(1, True)
+    single_fed_s = marks.get("t_fed", ts0) - ts0     # every byte of the file in a cut round (then: the chains of its last chunks)
     ring.quiesce()
     single_s = time.perf_counter() - ts0
     state["S"] = s_saved
@@ -945,6 +949,7 @@ def ring_run(a, rank, local_rank, world, ctx):
                 "traffic_note": None if tr is None else tr["note"],
                 "algorithmic_bytes_per_launch": int(svc_bytes),
                 "single_file": {"ms": round(single_s * 1e3, 1), "GiBps": round(file_bytes / GiB / single_s, 1),
+                                "cut_ms": round(single_fed_s * 1e3, 1),
                                 "note": "one file alone through an idle ring, first page filled to last record delivered"},
             },
             "serial_value": round(file_bytes / GiB / single_s, 2),
@@ -1053,12 +1058,9 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
                 fed["bytes"] += active[sid][1]
                 nxt += 1
                 nfeed += 1
-            # (a file that is ALONE gets a whole round's worth per turn: with 16 pages per turn one 64 GiB file went through
-            # 253 small rounds and ~100 ms of per-round latency — and never qualified for the ring's lone-stream cut-ahead)
-            q_turn = quota if (state["S"] > 1 or len(active) > 1) else 256 * int(ring.page_bytes)
             for sid, st in active.items():
                 if st[1]:
-                    want = min(st[1], q_turn)
+                    want = min(st[1], quota)
                     if edited["on"]:
                         st[1] -= ring.fill_pieces(sid, plan_of(st[0])[0] if st[3] else None, want, final=(want == st[1]))
                         st[3] = False

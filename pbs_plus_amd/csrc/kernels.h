@@ -215,6 +215,12 @@ struct RingSource {
     // [32] claim progress (device, for the backlog gate), [33] rounds enqueued so far (host).
     const uint32_t *heartbeat;
     unsigned long long idle_ticks;
+    uint32_t poll_mask;        // a wave that still carries chunks looks at the queue when (step & poll_mask) == 0 (0 = every step)
+    // An EXPRESS service (k_sha256_xpair on its own CUs) owns the long-chunk queue: the pair service's lanes then take a long
+    // chunk only while more than `long_spill` of them wait (the express lanes are all busy), never give up main-queue
+    // claims for it, and leave without looking at it.
+    uint32_t xp;
+    uint32_t long_spill;
 };
 constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHbRoundsEnq = 33;
 
@@ -257,7 +263,7 @@ struct RingSeg {
 };
 // Device-resident state of a stream slot.
 constexpr uint64_t kRingMaxStream = 1ull << 40;  // logical coordinates are (stream slot << 40) | offset
-constexpr uint32_t kRingPT = 64;       // page-table window per stream (open chunk <= 2 pages + new pages of one round)
+constexpr uint32_t kRingPT = 512;      // page-table window per stream (open chunk <= 2 pages + new pages of one round)
 struct RingStreamState {
     uint64_t c;            // start of the open chunk (logical offset in the stream)
     uint64_t end;          // bytes received so far
@@ -328,6 +334,7 @@ hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st, hi
                              hipEvent_t fill_ev = nullptr);
 // the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
 hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st);
+hipError_t launch_ring_service_xp(const RingSource &q, unsigned workgroups, hipStream_t st);
 // raise `stop` behind everything enqueued so far on `st`
 hipError_t launch_ring_stop(RingCtl *ctl, hipStream_t st);
 hipError_t launch_ring_reset(RingCtl *ctl, hipStream_t st);

@@ -1685,20 +1685,30 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         // lanes than chunks, and the longest-first order is what keeps its makespan at the longest chain.
         constexpr uint32_t kReserve = 16;
         uint32_t res_next = 0, res_end = 0;  // the wave's reserved positions [res_next, res_end): same value in every lane
+        [[maybe_unused]] uint32_t poll_ctr = 0;
         auto acquire = [&](bool need) {
             if constexpr (Source::kRing) {
+                // Lanes without work look at the queue — a device-scope load the wave then WAITS for (0.3-0.5 us: about the
+                // slack the producer has against its consumer). With every step of a wave that still carries chunks on its
+                // other lanes this made the PRODUCER the slower half of the pair whenever one lane was idle: the chain of a
+                // max-size chunk ran at ~1.95 us per block instead of 1.7 in a draining ring (drain floor 0.515 s, one file
+                // alone 0.58 s) and in every wave with a starved lane during the feed phase. A wave with work therefore
+                // polls on every 8th step only (src.poll_mask, PBSGPU_RING_POLL_EVERY; a free lane waits <= 14 us for its next
+                // chunk: 0.02 % of a 4 MiB chunk's chain); a wave with no work at all polls every step, as before.
+                if (__ballot(need) == 0) return;
+                if (__ballot(have) != 0 && ((++poll_ctr) & src.poll_mask) != 0u) return;
                 // (0) LONG chunks first (see RingSource::ldesc): one relaxed load of {ltail, lhead}; the wave's leader moves
                 // lhead forward by compare-and-swap only over published positions, so no lane ever waits on this queue
                 // Who may take a long chunk: a lane that holds NO claim on the main queue — one that has just finished a
                 // chunk, or one of the few lanes (1 in 16) that never claim there. A lane that waits at a claimed, not yet
                 // published position must not: the chunk published at its position later would then wait for the whole
                 // long chain (measured: +0.26-0.40 s on a single file when every idle lane could take long chunks).
-                const bool long_only = src.long_bytes != 0u && (lane & 15) == 0;
+                const bool long_only = src.long_bytes != 0u && src.xp == 0u && (lane & 15) == 0;
                 const bool elig = need && claimed == 0u;
                 if (src.long_bytes && __ballot(elig)) {
                     const unsigned long long lq = __hip_atomic_load(&src.ctl->lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t lt = (uint32_t)lq, lh = (uint32_t)(lq >> 32);
-                    const int32_t avail = (int32_t)(lt - lh);
+                    const int32_t avail = (int32_t)(lt - lh) - (int32_t)src.long_spill;  // (spill: what the express service's lanes are left)
                     if (avail > 0) {
                         const unsigned long long mn = __ballot(elig);
                         const uint32_t cnt = min((uint32_t)__popcll(mn), (uint32_t)avail);
@@ -1780,7 +1790,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 // stop: nothing will ever be published at this position. (stop is raised behind the last publish of BOTH queues;
                 // the long queue is looked at again after the fence, so a lane never leaves while long chunks are unclaimed)
                 bool leave = need && !ready && stop != 0u;
-                if (src.long_bytes && __ballot(leave)) {
+                if (src.long_bytes && src.xp == 0u && __ballot(leave)) {
                     __atomic_thread_fence(__ATOMIC_ACQUIRE);
                     const unsigned long long lq2 = __hip_atomic_load(&src.ctl->lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((int32_t)((uint32_t)lq2 - (uint32_t)(lq2 >> 32)) > 0) leave = false;
@@ -2035,6 +2045,407 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
 }
 
 // -------------------------------------------------------------------------------------
+// SHA-256, EXPRESS form: TWO LANES PER CHUNK, on top of the wave pair. Rounds 1-3 called the chain of a max-size chunk a
+// floor: 64 rounds x 14 instructions, one instruction per ~4.2 cycles per wave whatever its lane count, and two WAVES
+// cannot share one chain (an LDS round trip >> the 60 cycles of a round). Two LANES of the same wave can: DPP operands
+// move a value to the neighbouring lane inside the instruction that uses it. A round's two halves
+//     e' = Sigma1(e) + Ch(e,f,g) + [h + d + K + W]        (needs the a-chain only through d = a three rounds ago)
+//     a' = Sigma0(a) + Maj(a,b,c) + [e' - d]               (needs the e-chain only through e')
+// are the SAME nine instructions on different operands:
+//     lane A (even) keeps e,f,g,h = X0..X3, lane B (odd) keeps a,b,c,d and runs TWO rounds behind A, so that ONE
+//     register name serves both directions of the exchange: A reads d = a(r-3) from B's X1, B reads e(r-1) from A's X1;
+//     Sigma: three v_alignbit by per-lane shift registers (6,11,25 | 2,13,22) + xor3;
+//     Ch | Maj: bfi(X0 ^ (X2 & ROLE), X1, X2) — ROLE = 0 gives Ch(e,f,g), ROLE = ~0 gives bfi(a^c, b, c) = Maj(a,b,c);
+//     the bracket: NZ = (X3 ^ ROLE) + C (v_xad_u32: h + [K+W] for A with C = K+W; -d for B with C = 1), then
+//     P = partner's X1 + NZ (v_add_u32_dpp quad_perm:[1,0,3,2]); X0' = S + F + P (v_add3).
+// 9 instructions per round instead of 14, 66 slot-rounds per block (B's two rounds of lag) + 12 for the per-lane
+// selects at the block's ends: ~630 issue slots per block against ~946 — the serial chain of a chunk runs 1.5x faster
+// (oracle: the formulation was first checked lane by lane in Python against hashlib, scripts/r4_xpair_sim.py).
+// The PRODUCER wave needs no cross-lane work at all: the message schedule does not depend on the state, so its two lanes
+// of a chunk expand two CONSECUTIVE blocks at once (lane A block 2m, lane B block 2m+1, each with the ordinary code) and
+// a producer step (one barrier) feeds two consumer blocks: plane E and plane O of the LDS buffer, both in the row of lane
+// A; the rows of the B lanes hold the constant 1 (C above), written once.
+// Cost: a wave carries 32 chunks instead of 64, i.e. 0.74 of the pair form's throughput per CU — the form is for the
+// chunks whose chain bounds something (the ring's long-chunk queue, a lone file), not for all of them.
+// Four slot-rounds in ONE block of fixed order (36 instructions; the start variant adds the two selects that put b and a
+// into B's chain). One block, because (1) the DPP operand of a round (its X1) must have been written at least two
+// instructions before the v_add_u32_dpp that reads it and the hazard recogniser does not look into inline assembly: X1 is
+// an input of the block or the result of a round at least nine instructions earlier; (2) the compiler pads every boundary
+// between two assembly statements with an s_nop, and an s_nop costs a whole issue slot of the lone wave.
+#define XP_R(n, x0, x1, x2, x3, kw)                                                     \
+    "v_xad_u32 %[nz], " x3 ", %[role], " kw "\n\t"                                      \
+    "v_alignbit_b32 %[r1], " x0 ", " x0 ", %[sh1]\n\t"                                  \
+    "v_alignbit_b32 %[r2], " x0 ", " x0 ", %[sh2]\n\t"                                  \
+    "v_add_u32_dpp %[p], " x1 ", %[nz] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+    "v_alignbit_b32 %[r3], " x0 ", " x0 ", %[sh3]\n\t"                                  \
+    "v_bitop3_b32 %[sel], " x0 ", " x2 ", %[role] bitop3:0x78\n\t"                      \
+    "v_bitop3_b32 %[sg], %[r1], %[r2], %[r3] bitop3:0x96\n\t"                           \
+    "v_bitop3_b32 %[f], %[sel], " x1 ", " x2 " bitop3:0xca\n\t"                         \
+    "v_add3_u32 " n ", %[sg], %[f], %[p]\n\t"
+#define XP_TEMPS                                                                                                   \
+    [nz] "=&v"(nz), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [p] "=&v"(p), [sel] "=&v"(sel), [sg] "=&v"(sg), \
+        [f] "=&v"(f)
+struct XpRole {
+    uint32_t sh1, sh2, sh3, role;
+};
+// rounds r .. r+3 of a block; (x0..x3) in: the chain's last four values, newest first; out: the same after four rounds.
+// START: r = 0 — B's results of slot-rounds 0 and 1 are replaced by hb1 (= b) and hb0 (= a): its chain starts two late.
+template <bool START>
+__device__ __forceinline__ void xp_round4(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, const uint4 kw, const XpRole &R,
+                                          const uint32_t hb1 = 0, const uint32_t hb0 = 0) {
+    uint32_t n0, n1, n2, n3, nz, r1, r2, r3, p, sel, sg, f;
+    if constexpr (START) {
+        asm(XP_R("%[n0]", "%[x0]", "%[x1]", "%[x2]", "%[x3]", "%[k0]")
+            "v_bitop3_b32 %[n0], %[role], %[hb1], %[n0] bitop3:0xca\n\t"
+            XP_R("%[n1]", "%[n0]", "%[x0]", "%[x1]", "%[x2]", "%[k1]")
+            "v_bitop3_b32 %[n1], %[role], %[hb0], %[n1] bitop3:0xca\n\t"
+            XP_R("%[n2]", "%[n1]", "%[n0]", "%[x0]", "%[x1]", "%[k2]")
+            XP_R("%[n3]", "%[n2]", "%[n1]", "%[n0]", "%[x0]", "%[k3]")
+            : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), XP_TEMPS
+            : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [k0] "v"(kw.x), [k1] "v"(kw.y), [k2] "v"(kw.z), [k3] "v"(kw.w),
+              [sh1] "v"(R.sh1), [sh2] "v"(R.sh2), [sh3] "v"(R.sh3), [role] "v"(R.role), [hb1] "v"(hb1), [hb0] "v"(hb0));
+    } else {
+        asm(XP_R("%[n0]", "%[x0]", "%[x1]", "%[x2]", "%[x3]", "%[k0]")
+            XP_R("%[n1]", "%[n0]", "%[x0]", "%[x1]", "%[x2]", "%[k1]")
+            XP_R("%[n2]", "%[n1]", "%[n0]", "%[x0]", "%[x1]", "%[k2]")
+            XP_R("%[n3]", "%[n2]", "%[n1]", "%[n0]", "%[x0]", "%[k3]")
+            : [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2), [n3] "=&v"(n3), XP_TEMPS
+            : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [k0] "v"(kw.x), [k1] "v"(kw.y), [k2] "v"(kw.z), [k3] "v"(kw.w),
+              [sh1] "v"(R.sh1), [sh2] "v"(R.sh2), [sh3] "v"(R.sh3), [role] "v"(R.role));
+    }
+    x0 = n3; x1 = n2; x2 = n1; x3 = n0;
+}
+// the two slot-rounds behind round 63 (B finishes; A idles): K+W is irrelevant to B (its constant is the row of ones)
+__device__ __forceinline__ void xp_round2(uint32_t &x0, uint32_t &x1, uint32_t &x2, uint32_t &x3, const uint32_t kw, const XpRole &R) {
+    uint32_t n0, n1, nz, r1, r2, r3, p, sel, sg, f;
+    asm(XP_R("%[n0]", "%[x0]", "%[x1]", "%[x2]", "%[x3]", "%[k0]")
+        XP_R("%[n1]", "%[n0]", "%[x0]", "%[x1]", "%[x2]", "%[k0]")
+        : [n0] "=&v"(n0), [n1] "=&v"(n1), XP_TEMPS
+        : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [k0] "v"(kw), [sh1] "v"(R.sh1), [sh2] "v"(R.sh2), [sh3] "v"(R.sh3),
+          [role] "v"(R.role));
+    x3 = x1; x2 = x0; x1 = n0; x0 = n1;
+}
+// role ? b : a, bitwise (ROLE is 0 or ~0 per lane)
+__device__ __forceinline__ uint32_t xp_sel(uint32_t role, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(role, b, a, 0xCA); }
+
+template <typename Source>
+__global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t *nitems_p, uint32_t nitems_imm, uint32_t *queue,
+                                                      const uint32_t *wg_limit) {
+    if (wg_limit && *wg_limit == 0) return;  // k_order: skip this pass (a scan tile overflowed, the batch is re-run)
+    // waves 0,1 = consumers of pair 0,1; waves 2,3 = their producers. 32 chunks per pair: chunk ci = lanes 2ci (A), 2ci+1 (B).
+    __shared__ uint4 wkbuf_[2][2][2][16][64];  // [pair][buffer][plane E/O][4 rounds][row]: 128 KiB
+    __shared__ uint32_t ctrl_[2][2][2][32];    // [pair][buffer][plane][chunk]: bit0 block valid, bit1 last block of its chunk
+    __shared__ uint8_t *dstp_[2][2][2][32];    // digest destination (valid when bit1)
+    __shared__ uint32_t alive[2][2];           // [pair][buffer]: producer still had blocks
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int pr = wave & 1;
+    const bool producer = wave >= 2;
+    const bool roleB = (lane & 1) != 0;
+    const int ci = lane >> 1;
+    auto &wkbuf = wkbuf_[pr];
+    auto &ctrl = ctrl_[pr];
+    auto &dstp = dstp_[pr];
+    auto any_alive = [&](const int pb) -> uint32_t { return alive[0][pb] | alive[1][pb]; };
+    // rows of the B lanes: the constant 1 in every plane of every buffer (never written again)
+    for (int i = threadIdx.x; i < 2 * 2 * 2 * 16 * 32; i += 256) {
+        const int row = 2 * (i & 31) + 1, q = (i >> 5) & 15, pl = (i >> 9) & 1, pb = (i >> 10) & 1, pp = (i >> 11) & 1;
+        wkbuf_[pp][pb][pl][q][row] = make_uint4(1u, 1u, 1u, 1u);
+    }
+    __syncthreads();
+
+    if (producer) {
+        const uint32_t nitems = nitems_p ? *nitems_p : nitems_imm;
+        const uint8_t *base = nullptr;
+        uint64_t len = 0, blk = 0, nblk = 0;  // blk = the lane's next block (A: even blocks, B: odd blocks)
+        uint8_t *dst = nullptr;
+        bool have = false, exhausted = false;
+        [[maybe_unused]] const uint8_t *base2 = nullptr;
+        [[maybe_unused]] uint32_t len1 = 0, pages = 0xffffffffu;
+        [[maybe_unused]] unsigned long long idle_since = 0;
+        [[maybe_unused]] uint32_t poll_ctr = 0;
+        constexpr int D = 2;
+        uint32_t R[D][17];
+        uint32_t selv[D], cflag[D];
+        uint8_t *dstv[D];
+        [[maybe_unused]] uint32_t pagesv[D];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+#pragma unroll
+            for (int j = 0; j < 17; ++j) R[s][j] = 0;
+            selv[s] = 0x00010203u;
+            cflag[s] = 0;
+            dstv[s] = nullptr;
+            pagesv[s] = 0xffffffffu;
+        }
+        // `need`: this A lane's PAIR has issued every block of its chunk and wants the next one (B lanes never ask)
+        auto acquire = [&](bool need) {
+            if (__ballot(need) == 0) return;
+            bool got = false;
+            if constexpr (Source::kRing) {
+                // the ring's LONG-chunk queue only (RingSource::ldesc): no claims, no waiting at positions — the wave's
+                // leader moves lhead forward by compare-and-swap over published positions
+                if (__ballot(have) != 0 && ((++poll_ctr) & src.poll_mask) != 0u) return;
+                const unsigned long long lq = __hip_atomic_load(&src.ctl->lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t lt = (uint32_t)lq, lh = (uint32_t)(lq >> 32);
+                const int32_t avail = (int32_t)(lt - lh);
+                const unsigned long long mn = __ballot(need);
+                if (avail > 0) {
+                    const uint32_t cnt = min((uint32_t)__popcll(mn), (uint32_t)avail);
+                    const int leader = __ffsll((long long)mn) - 1;
+                    uint32_t got0 = 0xffffffffu;
+                    if (lane == leader && atomicCAS(&src.ctl->lhead, lh, lh + cnt) == lh) got0 = lh;
+                    got0 = __shfl(got0, leader, 64);
+                    if (got0 != 0xffffffffu) {
+                        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                        const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
+                        got = need && rank < cnt;
+                        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+                        if (got) {
+                            e0 = src.ldesc[2u * ((got0 + rank) & src.lmask)];
+                            e1 = src.ldesc[2u * ((got0 + rank) & src.lmask) + 1u];
+                        }
+                        base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e0.y << 32) | e0.x) : base;
+                        base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e1.y << 32) | e1.x) : base2;
+                        len = got ? (uint64_t)e0.z : len;
+                        len1 = got ? e0.w : len1;
+                        dst = got ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
+                        pages = got ? e1.w : pages;
+                    }
+                } else {
+                    // nothing published: has the service been told to stop? (stop is raised behind the last publish; the
+                    // queue is looked at again behind the fence, so no lane leaves while long chunks are unclaimed)
+                    const unsigned long long ts = __hip_atomic_load(&src.ctl->tail_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(ts >> 32) != 0u) {
+                        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                        const unsigned long long lq2 = __hip_atomic_load(&src.ctl->lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((int32_t)((uint32_t)lq2 - (uint32_t)(lq2 >> 32)) <= 0) exhausted = exhausted | need;
+                    }
+                }
+            } else {
+                const unsigned long long m = __ballot(need);
+                uint32_t first = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) first = atomicAdd(queue, (uint32_t)__popcll(m));
+                first = __shfl(first, leader, 64);
+                if (need) {
+                    const uint32_t i = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (i < nitems) {
+                        src.get(i, base, len, dst);
+                        got = true;
+                    } else {
+                        exhausted = true;
+                    }
+                }
+            }
+            // the chunk (or the end of work) goes to the pair's B lane
+            const int srcl = lane & ~1;
+            const bool pgot = __shfl((int)got, srcl, 64) != 0;
+            exhausted = __shfl((int)exhausted, srcl, 64) != 0;
+            if (__ballot(pgot)) {
+                const uint64_t b1 = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(base), srcl, 64);
+                const uint64_t ln = (uint64_t)__shfl((unsigned long long)len, srcl, 64);
+                const uint64_t ds = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dst), srcl, 64);
+                if (pgot) {
+                    base = reinterpret_cast<const uint8_t *>(b1);
+                    len = ln;
+                    dst = reinterpret_cast<uint8_t *>(ds);
+                }
+                if constexpr (Source::kRing) {
+                    const uint64_t b2 = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(base2), srcl, 64);
+                    const uint32_t l1 = (uint32_t)__shfl((int)len1, srcl, 64);
+                    const uint32_t pg = (uint32_t)__shfl((int)pages, srcl, 64);
+                    if (pgot) {
+                        base2 = reinterpret_cast<const uint8_t *>(b2);
+                        len1 = l1;
+                        pages = pg;
+                    }
+                }
+                if (pgot) {
+                    nblk = (len + 8) / 64 + 1;
+                    blk = roleB ? 1ull : 0ull;
+                    have = blk < nblk;
+                }
+            }
+        };
+        auto prep = [&](const int s) {
+            const unsigned long long hm = __ballot(have);
+            const bool pair_busy = ((hm >> (lane & ~1)) & 3ull) != 0ull;
+            acquire(!roleB && !pair_busy && !exhausted);
+            uint32_t c = 0;
+            if (have) {
+                const uint64_t off = blk * 64;
+                const uint8_t *bb = base;
+                if constexpr (Source::kRing) bb = (off < len1) ? base : base2;
+                if (off + 64 <= len) {
+                    const uint8_t *p = bb + off;
+                    const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
+                    const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
+                    const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+                    R[s][0] = v0.x; R[s][1] = v0.y; R[s][2] = v0.z; R[s][3] = v0.w;
+                    R[s][4] = v1.x; R[s][5] = v1.y; R[s][6] = v1.z; R[s][7] = v1.w;
+                    R[s][8] = v2.x; R[s][9] = v2.y; R[s][10] = v2.z; R[s][11] = v2.w;
+                    R[s][12] = v3.x; R[s][13] = v3.y; R[s][14] = v3.z; R[s][15] = v3.w;
+                    R[s][16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
+                    selv[s] = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
+                } else {
+                    sha256_tail_words(bb, len, off, blk + 1 == nblk, R[s]);
+                    selv[s] = 0x00010203u;
+                }
+                c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
+                dstv[s] = dst;
+                if constexpr (Source::kRing) pagesv[s] = pages;
+                blk += 2;
+                if (blk >= nblk) have = false;
+            }
+            cflag[s] = c;
+        };
+        // where this lane's expanded block goes: plane E (A lanes) or O (B lanes), always the row of the pair's A lane
+        const int wrow = lane & ~1, wplane = lane & 1;
+
+#pragma unroll
+        for (int s = 0; s < D; ++s) prep(s);
+        bool running = true;
+        while (running) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                if (running) {
+                    const int pb = s & 1;
+                    uint32_t W[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
+                    const uint32_t c = cflag[s];
+                    uint8_t *cur_dst = dstv[s];
+                    if constexpr (Source::kRing) {
+                        // the chunk's LAST block is in registers (the partner's blocks of this step and all earlier ones
+                        // too: same load instructions, same wait): drop the chunk's page references, as the pair form does
+                        if (c & 2u) {
+                            const uint32_t pg = pagesv[s];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
+                                if (pi != 0xffffu) {
+                                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
+                                                                                __HIP_MEMORY_SCOPE_AGENT);
+                                    if (old == 1u) {
+                                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
+                                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask],
+                                                           ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    prep(s);
+                    const bool any_cur = __any(c & 1u);
+                    if (any_cur) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            uint32_t x[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int t = 4 * q + j;
+                                x[j] = ((t < 16) ? W[t] : sha256_sched(W, t)) + kSha256K[t];
+                            }
+                            wkbuf[pb][wplane][q][wrow] = make_uint4(x[0], x[1], x[2], x[3]);
+                        }
+                    }
+                    ctrl[pb][wplane][ci] = c;
+                    dstp[pb][wplane][ci] = cur_dst;
+                    bool live = any_cur;
+                    if constexpr (Source::kRing) {
+                        // stays until `stop` has reached every pair and the block FIFO has drained; naps while idle. (The
+                        // idle self-stop of a silent host is the pair service's business: it raises `stop` for both.)
+                        const bool wave_done = __ballot(!exhausted) == 0ull;
+                        live = any_cur || !wave_done;
+                        if (!any_cur && !wave_done) __builtin_amdgcn_s_sleep(48);
+                    }
+                    if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
+                    __syncthreads();
+                    if (!any_alive(pb)) running = false;
+                }
+            }
+        }
+    } else {
+        // CONSUMER: lane A = e,f,g,h (H4..H7), lane B = a,b,c,d (H0..H3), lock-step
+        const XpRole R{roleB ? 2u : 6u, roleB ? 13u : 11u, roleB ? 22u : 25u, roleB ? 0xffffffffu : 0u};
+        const uint32_t role = R.role;
+        uint32_t ivr[4];
+        ivr[0] = roleB ? 0x6a09e667u : 0x510e527fu;
+        ivr[1] = roleB ? 0xbb67ae85u : 0x9b05688cu;
+        ivr[2] = roleB ? 0x3c6ef372u : 0x1f83d9abu;
+        ivr[3] = roleB ? 0xa54ff53au : 0x5be0cd19u;
+        uint32_t HR[4] = {ivr[0], ivr[1], ivr[2], ivr[3]};
+        struct Blk {
+            uint32_t al, c;
+            uint8_t *d;
+            uint4 wk[16];
+        };
+        auto fetch = [&](Blk &x, const int pb, const int plane) {
+            x.al = any_alive(pb);
+            x.c = ctrl[pb][plane][ci];
+            x.d = dstp[pb][plane][ci];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x.wk[q] = wkbuf[pb][plane][q][lane];
+        };
+        auto rounds = [&](const Blk &x) {
+            if (x.c & 1u) {
+                // slot-round r: A computes e(r+1), B computes a(r-1). B's first two slot-rounds only shift its start
+                // values into place (a(-1) = b, a(0) = a), A's last two are idle: per-lane selects at both ends.
+                uint32_t x0 = xp_sel(role, HR[0], HR[2]), x1 = xp_sel(role, HR[1], HR[3]), x2 = HR[2], x3 = HR[3];
+                xp_round4<true>(x0, x1, x2, x3, x.wk[0], R, HR[1], HR[0]);
+#pragma unroll
+                for (int g = 1; g < 16; ++g) xp_round4<false>(x0, x1, x2, x3, x.wk[g], R);
+                // after slot-round 63: (x0..x3) = results of slot-rounds 63, 62, 61, 60 = A's e(64..61)
+                const uint32_t o63 = x0, o62 = x1, o61 = x2, o60 = x3;
+                xp_round2(x0, x1, x2, x3, x.wk[15].w, R);
+                // ... after 65: x0, x1 = results of 65, 64; B's a(64..61) = results of 65, 64, 63, 62
+                HR[0] += xp_sel(role, o63, x0);
+                HR[1] += xp_sel(role, o62, x1);
+                HR[2] += xp_sel(role, o61, o63);
+                HR[3] += xp_sel(role, o60, o62);
+                if (x.c & 2u) {
+                    // B holds digest words 0..3, A words 4..7: one 16-byte store each
+                    uint32_t *o = reinterpret_cast<uint32_t *>(x.d) + (roleB ? 0 : 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = __builtin_bswap32(HR[j]);
+                    if constexpr (Source::kRing) {  // record cell in mapped pinned memory: both halves first, then the flag
+                        __threadfence_system();
+                        __hip_atomic_store(reinterpret_cast<uint32_t *>(x.d) + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) HR[j] = ivr[j];
+                }
+            }
+        };
+        // Software-pipelined like the pair form: the LDS reads of the NEXT block are issued before the rounds of the current
+        // one run from registers. A producer step = two blocks (planes E, O) and one barrier.
+        Blk E0, O0, E1, O1;
+        __syncthreads();  // barrier 0: step 0 is published (buffer 0)
+        fetch(E0, 0, 0);
+        for (;;) {
+            if (!E0.al) break;
+            fetch(O0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rounds(E0);
+            __syncthreads();  // step k+1 published (buffer 1); the producer may now overwrite buffer 0: O0 is in registers
+            fetch(E1, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rounds(O0);
+            if (!E1.al) break;
+            fetch(O1, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            rounds(E1);
+            __syncthreads();
+            fetch(E0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rounds(O1);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // Longest-first queue order + workgroup budget for the SHA kernel (one small workgroup).
 // A batch's makespan is max(longest chunk, total work / lanes): starting the long chunks first
 // and letting lanes pull the short ones afterwards reaches that bound with FEWER lanes than
@@ -2143,12 +2554,13 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
                                (int)bytes);
 }
 
-// PBSGPU_SHA_MODE=lane selects the single-wave kernel (A/B measurements); default = wave pairs
+// PBSGPU_SHA_MODE=lane selects the single-wave kernel, =xpair the express form (two lanes per chunk) for EVERY chunk of
+// the batch path (A/B measurements, and the parity tests of those kernels); default = wave pairs
 static int sha_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char *e = getenv("PBSGPU_SHA_MODE");
-        mode = (e && e[0] == 'l') ? 0 : 1;
+        mode = (e && e[0] == 'l') ? 0 : (e && e[0] == 'x') ? 2 : 1;
     }
     return mode;
 }
@@ -2156,6 +2568,11 @@ static int sha_mode() {
 // host-decided form (descriptor jobs, whole-segment hashing): exactly one launch
 template <typename Source>
 static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source src, uint32_t nitems, uint32_t *queue) {
+    if (sha_mode() == 2) {  // (131 KB static LDS: one workgroup per CU without padding)
+        hipLaunchKernelGGL((k_sha256_xpair<Source>), dim3(grid * (dense ? 4u : 2u)), dim3(256), 0, st, src, (const uint32_t *)nullptr,
+                           nitems, queue, (const uint32_t *)nullptr);
+        return hipGetLastError();
+    }
     if (dense) {
         hipLaunchKernelGGL((k_sha256_pair<Source, true>), dim3(grid), dim3(512), 0, st, src, (const uint32_t *)nullptr,
                            nitems, queue, (const uint32_t *)nullptr);
@@ -2190,6 +2607,9 @@ hipError_t launch_sha256_records(pbsgpu_record *recs, const uint32_t *nrec, uint
     if (dense && sha_dense_lanes()) {
         hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u * (unsigned)sha_dense_lanes()), dim3(64), 0,
                            st, src, nrec, 0u, queue, wg_limit, 1u);
+    } else if (sha_mode() == 2) {
+        hipLaunchKernelGGL((k_sha256_xpair<RecordSource>), dim3((unsigned)num_cus), dim3(256), 0, st, src, nrec, 0u, queue,
+                           wg_limit);
     } else if (sha_mode() == 1) {
         if (dense) {
             hipLaunchKernelGGL((k_sha256_pair<RecordSource, true>), dim3((unsigned)num_cus), dim3(512), 0, st, src, nrec,
@@ -2218,7 +2638,7 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
     unsigned grid = sha_grid(num_cus);
     const unsigned need = (nseg + 63) / 64;
     if (grid > need) grid = need;
-    if (sha_mode() == 1) {
+    if (sha_mode() != 0) {
         unsigned g2 = (unsigned)num_cus;
         const unsigned need2 = (nseg + (dense ? 255u : 127u)) / (dense ? 256u : 128u);
         if (g2 > need2) g2 = need2;

@@ -167,6 +167,21 @@ void ring_reap_rounds(pbsgpu_ring *r) {
     while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
 }
 
+// the pair service on `ss` and, when the ring has one, the express service on `xs`; ev_svc1 = BOTH have ended
+int ring_launch_services(pbsgpu_ring *r) {
+    HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));  // (never recorded before the first launch: no wait)
+    HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
+    HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
+    if (r->xp_cus) {
+        HIPCHK(hipStreamWaitEvent(r->xs, r->ev_reset, 0));
+        HIPCHK(pbsk::launch_ring_service_xp(r->source(), r->xp_cus, r->xs));
+        HIPCHK(hipEventRecord(r->ev_xsvc1, r->xs));
+        HIPCHK(hipStreamWaitEvent(r->ss, r->ev_xsvc1, 0));
+    }
+    HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
+    return PBSGPU_OK;
+}
+
 int ring_start_service(pbsgpu_ring *r) {
     if (r->svc == SvcState::Running) return PBSGPU_OK;
     if (r->svc == SvcState::Stopping) {
@@ -181,10 +196,7 @@ int ring_start_service(pbsgpu_ring *r) {
     r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
     r->defer_t0 = 0;
     hb_words(r)[pbsk::kHbClaim] = r->tail_seen;
-    HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));  // (never recorded before the first launch: no wait)
-    HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
-    HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
-    HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
+    CHK(ring_launch_services(r));
     r->svc_t0 = now_ms();
     r->svc_bytes0 = r->st.bytes_enqueued - r->deferred_bytes;  // (bytes cut ahead of this launch are its work too)
     r->deferred_bytes = 0;
@@ -358,7 +370,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.cell_base = (uint32_t)(ri.cell_base & (r->ncells - 1));
     rr.cell_cap = ri.cell_cap;
     rr.cell_mask = r->ncells - 1;
-    rr.scan_blocks = (uint32_t)std::max(1, e->num_cus - (int)r->sha_cus);
+    rr.scan_blocks = (uint32_t)std::max(1, e->num_cus - (int)r->sha_cus - (int)r->xp_cus);
     rr.status = hs;
     rr.streams = r->streams.as<pbsk::RingStreamState>();
     rr.q = r->source();
@@ -394,15 +406,17 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     // three quarters of it: 64 GiB are cut in ~20 ms at full width instead of ~75 ms on the cut side's quarter. The
     // service starts when the stream's bytes are all in, when another stream shows up, or after lone_defer_ms — and
     // finds every chunk queued (the queue was reset when the previous service ended, not now).
+    // The same holds for the first rounds of SEVERAL bulk streams on an idle ring: until the service's lanes could all be
+    // busy (lanes x average chunk size: ~96 GiB at avg 4 MiB) it only holds CUs the cut side could use — 96 GiB are cut in
+    // ~26 ms on the whole chip, ~105 ms on a quarter of it with lanes waiting all the while. A trickle of pages (host-fed
+    // streams: a few pages per pump) never defers: np is small there.
     bool defer = r->defer_service;
-    if (!defer && r->svc == SvcState::Stopped && r->lone_defer_ms > 0 && !any_final) {
-        uint32_t open_streams = 0;
-        for (auto &s : r->slots) open_streams += s.open ? 1u : 0u;
-        if (open_streams == 1 && np >= std::max<uint32_t>(1, r->round_pages / 2)) {
-            const double t = now_ms();
-            if (r->defer_t0 == 0) r->defer_t0 = t;
-            defer = t - r->defer_t0 < r->lone_defer_ms;
-        }
+    if (!defer && r->svc == SvcState::Stopped && r->lone_defer_ms > 0 && !any_final &&
+        np >= std::max<uint32_t>(1, r->round_pages / 2)) {
+        const uint64_t lanes_worth = (uint64_t)r->sha_cus * 128u * (uint64_t)e->cfg.avg;
+        const double t = now_ms();
+        if (r->defer_t0 == 0) r->defer_t0 = t;
+        defer = t - r->defer_t0 < r->lone_defer_ms && r->deferred_bytes + new_bytes < lanes_worth;
     }
     if (!defer) {
         const int st = ring_start_service(r);
@@ -460,6 +474,8 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.ldesc = ldesc.as<uint4>();
     q.lmask = lslots - 1;
     q.long_bytes = long_bytes;
+    q.xp = xp_cus ? 1u : 0u;
+    q.long_spill = xp_cus ? xp_cus * 64u / 2u : 0u;  // the pair lanes help out once half the express lanes' worth of long chunks waits
     q.ctl = ctl.as<pbsk::RingCtl>();
     q.cells = cells.as<uint8_t>();
     q.pending = pending.as<uint32_t>();
@@ -469,6 +485,11 @@ pbsk::RingSource pbsgpu_ring::source() const {
     if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.05, atof(v));
     q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
     q.heartbeat = heartbeat.as<uint32_t>();
+    {   // poll period of waves that carry work (power of two; 1 = every step, the behaviour before round 4)
+        int every = 8;
+        if (const char *v = getenv("PBSGPU_RING_POLL_EVERY")) every = std::max(1, atoi(v));
+        q.poll_mask = pow2_at_least((uint64_t)every) - 1u;
+    }
     return q;
 }
 
@@ -610,7 +631,16 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - e->num_cus / 4);
         if (!o.sha_cus)
             if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
-        r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1));
+        // EXPRESS service (PBSGPU_RING_XP_CUS, off by default): that many CUs run k_sha256_xpair — two lanes per chunk, the
+        // chain of a chunk 1.5x faster at 0.74 of the throughput per CU — on the chunks of at least long_bytes
+        // (default 5/8 of the maximum: a 10 MiB chunk on a pair lane and a 16 MiB one on an express pair then take the same
+        // ~0.3 s). The CUs come out of the pair service's share unless that was given explicitly.
+        int xp = 0;
+        if (const char *v = getenv("PBSGPU_RING_XP_CUS")) xp = std::max(0, atoi(v));
+        xp = std::min(xp, std::max(0, e->num_cus / 2));
+        if (xp && !o.sha_cus && !getenv("PBSGPU_RING_SHA_CUS")) sha = std::max(1, sha - xp);
+        r->xp_cus = (uint32_t)xp;
+        r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1 - xp));
         r->round_pages = o.round_pages ? o.round_pages : 256;
         if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
         r->round_pages = std::min(r->round_pages, r->npages);
@@ -652,8 +682,9 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // bytes of random data): idle lanes look at it first
         // (OFF by default: measured +0.8 % on the bench line for +40 ms of single-file latency — the drain is not made of
         // late-starting long chunks; kept as a switch)
-        r->long_bytes = 0;
+        r->long_bytes = r->xp_cus ? (uint32_t)((uint64_t)e->cfg.max * 5 / 8) : 0;
         if (const char *v = getenv("PBSGPU_RING_LONG_BYTES")) r->long_bytes = (uint32_t)std::max(0L, atol(v));
+        if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);
         CHK(r->ldesc.ensure((size_t)r->lslots * 32));
         CHK(r->scalars.ensure(pbsk::kRsCount * 4 + 64));
@@ -706,6 +737,10 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&r->ss, hipStreamNonBlocking, hi));
+        if (r->xp_cus) {
+            HIPCHK(hipStreamCreateWithPriority(&r->xs, hipStreamNonBlocking, hi));
+            HIPCHK(hipEventCreateWithFlags(&r->ev_xsvc1, hipEventDisableTiming));
+        }
         HIPCHK(hipEventCreateWithFlags(&r->ev_reset, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&r->ev_svc0));
         HIPCHK(hipEventCreate(&r->ev_svc1));
@@ -751,10 +786,7 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
         HIPCHK(hipStreamSynchronize(r->cs));
         HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
         HIPCHK(hipEventRecord(r->ev_reset, r->cs));
-        HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));
-        HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
-        HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
-        HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
+        CHK(ring_launch_services(r));
         g_services.fetch_add(1, std::memory_order_acq_rel);
         r->svc = SvcState::Running;
         r->st.service_launches++;
@@ -800,6 +832,8 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
             g_services.fetch_sub(1, std::memory_order_acq_rel);
         }
         if (r->ss) (void)hipStreamDestroy(r->ss);
+        if (r->xs) (void)hipStreamDestroy(r->xs);
+        if (r->ev_xsvc1) (void)hipEventDestroy(r->ev_xsvc1);
         if (r->cs) (void)hipStreamDestroy(r->cs);
         if (r->fs) (void)hipStreamDestroy(r->fs);
         for (auto ev : r->ev_fill)
@@ -1016,7 +1050,9 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
         // the deferral has lasted long enough
         bool waiting = false;
         for (auto &s : r->slots) waiting |= s.open && !s.ready.empty();
-        if ((!any_round && !waiting) || now_ms() - r->defer_t0 >= r->lone_defer_ms) CHK(ring_start_service(r));
+        const uint64_t lanes_worth = (uint64_t)r->sha_cus * 128u * (uint64_t)r->eng->cfg.avg;
+        if ((!any_round && !waiting) || now_ms() - r->defer_t0 >= r->lone_defer_ms || r->deferred_bytes >= lanes_worth)
+            CHK(ring_start_service(r));
     }
     if (r->autopark_ms > 0 && r->svc == SvcState::Running) {  // nothing anywhere in the ring: give the CUs (and hipFree) back
         if (ring_idle(r)) {

@@ -12,7 +12,9 @@
 namespace pbse {
 
 constexpr uint32_t kRingInputs = 16;            // rounds whose host-written tables may be in flight
-constexpr uint32_t kPagesPerStreamRound = 48;   // < kRingPT - 2 (open chunk) with room to spare
+constexpr uint32_t kPagesPerStreamRound = 256;  // < kRingPT - 2 (open chunk). It was 48 until a lone 64 GiB file turned out to
+                                                // go through 83 small rounds, none of them large enough for the cut-ahead at
+                                                // full chip width (ring_enqueue_round): a whole default round per stream now
 
 struct PageReq {                          // a committed page waiting for its round
     uint32_t phys = 0;
@@ -99,7 +101,9 @@ struct pbsgpu_ring {
     size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_segstat_off = 0, in_recbase_off = 0, in_suggidx_off = 0,
            in_status_off = 0;
     hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
-    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr;
+    hipStream_t xs = nullptr;             // the EXPRESS service (two lanes per chunk, long chunks only) when xp_cus > 0
+    uint32_t xp_cus = 0;
+    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr, ev_xsvc1 = nullptr;
     hipEvent_t ev_fill[pbse::kRingInputs] = {};
     std::vector<hipEvent_t> ev_pool;      // page dependency events (ring_event_get / ring_event_put)
     pbse::SvcState svc = pbse::SvcState::Stopped;
