@@ -1634,6 +1634,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
     __shared__ uint32_t ctrl_[NP][2][64];    // bit0 block valid, bit1 last block of its range
     __shared__ uint8_t *dstp_[NP][2][64];    // digest destination (valid when bit1)
     __shared__ uint32_t alive[NP][2];        // [pair][buffer]: producer still had blocks
+    __shared__ uint32_t curw[NP][2];         // [pair][buffer]: the pair had a block in this step (ring service: who may nap)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int pr = (wave & 1) | (wave >= 4 ? 2 : 0);
@@ -1874,6 +1875,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
 #pragma unroll
         for (int s = 0; s < D; ++s) prep(s);
         bool running = true;
+        [[maybe_unused]] bool wg_busy = false;  // some pair of this workgroup had a block in the previous step
         while (running) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -1969,14 +1971,23 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                                     }
                                 }
                             }
-                            __builtin_amdgcn_s_sleep(48);
+                            // (nap only while the WHOLE workgroup is idle: the pairs of a workgroup share the block barrier, and
+                            // an idle pair that slept 1.3 us per step held its working sibling at 1.9 us per block instead of 1.7
+                            // — the chain of every chunk in a draining ring, of every chunk of a lone file)
+                            if (!wg_busy) __builtin_amdgcn_s_sleep(48);
                         } else {
                             idle_since = 0;
                         }
+                        if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
                     if (!any_alive(pb)) running = false;  // every pair drained
+                    if constexpr (Source::kRing) {
+                        uint32_t w = curw[0][pb] | curw[1][pb];
+                        if constexpr (DENSE) w |= curw[2][pb] | curw[3][pb];
+                        wg_busy = w != 0u;
+                    }
                 }
             }
         }
@@ -2137,6 +2148,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
     __shared__ uint32_t ctrl_[2][2][2][32];    // [pair][buffer][plane][chunk]: bit0 block valid, bit1 last block of its chunk
     __shared__ uint8_t *dstp_[2][2][2][32];    // digest destination (valid when bit1)
     __shared__ uint32_t alive[2][2];           // [pair][buffer]: producer still had blocks
+    __shared__ uint32_t curw[2][2];            // [pair][buffer]: the pair had a block in this step
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int pr = wave & 1;
@@ -2306,6 +2318,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
 #pragma unroll
         for (int s = 0; s < D; ++s) prep(s);
         bool running = true;
+        [[maybe_unused]] bool wg_busy = false;
         while (running) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -2359,11 +2372,13 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         // idle self-stop of a silent host is the pair service's business: it raises `stop` for both.)
                         const bool wave_done = __ballot(!exhausted) == 0ull;
                         live = any_cur || !wave_done;
-                        if (!any_cur && !wave_done) __builtin_amdgcn_s_sleep(48);
+                        if (!any_cur && !wave_done && !wg_busy) __builtin_amdgcn_s_sleep(48);  // (never while the sibling pair works)
+                        if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
                     if (!any_alive(pb)) running = false;
+                    if constexpr (Source::kRing) wg_busy = (curw[0][pb] | curw[1][pb]) != 0u;
                 }
             }
         }
