@@ -49,6 +49,7 @@ type (
 	RingOptions struct {
 		ArenaBytes, PageBytes          uint64
 		MaxStreams, ShaCUs, RoundPages uint32
+		ExpressCUs                     uint32
 	}
 	RingStats struct {
 		PageBytes, BytesEnqueued, Chunks uint64
@@ -120,4 +121,5 @@ func (r *Ring) Quiesce() error                                                  
 func (r *Ring) Park() error                                                      { return ErrNotBuilt }
 func (r *Ring) Suggest(uint32, uint64) error                                     { return ErrNotBuilt }
 func (r *Ring) Stats() (RingStats, error)                                        { return RingStats{}, ErrNotBuilt }
+func (r *Ring) Express() (uint32, uint64, error)                                 { return 0, 0, ErrNotBuilt }
 func (r *Ring) Close()                                                           {}

@@ -645,12 +645,16 @@ type Ring struct {
 type RingOptions struct {
 	ArenaBytes, PageBytes         uint64
 	MaxStreams, ShaCUs, RoundPages uint32
+	// ExpressCUs run the two-lanes-per-chunk SHA-256 form on the long chunks (>= 5/8 of the maximum size): the chain of a
+	// chunk ~1.4x faster at ~0.65 of the throughput per CU. For rings whose latency matters more than their CU-time.
+	ExpressCUs uint32
 }
 
 func (e *Engine) NewRing(o RingOptions) (*Ring, error) {
 	defer runtime.KeepAlive(e)
 	co := C.pbsgpu_ring_options{arena_bytes: C.uint64_t(o.ArenaBytes), page_bytes: C.uint64_t(o.PageBytes),
-		max_streams: C.uint32_t(o.MaxStreams), sha_cus: C.uint32_t(o.ShaCUs), round_pages: C.uint32_t(o.RoundPages)}
+		max_streams: C.uint32_t(o.MaxStreams), sha_cus: C.uint32_t(o.ShaCUs), round_pages: C.uint32_t(o.RoundPages),
+		express_cus: C.uint32_t(o.ExpressCUs)}
 	r := &Ring{eng: e}
 	if err := check(C.pbsgpu_ring_create(e.h, &co, &r.h), "ring_create"); err != nil {
 		return nil, err
@@ -790,6 +794,17 @@ func (r *Ring) Stats() (RingStats, error) {
 	}
 	return RingStats{uint64(st.page_bytes), uint64(st.bytes_enqueued), uint64(st.chunks), uint32(st.pages_total),
 		uint32(st.pages_free), uint32(st.rounds), float64(st.service_ms_last)}, nil
+}
+
+// Express reports the CUs of the ring's express service (0 = none) and the chunk size from which a chunk takes it.
+func (r *Ring) Express() (cus uint32, longBytes uint64, err error) {
+	defer runtime.KeepAlive(r)
+	var c C.uint32_t
+	var l C.uint64_t
+	if err = check(C.pbsgpu_ring_express(r.h, &c, &l), "ring_express"); err != nil {
+		return 0, 0, err
+	}
+	return uint32(c), uint64(l), nil
 }
 
 func (r *Ring) Close() {

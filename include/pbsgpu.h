@@ -309,7 +309,12 @@ typedef struct pbsgpu_ring_options {
     uint32_t max_streams;  /* streams open at once; 0 = 64 */
     uint32_t sha_cus;      /* CUs of the SHA-256 service; 0 = three quarters of the chip (the rest runs the cut rounds) */
     uint32_t round_pages;  /* most pages one round cuts; 0 = 256 */
-    uint32_t reserved;
+    uint32_t express_cus;  /* CUs of the EXPRESS service (two lanes per chunk: the SHA-256 chain of a chunk runs ~1.4x faster at
+                            * ~0.65 of the throughput per CU) for the longest chunks (>= 13/16 of the maximum size: 1.3 % of
+                            * the chunks of random data; PBSGPU_RING_LONG_BYTES). 0 = the default: 16 CUs out of the default
+                            * service share when sha_cus is 0 too (measured: throughput unchanged, a lone 64 GiB file 15 %
+                            * sooner, the drain of a burst 0.08 s shorter), none when sha_cus is given. A value given here
+                            * comes ON TOP of a given sha_cus. PBSGPU_RING_XP_CUS overrides (0 = off). (`reserved` before.) */
 } pbsgpu_ring_options;
 typedef struct pbsgpu_ring_stats {
     uint64_t page_bytes, bytes_enqueued, chunks, candidates, pages_enqueued, pages_recycled, service_bytes_last;
@@ -372,6 +377,8 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *ring);
  * process to be possible again soon. */
 int pbsgpu_ring_park(pbsgpu_ring *ring);
 int pbsgpu_ring_get_stats(pbsgpu_ring *ring, pbsgpu_ring_stats *out);
+/* How the ring's service is laid out: CUs of the express service (0 = none) and the chunk size from which a chunk takes it. */
+int pbsgpu_ring_express(pbsgpu_ring *ring, uint32_t *express_cus, uint64_t *long_bytes);
 /* Diagnostic text snapshot of the ring's device-side state (queue words, page reference counts, stream states). */
 int pbsgpu_ring_debug(pbsgpu_ring *ring, char *buf, uint64_t cap);
 

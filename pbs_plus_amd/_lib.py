@@ -85,7 +85,7 @@ class FileHash(C.Structure):
 
 class RingOptions(C.Structure):
     _fields_ = [("arena_bytes", C.c_uint64), ("page_bytes", C.c_uint64), ("max_streams", C.c_uint32),
-                ("sha_cus", C.c_uint32), ("round_pages", C.c_uint32), ("reserved", C.c_uint32)]
+                ("sha_cus", C.c_uint32), ("round_pages", C.c_uint32), ("express_cus", C.c_uint32)]
 
 
 class RingStats(C.Structure):
@@ -174,6 +174,7 @@ SYMBOLS = {
     "pbsgpu_ring_suggest": (C.c_int, [_P, C.c_uint32, C.c_uint64]),
     "pbsgpu_ring_get_stats": (C.c_int, [_P, C.POINTER(RingStats)]),
     "pbsgpu_ring_debug": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
+    "pbsgpu_ring_express": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),

@@ -242,7 +242,9 @@ struct RingPage {
     uint32_t do_fill;
     const struct FillPiece *fill_tab;  // kind 5: the stream's piece table (mapped pinned), ascending dst_off, contiguous
     uint32_t fill_ntab;
-    uint32_t pad;
+    uint32_t prev_phys;    // physical page that holds the stream's PREVIOUS logical page (~0: this is the stream's first page).
+                           // Host-known, so the page's head pad — the scan's window warm-up — needs no device state:
+                           // scan(n + 1) can run while control(n) still resolves (launch_ring_round)
 };
 // One piece of a synthetic EDITED stream (BASELINE.json configs[4] through the ring): stream bytes [dst_off, dst_off + len)
 // are generator 4's bytes (seed) at [src_off, src_off + len) — a kept extent of the base file, or newly written bytes.
@@ -303,7 +305,10 @@ struct RingRound {
     RingSource q;
     uint4 *desc_w;             // writable view of q.desc
     uint4 *ldesc_w;            // ... and of q.ldesc
-    // work buffers (one set: rounds run in order on one HIP stream)
+    // work buffers. The SCAN side (tile_cnt, tile_slots, tile_queue) exists twice: round n + 1 is scanned on its own HIP
+    // stream while round n's control kernel still reads round n's candidates; everything behind the scan runs in order on
+    // the control stream and has one set.
+    unsigned long long *tile_queue;  // the scan's dynamic tile counter
     uint32_t *scalars;         // SC_* layout of engine_internal.h
     uint32_t *tile_cnt, *tile_off, *tile_slots, *scan_tmp;
     uint64_t *dense;
@@ -330,8 +335,10 @@ struct RingRound {
 };
 // enqueue one cut round on `st` (fill -> pads/segments -> scan -> compaction -> resolve -> descriptors -> publish)
 // (`fill_st` / `fill_ev`: the synthetic producer's own stream and the event the cut waits for; null = same stream)
+// (`scan_st` / `scan_ev`: the scan's own stream — head pads + scan of this round may overlap the control kernel of the
+// previous one — and the event the control stream waits for; null = everything in order on `st`)
 hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st, hipStream_t fill_st = nullptr,
-                             hipEvent_t fill_ev = nullptr);
+                             hipEvent_t fill_ev = nullptr, hipStream_t scan_st = nullptr, hipEvent_t scan_ev = nullptr);
 // the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
 hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st);
 hipError_t launch_ring_service_xp(const RingSource &q, unsigned workgroups, hipStream_t st);

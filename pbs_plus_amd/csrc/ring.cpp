@@ -277,6 +277,8 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
             p.fill_kind = q.kind;
             p.fill_tab = q.tab;
             p.fill_ntab = q.ntab;
+            p.prev_phys = (q.k > 0 && s.last_phys >= 0) ? (uint32_t)s.last_phys : 0xffffffffu;
+            s.last_phys = (int64_t)q.phys;
             pg[np++] = p;
             if (q.dep) deps.push_back(q.dep);
             end += q.valid;
@@ -376,10 +378,12 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.q = r->source();
     rr.desc_w = r->desc.as<uint4>();
     rr.ldesc_w = r->ldesc.as<uint4>();
+    const uint32_t set = r->ps ? r->scan_set : 0u;
     rr.scalars = r->scalars.as<uint32_t>();
-    rr.tile_cnt = r->tile_cnt.as<uint32_t>();
+    rr.tile_queue = r->tileq.as<unsigned long long>() + set * 8u;
+    rr.tile_cnt = set ? r->tile_cnt2.as<uint32_t>() : r->tile_cnt.as<uint32_t>();
     rr.tile_off = r->tile_off.as<uint32_t>();
-    rr.tile_slots = r->tile_slots.as<uint32_t>();
+    rr.tile_slots = set ? r->tile_slots2.as<uint32_t>() : r->tile_slots.as<uint32_t>();
     rr.scan_tmp = r->scan_tmp.as<uint32_t>();
     rr.dense = r->dense.as<uint64_t>();
     rr.dense_cap = r->dense_cap;
@@ -425,16 +429,25 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
         r->deferred_bytes += new_bytes;
     }
     if (r->svc == SvcState::Stopped) rr.scan_blocks = (uint32_t)std::max(1, e->num_cus);  // nobody else on the chip: full width
+    else if (r->ps && rr.scan_blocks > 8) rr.scan_blocks -= 1;  // (one CU stays free for the control kernel that runs beside the scan)
+    hipStream_t scan_st = r->ps ? r->ps : r->cs;
     for (hipEvent_t ev : deps)  // host-fed pages: the cut waits for their copies (device-side wait; the copies never wait for a kernel)
-        if (hipStreamWaitEvent(r->cs, ev, 0) != hipSuccess) return fail(PBSGPU_E_HIP);
+        if (hipStreamWaitEvent(scan_st, ev, 0) != hipSuccess) return fail(PBSGPU_E_HIP);
     for (hipEvent_t ev : deps) ring_event_put(r, ev);
     deps.clear();
+    if (r->ps && r->ctl_used[set])  // this scan set's previous user must have been resolved before the scan overwrites it
+        if (hipStreamWaitEvent(r->ps, r->ev_ctl[set], 0) != hipSuccess) return fail(PBSGPU_E_HIP);
     {
-        const hipError_t he = pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in]);
+        const hipError_t he = pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in], r->ps, r->ps ? r->ev_scan[in] : nullptr);
         if (he != hipSuccess) {
             g_last_hip_error.store((int)he);
             return fail(PBSGPU_E_HIP);
         }
+    }
+    if (r->ps) {
+        if (hipEventRecord(r->ev_ctl[set], r->cs) != hipSuccess) return fail(PBSGPU_E_HIP);
+        r->ctl_used[set] = true;
+        r->scan_set ^= 1u;
     }
     r->input_busy[in] = true;
     ri.new_bytes = new_bytes;
@@ -631,11 +644,14 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - e->num_cus / 4);
         if (!o.sha_cus)
             if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
-        // EXPRESS service (PBSGPU_RING_XP_CUS, off by default): that many CUs run k_sha256_xpair — two lanes per chunk, the
-        // chain of a chunk 1.5x faster at 0.74 of the throughput per CU — on the chunks of at least long_bytes
-        // (default 5/8 of the maximum: a 10 MiB chunk on a pair lane and a 16 MiB one on an express pair then take the same
-        // ~0.3 s). The CUs come out of the pair service's share unless that was given explicitly.
-        int xp = 0;
+        // EXPRESS service: that many CUs run k_sha256_xpair — two lanes per chunk: the chain of a chunk 1.37x faster (1.28
+        // vs 1.75 us per block, profiles/r04_chain_time_pair_vs_express.log) at 0.65 of the throughput per CU — on the
+        // chunks of at least long_bytes. Bulk rings (default service share): 16 CUs for chunks >= 13/16 of the maximum
+        // (1.3 % of random data's chunks, 5 % of its bytes): the driver's line is unchanged within noise (the drain gets
+        // 0.08 s shorter, the feed phase 4 % slower: profiles/r04_ab_express_service.log), one file alone is 15 % sooner.
+        // The CUs come out of the pair service's share unless that was given explicitly.
+        int xp = (int)o.express_cus;
+        if (xp == 0 && !o.sha_cus && !getenv("PBSGPU_RING_SHA_CUS") && e->num_cus >= 128) xp = 16;
         if (const char *v = getenv("PBSGPU_RING_XP_CUS")) xp = std::max(0, atoi(v));
         xp = std::min(xp, std::max(0, e->num_cus / 2));
         if (xp && !o.sha_cus && !getenv("PBSGPU_RING_SHA_CUS")) sha = std::max(1, sha - xp);
@@ -682,7 +698,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // bytes of random data): idle lanes look at it first
         // (OFF by default: measured +0.8 % on the bench line for +40 ms of single-file latency — the drain is not made of
         // late-starting long chunks; kept as a switch)
-        r->long_bytes = r->xp_cus ? (uint32_t)((uint64_t)e->cfg.max * 5 / 8) : 0;
+        r->long_bytes = r->xp_cus ? (uint32_t)((uint64_t)e->cfg.max * 13 / 16) : 0;
         if (const char *v = getenv("PBSGPU_RING_LONG_BYTES")) r->long_bytes = (uint32_t)std::max(0L, atol(v));
         if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);
@@ -691,6 +707,13 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         CHK(r->tile_cnt.ensure((size_t)ntiles * 4 + 16));
         CHK(r->tile_off.ensure((size_t)ntiles * 4 + 16));
         CHK(r->tile_slots.ensure((size_t)ntiles * r->cap * 4 + 16));
+        CHK(r->tileq.ensure(128));
+        bool overlap = true;
+        if (const char *v = getenv("PBSGPU_RING_OVERLAP")) overlap = atoi(v) != 0;
+        if (overlap) {
+            CHK(r->tile_cnt2.ensure((size_t)ntiles * 4 + 16));
+            CHK(r->tile_slots2.ensure((size_t)ntiles * r->cap * 4 + 16));
+        }
         CHK(r->dense.ensure((size_t)r->dense_cap * 8 + 16));
         CHK(r->scan_tmp.ensure(pbsk::scan_tmp_words(std::max<uint64_t>(ntiles, r->max_streams)) * 4 + 64));
         CHK(r->segs.ensure((size_t)r->max_streams * sizeof(pbsgpu_segment)));
@@ -729,8 +752,14 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         HIPCHK(hipMemsetAsync(r->streams.p, 0, (size_t)r->max_streams * sizeof(pbsk::RingStreamState), r->cs));
         HIPCHK(hipMemsetAsync(r->pending.p, 0, (size_t)r->npages * 4 + 64, r->cs));
         HIPCHK(hipMemsetAsync(r->scalars.p, 0, pbsk::kRsCount * 4 + 64, r->cs));
+        HIPCHK(hipMemsetAsync(r->tileq.p, 0, 128, r->cs));
         HIPCHK(hipStreamSynchronize(r->cs));
         for (auto &ev : r->ev_fill) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (overlap) {
+            HIPCHK(hipStreamCreateWithFlags(&r->ps, hipStreamNonBlocking));
+            for (auto &ev : r->ev_scan) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            for (auto &ev : r->ev_ctl) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
         // the service must never share a hardware queue with a stream that enqueues behind it (packets of one queue
         // run in order: work queued behind a kernel that only ends on request would never start). HIP keeps one queue
         // pool per priority: the service gets the highest priority to itself.
@@ -835,7 +864,12 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         if (r->xs) (void)hipStreamDestroy(r->xs);
         if (r->ev_xsvc1) (void)hipEventDestroy(r->ev_xsvc1);
         if (r->cs) (void)hipStreamDestroy(r->cs);
+        if (r->ps) (void)hipStreamDestroy(r->ps);
         if (r->fs) (void)hipStreamDestroy(r->fs);
+        for (auto ev : r->ev_scan)
+            if (ev) (void)hipEventDestroy(ev);
+        for (auto ev : r->ev_ctl)
+            if (ev) (void)hipEventDestroy(ev);
         for (auto ev : r->ev_fill)
             if (ev) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : {r->ev_reset, r->ev_svc0, r->ev_svc1})
@@ -845,7 +879,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
                 if (q.dep) r->ev_pool.push_back(q.dep);
         for (auto ev : r->ev_pool) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
-                          &r->tile_slots, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
+                          &r->tile_slots, &r->tile_cnt2, &r->tile_slots2, &r->tileq, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
                           &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->seg_fail})
             b->release();
         r->cells.release();
@@ -1148,6 +1182,13 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
                 *reinterpret_cast<const uint32_t *>(c + 48));
         }
     }
+    return PBSGPU_OK;
+}
+
+int pbsgpu_ring_express(pbsgpu_ring *r, uint32_t *express_cus, uint64_t *long_bytes) {
+    if (!r) return PBSGPU_E_INVALID;
+    if (express_cus) *express_cus = r->xp_cus;
+    if (long_bytes) *long_bytes = r->xp_cus ? r->long_bytes : 0;
     return PBSGPU_OK;
 }
 

@@ -45,6 +45,7 @@ struct StreamSlot {
     bool final_committed = false, final_enqueued = false, final_done = false;
     bool zero_final = false;              // final commit of 0 bytes still to be carried by a round
     int64_t reserved = -1;                // physical page handed out by reserve
+    int64_t last_phys = -1;               // physical page of the last page that went into a round (the next page's head pad source)
     std::deque<PageReq> ready;
     std::deque<CellRef> cells;            // record cells in stream order (round results reaped)
     uint64_t records_out = 0;
@@ -92,6 +93,7 @@ struct pbsgpu_ring {
     pbse::DevBuf arena, ctl, streams, pending, desc, ldesc;
     uint32_t lslots = 0, long_bytes = 0;
     pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
+    pbse::DevBuf tile_cnt2, tile_slots2, tileq;  // second set of the scan side (rounds alternate) + the two tile-queue counters
     pbse::DevBuf seg_ecand_in, seg_ecand, seg_fail;
     // mapped pinned
     pbse::PinnedBuf cells, free_fifo, inputs, heartbeat;
@@ -102,6 +104,12 @@ struct pbsgpu_ring {
            in_status_off = 0;
     hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
     hipStream_t xs = nullptr;             // the EXPRESS service (two lanes per chunk, long chunks only) when xp_cus > 0
+    hipStream_t ps = nullptr;             // scan side of the cut rounds (head pads + scan): round n + 1 is scanned while round n's
+                                          // control kernel runs on cs (PBSGPU_RING_OVERLAP=0: everything on cs)
+    hipEvent_t ev_scan[pbse::kRingInputs] = {};  // scan of the round built in input i done
+    hipEvent_t ev_ctl[2] = {};            // control kernel of the last round that used scan set 0 / 1 done
+    bool ctl_used[2] = {false, false};
+    uint32_t scan_set = 0;                // scan set of the next round
     uint32_t xp_cus = 0;
     hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr, ev_xsvc1 = nullptr;
     hipEvent_t ev_fill[pbse::kRingInputs] = {};

@@ -229,6 +229,12 @@ int engine_ring_get(pbsgpu_engine *e, pbsgpu_ring **out) {
         int cus = std::max(1, std::min(32, e->num_cus / 2));
         if (const char *v = getenv("PBSGPU_STREAM_SHA_CUS")) cus = std::max(1, std::min(atoi(v), e->num_cus - 1));
         o.sha_cus = (uint32_t)cus;
+        // ... and 8 more for the EXPRESS service: what an archive waits for at its end is the serial SHA-256 chain of its last
+        // long chunks (0.49 s for a 16 MiB chunk on a pair lane); two lanes per chunk finish it in 0.36 s, and a host-fed
+        // engine has CUs to spare (12.5 % of 50 GiB/s in chunks >= 10 MiB need 3 express CUs) (PBSGPU_STREAM_XP_CUS)
+        int xp = std::min(8, std::max(0, e->num_cus / 2 - cus));
+        if (const char *v = getenv("PBSGPU_STREAM_XP_CUS")) xp = std::max(0, std::min(atoi(v), e->num_cus / 2));
+        o.express_cus = (uint32_t)xp;
         o.max_streams = 256;
         if (const char *v = getenv("PBSGPU_STREAM_RING_SLOTS")) o.max_streams = (uint32_t)std::max(4, std::min(atoi(v), 4096));
         if (const char *v = getenv("PBSGPU_STREAM_PAGE_BYTES")) o.page_bytes = (uint64_t)std::max(0L, atol(v));

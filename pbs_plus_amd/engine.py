@@ -501,10 +501,11 @@ class PageRing:
     (internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836) when bytes are in device memory."""
 
     def __init__(self, eng: Engine, arena_bytes: int = 0, page_bytes: int = 0, max_streams: int = 0, sha_cus: int = 0,
-                 round_pages: int = 0):
+                 round_pages: int = 0, express_cus: int = 0):
         self._eng = eng
         self._L = eng._L
-        opt = _lib.RingOptions(int(arena_bytes), int(page_bytes), int(max_streams), int(sha_cus), int(round_pages), 0)
+        opt = _lib.RingOptions(int(arena_bytes), int(page_bytes), int(max_streams), int(sha_cus), int(round_pages),
+                               int(express_cus))
         h = C.c_void_p()
         check(self._L.pbsgpu_ring_create(eng._h, C.byref(opt), C.byref(h)), "ring_create")
         self._h = h
@@ -584,6 +585,12 @@ class PageRing:
         st = _lib.RingStats()
         check(self._L.pbsgpu_ring_get_stats(self._h, C.byref(st)), "ring_get_stats")
         return {k: getattr(st, k) for k, _ in _lib.RingStats._fields_}
+
+    def express(self) -> tuple:
+        """(CUs of the express service, chunk size from which a chunk takes it) — (0, 0) when the ring has none"""
+        cus, lb = C.c_uint32(0), C.c_uint64(0)
+        check(self._L.pbsgpu_ring_express(self._h, C.byref(cus), C.byref(lb)), "ring_express")
+        return int(cus.value), int(lb.value)
 
     def debug(self) -> str:
         buf = C.create_string_buffer(1 << 16)

@@ -223,6 +223,9 @@ class _FakeRing:
         return {"page_bytes": self.PAGE, "pages_total": 64, "sha_cus": 208, "rounds": self.rounds, "service_launches": self.launches,
                 "service_ms_last": 5.0, "service_bytes_last": getattr(self, "svc_last", 0), "chunks": 0, "bytes_enqueued": self.bytes}
 
+    def express(self):
+        return (16, 13 << 20)
+
     def close(self):
         pass
 
@@ -320,10 +323,14 @@ def test_bench_ring_workload_is_the_default_and_keeps_the_contract(monkeypatch):
     assert "page ring" in d["config"]["path"] and d["config"]["files_in_flight"] == 3
     assert d["config"]["bytes_per_step"] == 24 << 20 and d["config"]["distinct_data_per_step"] is True
     r = d["roofline"]
-    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "path", "single_file"):
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "path", "single_file"):
         assert key in r, key
     assert "RingSource" in r["kernel"] and r["service_launch_bytes"] == 5 * (24 << 20)
+    # the contract's form: the dominant kernel's algorithmic bytes / its duration against the HBM peak; the integer-issue
+    # ceiling that actually binds SHA-256 sits beside it
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["valu"]["frac"] - r["achieved"] / r["valu"]["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["records_match_gpu"] is True and c["kind"] == "port" and c["cores"] == 1
     sp = c["whole_file_restart_points"]
