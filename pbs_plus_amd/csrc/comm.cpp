@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <string>
 #include <rccl/rccl.h>
 
 #include "engine_internal.h"
@@ -34,14 +35,26 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r = []() {
         Rccl x;
-        // a process that already has an RCCL (PyTorch bundles one) keeps using THAT instance
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-            if (x.h) break;
+        // The RCCL that belongs to the HIP runtime THIS library runs on: the one installed beside it. A process may hold a
+        // second pair (PyTorch bundles its own libamdhip64 + librccl; whichever HIP runtime was loaded first is the one
+        // libpbsgpu is bound to): an RCCL built against the other runtime fails in ncclCommInitRank with "unhandled cuda
+        // error" (seen in the test process, where torch is imported after libpbsgpu). RTLD_LOCAL | RTLD_DEEPBIND: a second
+        // RCCL in the process must neither capture nor be captured by this one's symbols.
+        Dl_info di{};
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char *name : {"librccl.so.1", "librccl.so"}) {
+                    x.h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+                    if (x.h) break;
+                }
+            }
         }
         if (!x.h)
             for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-                x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                x.h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
                 if (x.h) break;
             }
         if (!x.h) return x;
