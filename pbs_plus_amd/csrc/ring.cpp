@@ -655,6 +655,11 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (const char *v = getenv("PBSGPU_RING_XP_CUS")) xp = std::max(0, atoi(v));
         xp = std::min(xp, std::max(0, e->num_cus / 2));
         if (xp && !o.sha_cus && !getenv("PBSGPU_RING_SHA_CUS")) sha = std::max(1, sha - xp);
+        // The cut side needs its share: with 13/16 of the chip (208 of 256 CUs) in service workgroups the driver's line falls
+        // to 525-545 GiB/s, with 216 the cut kernels barely find a CU (a warm-up of 5 files took 120 s:
+        // profiles/r04_ab_cu_split.log). Whatever was asked for, the services together get at most 3/4 of the chip + 8.
+        const int svc_max = std::max(2, e->num_cus - e->num_cus / 4 + (e->num_cus >= 64 ? 8 : 0));
+        if (sha + xp > svc_max) sha = std::max(1, svc_max - xp);
         r->xp_cus = (uint32_t)xp;
         r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1 - xp));
         r->round_pages = o.round_pages ? o.round_pages : 256;
