@@ -745,8 +745,18 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->input_stride = r->in_status_off + 64;
         CHK(r->inputs.ensure(r->input_stride * kRingInputs));
         std::memset(r->inputs.p, 0, r->input_stride * kRingInputs);
+        // Three priorities: the services highest (their own hardware-queue pool: nothing may queue behind a kernel that only
+        // ends on request), the CONTROL side of the rounds normal, the producers of bulk work — synthetic refill, scan —
+        // lowest: the one-workgroup control kernel and its prep launch find a CU as soon as one frees up instead of waiting
+        // behind the next round's scan workgroups (kernel trace of the driver's command: k_ring_prep 1.2 ms and
+        // k_ring_control 1.1 ms per launch for 10 us / 170 us of work; PBSGPU_RING_CUT_PRIO=0: all normal).
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        bool cut_prio = true;
+        if (const char *v = getenv("PBSGPU_RING_CUT_PRIO")) cut_prio = atoi(v) != 0;
+        r->bulk_prio = cut_prio ? prio_lo : 0;
         HIPCHK(hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&r->fs, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithPriority(&r->fs, hipStreamNonBlocking, r->bulk_prio));
         // The device-side state starts from zero — cleared ON THE CONTROL STREAM and waited for. A plain hipMemset is
         // queued on the null stream and returns at once for device memory; the ring's streams are non-blocking, i.e. not
         // ordered against the null stream: when the null stream was held up (it waits for every blocking stream's earlier
@@ -761,7 +771,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         HIPCHK(hipStreamSynchronize(r->cs));
         for (auto &ev : r->ev_fill) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         if (overlap) {
-            HIPCHK(hipStreamCreateWithFlags(&r->ps, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithPriority(&r->ps, hipStreamNonBlocking, r->bulk_prio));
             for (auto &ev : r->ev_scan) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             for (auto &ev : r->ev_ctl) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }

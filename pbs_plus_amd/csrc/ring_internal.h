@@ -110,6 +110,7 @@ struct pbsgpu_ring {
     hipEvent_t ev_ctl[2] = {};            // control kernel of the last round that used scan set 0 / 1 done
     bool ctl_used[2] = {false, false};
     uint32_t scan_set = 0;                // scan set of the next round
+    int bulk_prio = 0;                    // HIP priority of the refill and scan streams (lowest: the control side goes first)
     uint32_t xp_cus = 0;
     hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr, ev_xsvc1 = nullptr;
     hipEvent_t ev_fill[pbse::kRingInputs] = {};
