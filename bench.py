@@ -687,11 +687,9 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
                          "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
         except BaseException as exc:  # noqa: BLE001
             res[name] = {"error": repr(exc)}
-    # The host-fed legs go LAST (profiles/r03_extras_leg_order.log): whatever runs in this process behind the first
-    # host-fed leg loses 20-30 % (with the host-fed legs first: batch path 386 instead of 497 GiB/s, ring legs 289 / 343
-    # instead of 424 / 520, one writer 31 instead of 40; the eight-writer leg therefore shows 29-33 here and 38-44 in a
-    # process of its own). Cause: a process that has used more than ~20 hardware queues is time-sliced by the hardware
-    # scheduler from then on (GPU_MAX_HW_QUEUES=24 here; with 20 the effect is gone) - DESIGN.md section 9.
+    # (The host-fed legs ran last for a reason until round 4: with GPU_MAX_HW_QUEUES=24 a process that had used more than ~20
+    # hardware queues was time-sliced by the hardware scheduler from then on and every later leg lost 20-30 %,
+    # profiles/r03_extras_leg_order.log. With 20 the effect is gone and the order is free.)
     for label, key, producers, gib_steps, archives in (("hostfeed_1_writer", "hostfeed1", 1, 96, 1),
                                                        ("hostfeed_1_writer_4_archives", "hostfeed1", 1, 96, 4),
                                                        ("hostfeed_8_writers", "hostfeed8", 8, 32, 1)):

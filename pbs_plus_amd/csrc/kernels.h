@@ -188,7 +188,9 @@ struct alignas(64) RingCtl {   // device memory, one 64-byte line
     uint32_t error;        // sticky, ring-wide: a round overflowed its record / cell capacity (never a single stream's fault)
     uint32_t rounds_done;  // rounds published so far (k_ring_publish); the service compares it with the host's count of
                            // enqueued rounds before it stops on its own
-    uint32_t pad[8];
+    uint32_t xp_busy;      // express service: lane pairs that hold a chunk right now (the pair service's lanes take a long
+                           // chunk only while every express pair is busy: waiting for one would cost more than it saves)
+    uint32_t pad[7];
 };
 struct RingSource {
     static constexpr bool kRing = true;
@@ -221,6 +223,7 @@ struct RingSource {
     // claims for it, and leave without looking at it.
     uint32_t xp;
     uint32_t long_spill;
+    uint32_t xp_pairs;         // lane pairs of the express service (its CUs x 64)
 };
 constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHbRoundsEnq = 33;
 

@@ -1709,7 +1709,14 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 if (src.long_bytes && __ballot(elig)) {
                     const unsigned long long lq = __hip_atomic_load(&src.ctl->lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t lt = (uint32_t)lq, lh = (uint32_t)(lq >> 32);
-                    const int32_t avail = (int32_t)(lt - lh) - (int32_t)src.long_spill;  // (spill: what the express service's lanes are left)
+                    int32_t avail = (int32_t)(lt - lh) - (int32_t)src.long_spill;  // (spill: what the express service's lanes are left)
+                    // with an express service: only while ALL its lane pairs are busy — a long chunk that waited for one would
+                    // finish later than on a pair lane that is free now (configs[2]: half the bytes are 16 MiB chunks)
+                    // (safety valve: more long chunks waiting than the express service has pairs — e.g. its workgroups have not
+                    // found their CUs yet — are everybody's business)
+                    if (avail > 0 && src.xp != 0u && (uint32_t)avail <= src.xp_pairs &&
+                        __hip_atomic_load(&src.ctl->xp_busy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < src.xp_pairs)
+                        avail = 0;
                     if (avail > 0) {
                         const unsigned long long mn = __ballot(elig);
                         const uint32_t cnt = min((uint32_t)__popcll(mn), (uint32_t)avail);
@@ -2223,6 +2230,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         len1 = got ? e0.w : len1;
                         dst = got ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
                         pages = got ? e1.w : pages;
+                        if (lane == leader) atomicAdd(&src.ctl->xp_busy, cnt);  // (given back when the chunk's last block is in)
                     }
                 } else {
                     // nothing published: has the service been told to stop? (stop is raised behind the last publish; the
@@ -2331,7 +2339,12 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
                         // the chunk's LAST block is in registers (the partner's blocks of this step and all earlier ones
-                        // too: same load instructions, same wait): drop the chunk's page references, as the pair form does
+                        // too: same load instructions, same wait): the pair is free for the service's accounting, and the
+                        // chunk's page references are dropped, as the pair form does
+                        {
+                            const unsigned long long mdone = __ballot((c & 2u) != 0u);
+                            if (mdone && lane == (__ffsll((long long)mdone) - 1)) atomicSub(&src.ctl->xp_busy, (uint32_t)__popcll(mdone));
+                        }
                         if (c & 2u) {
                             const uint32_t pg = pagesv[s];
 #pragma unroll

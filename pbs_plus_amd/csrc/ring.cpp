@@ -488,7 +488,13 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.lmask = lslots - 1;
     q.long_bytes = long_bytes;
     q.xp = xp_cus ? 1u : 0u;
-    q.long_spill = xp_cus ? xp_cus * 64u / 2u : 0u;  // the pair lanes help out once half the express lanes' worth of long chunks waits
+    // the pair lanes take a long chunk only while EVERY express pair is busy (RingCtl::xp_busy): random data keeps the express
+    // service just busy (2.6 long chunks per ms against the 2.8 it can take), a corpus whose files are mostly zero runs or
+    // periodic (configs[2]: half the bytes in 16 MiB chunks) swamps 16 CUs at once — and a long chunk that WAITS for an express
+    // pair (0.36 s + 0.36 s) finishes later than on a pair lane that is free now (0.49 s), holding its page all the while
+    // (measured with a queue-length rule instead: ring_manyfiles 441 -> 418 GiB/s, drain 0.50 -> 0.58 s)
+    q.long_spill = 0u;
+    q.xp_pairs = xp_cus * 64u;
     q.ctl = ctl.as<pbsk::RingCtl>();
     q.cells = cells.as<uint8_t>();
     q.pending = pending.as<uint32_t>();
@@ -595,7 +601,8 @@ int ring_commit_dep(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final,
     return PBSGPU_OK;
 }
 
-int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool hold_engine_ref, pbsgpu_ring **out) {
+int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool hold_engine_ref, pbsgpu_ring **out,
+                         uint32_t long_bytes_hint) {
     if (!e || !out) return PBSGPU_E_INVALID;
     *out = nullptr;
     CHK(set_device(e));
@@ -703,7 +710,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // bytes of random data): idle lanes look at it first
         // (OFF by default: measured +0.8 % on the bench line for +40 ms of single-file latency — the drain is not made of
         // late-starting long chunks; kept as a switch)
-        r->long_bytes = r->xp_cus ? (uint32_t)((uint64_t)e->cfg.max * 13 / 16) : 0;
+        r->long_bytes = r->xp_cus ? (long_bytes_hint ? long_bytes_hint : (uint32_t)((uint64_t)e->cfg.max * 13 / 16)) : 0;
         if (const char *v = getenv("PBSGPU_RING_LONG_BYTES")) r->long_bytes = (uint32_t)std::max(0L, atol(v));
         if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);

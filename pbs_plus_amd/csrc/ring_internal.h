@@ -152,7 +152,9 @@ struct pbsgpu_ring {
 namespace pbse {
 
 // ring.cpp internals the stream writer uses (caller holds ring->mu)
-int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool hold_engine_ref, pbsgpu_ring **out);
+// (long_bytes_hint: from which chunk size a chunk takes the express service; 0 = the default 13/16 of the maximum)
+int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool hold_engine_ref, pbsgpu_ring **out,
+                         uint32_t long_bytes_hint = 0);
 // an event from the ring's pool; record it behind the page's last copy / tee and hand it to ring_commit_dep
 int ring_event_get(pbsgpu_ring *r, hipEvent_t *ev);
 void ring_event_put(pbsgpu_ring *r, hipEvent_t ev);

@@ -23,6 +23,7 @@ timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/k_default -o bench -- pytho
 $EXP stats $(db $OUT/k_default) $OUT/kernel_stats_bench_default.csv; $EXP trace $(db $OUT/k_default) $OUT/kernel_trace_bench_default.csv
 gzip -f $OUT/kernel_trace_bench_default.csv
 head -9 $OUT/kernel_stats_bench_default.csv | cut -c1-220
+if [ -n "$SKIP_PMC" ]; then find $OUT -name "*.db" -delete; find $OUT -type d -empty -delete; exit 0; fi
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $OUT/pmc_sq -o s -- python3 $ROOT/scripts/r4_ring_pmc.py 48 4 > $OUT/ring_pmc_sq.json 2> $OUT/ring_pmc_sq.err
 $EXP counters $(db $OUT/pmc_sq) $OUT/pmc_sq_ring.csv
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python3 $ROOT/scripts/r4_ring_pmc.py 48 4 > $OUT/ring_pmc_fetch.json 2> $OUT/ring_pmc_fetch.err
