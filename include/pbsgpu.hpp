@@ -424,6 +424,12 @@ class PageRing {
         const int st = pbsgpu_ring_suggest(r_, stream, offset);
         return st == PBSGPU_OK ? std::string() : errorf("ring suggest", st);
     }
+    // {CUs of the express service (two lanes per chunk, the longest chunks), chunk size from which a chunk takes it}; {0, 0}: none
+    std::pair<uint32_t, uint64_t> Express() const {
+        std::pair<uint32_t, uint64_t> r{0, 0};
+        (void)pbsgpu_ring_express(r_, &r.first, &r.second);
+        return r;
+    }
 
   private:
     PageRing(std::shared_ptr<Engine> eng, pbsgpu_ring *r, Sink sink) : eng_(std::move(eng)), r_(r), sink_(std::move(sink)) {}
