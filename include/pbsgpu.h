@@ -445,7 +445,10 @@ const char *pbsgpu_comm_last_error(void);
 /* Collective. recs[0..n) (host memory, n <= cap_records) = this rank's records; cap_records must be the SAME on every
  * rank (bytes per rank / minimum chunk size is a bound every rank can compute). *stats describes the union over all
  * ranks and is identical on every rank; dup_own[i] (may be NULL) = 1 when an earlier record of the union — a lower rank's,
- * or this rank's with a lower index — carries the same digest. ~48 B per chunk travel: 12 MB per TiB of corpus. */
+ * or this rank's with a lower index — carries the same digest. ~48 B per chunk travel: 12 MB per TiB of corpus.
+ * Errors are collective too: bad arguments (n > cap_records, recs NULL with n > 0), capacities that differ between ranks or
+ * an allocation that fails on ONE rank make EVERY rank return that error from this call — the ranks agree over two 64-byte
+ * all-gathers before the large one, so no rank is left waiting inside it. (Only comm / stats NULL fail locally.) */
 int pbsgpu_digest_allgather_dedup(pbsgpu_comm *comm, const pbsgpu_record *recs, uint64_t n, uint64_t cap_records,
                                   uint8_t *dup_own /* n, may be NULL */, pbsgpu_dedup_stats *stats);
 

@@ -14,9 +14,26 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <string>
-#include <rccl/rccl.h>
 
 #include "engine_internal.h"
+
+// RCCL's few types, declared here instead of <rccl/rccl.h>: the library itself is resolved at run time (dlopen below), so a
+// host without the RCCL development headers can still build libpbsgpu (round 5; the header used to be a hard build
+// dependency). Layouts per the NCCL API both RCCL and NCCL keep stable: an opaque communicator pointer, a 128-byte id
+// passed BY VALUE, int-sized result and datatype enums.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct {
+    char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+}
+namespace {
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint8 = 1;
+}  // namespace
 
 using namespace pbse;
 
@@ -84,6 +101,17 @@ int comm_fail(const char *what, ncclResult_t rc) {
 
 constexpr uint64_t kSlotHeader = 64;  // [count u64 | pad] in front of a rank's records: keeps the records 64-byte aligned
 
+// What the ranks tell each other BEFORE the large all-gather (one 64-byte all-gather per agreement step): a rank that cannot
+// take part — bad arguments, an allocation that failed — says so here, and EVERY rank returns the same error together.
+// (Round 4 returned from the failing rank alone and left the others waiting inside ncclAllGather; a capacity mismatch was
+// only looked for after an all-gather whose slot sizes already disagreed.)
+struct CommHeader {
+    int64_t status;       // PBSGPU_OK or the rank's error
+    uint64_t n, cap;      // records of this rank, the capacity it was called with
+    uint64_t pad[5];
+};
+static_assert(sizeof(CommHeader) == 64, "header size");
+
 }  // namespace
 
 struct pbsgpu_comm {
@@ -92,9 +120,38 @@ struct pbsgpu_comm {
     int rank = 0, world = 1;
     hipStream_t st = nullptr;
     DevBuf send, recv, dense;
-    PinnedBuf h_send, h_counts, h_items;
+    DevBuf d_hdr;            // [own header | world headers]: allocated at create, so an agreement step can never fail to allocate
+    PinnedBuf h_send, h_hdr, h_items;
     std::mutex mu;  // one collective at a time per communicator
 };
+
+namespace {
+// One agreement step: every rank contributes (status, n, cap); returns the headers of all ranks in c->h_hdr[1 .. world].
+// Only a dead device or a broken communicator fails here — conditions no exchange could report anyway.
+int comm_agree(pbsgpu_comm *c, int status, uint64_t n, uint64_t cap) {
+    CommHeader *hh = c->h_hdr.as<CommHeader>();
+    std::memset(&hh[0], 0, sizeof(CommHeader));
+    hh[0].status = status;
+    hh[0].n = n;
+    hh[0].cap = cap;
+    uint8_t *d = c->d_hdr.as<uint8_t>();
+    HIPCHK(hipMemcpyAsync(d, &hh[0], sizeof(CommHeader), hipMemcpyHostToDevice, c->st));
+    if (const ncclResult_t rc = rccl().AllGather(d, d + sizeof(CommHeader), sizeof(CommHeader), ncclUint8, c->comm, c->st);
+        rc != ncclSuccess)
+        return comm_fail("ncclAllGather (agreement)", rc);
+    HIPCHK(hipMemcpyAsync(&hh[1], d + sizeof(CommHeader), (size_t)c->world * sizeof(CommHeader), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return PBSGPU_OK;
+}
+// the first error any rank reported (this rank's own first), or PBSGPU_OK
+int comm_verdict(const pbsgpu_comm *c) {
+    const CommHeader *hh = c->h_hdr.as<CommHeader>();
+    if (hh[1 + c->rank].status != PBSGPU_OK) return (int)hh[1 + c->rank].status;
+    for (int r = 0; r < c->world; ++r)
+        if (hh[1 + r].status != PBSGPU_OK) return (int)hh[1 + r].status;
+    return PBSGPU_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -119,8 +176,9 @@ void pbsgpu_comm_destroy(pbsgpu_comm *c) {
     c->send.release();
     c->recv.release();
     c->dense.release();
+    c->d_hdr.release();
     c->h_send.release();
-    c->h_counts.release();
+    c->h_hdr.release();
     c->h_items.release();
     delete c;
     if (e) engine_unref(e);
@@ -142,6 +200,8 @@ int pbsgpu_comm_create(pbsgpu_engine *e, const uint8_t id[PBSGPU_COMM_ID_BYTES],
     std::memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
     int st = PBSGPU_OK;
     if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) st = PBSGPU_E_HIP;
+    if (st == PBSGPU_OK) st = c->d_hdr.ensure((size_t)(world + 1) * sizeof(CommHeader));
+    if (st == PBSGPU_OK) st = c->h_hdr.ensure((size_t)(world + 1) * sizeof(CommHeader));
     if (st == PBSGPU_OK) {
         ncclResult_t rc = r.CommInitRank(&c->comm, world, u, rank);
         if (rc != ncclSuccess && world == 1) {
@@ -182,51 +242,66 @@ int pbsgpu_comm_rank(const pbsgpu_comm *c, int *rank, int *world) {
     return PBSGPU_OK;
 }
 
-// The digest-set reduce. Collective. `recs` (host, n <= cap_records) = this rank's records; cap_records must be the SAME on
-// every rank (the all-gather moves fixed-size slots; bytes / min chunk size is a bound every rank can compute). On return
+// The digest-set reduce. Collective: every rank calls it, in the same order. `recs` (host, n <= cap_records) = this rank's
+// records; cap_records must be the SAME on every rank (bytes / min chunk size is a bound every rank can compute). On return
 // `stats` describes the union over all ranks (identical on every rank); dup_own[i] = 1 when an EARLIER record of the union
 // — lower rank, or same rank and lower index — carries the same digest (may be NULL).
+// Errors are COLLECTIVE too: bad arguments, capacities that disagree or an allocation that fails on ONE rank make EVERY
+// rank return that error from this call (two 64-byte agreement all-gathers around the allocation), nobody is left inside
+// the large all-gather. What travels is [count | max over ranks of n records] per rank — not the capacity — and the unused
+// tail of a rank's slot is zeroed.
 int pbsgpu_digest_allgather_dedup(pbsgpu_comm *c, const pbsgpu_record *recs, uint64_t n, uint64_t cap_records,
                                   uint8_t *dup_own, pbsgpu_dedup_stats *stats) {
-    if (!c || !stats || (!recs && n) || n > cap_records || cap_records == 0) return PBSGPU_E_INVALID;
+    if (!c || !stats) return PBSGPU_E_INVALID;  // (no communicator to tell the others with)
     pbsgpu_engine *e = c->eng;
     std::lock_guard<std::mutex> lk(c->mu);
     CHK(set_device(e));
-    const uint64_t slot = kSlotHeader + cap_records * sizeof(pbsgpu_record);
-    if (slot * (uint64_t)c->world >= (1ull << 40)) return PBSGPU_E_INVALID;
-    CHK(c->send.ensure(slot));
-    CHK(c->recv.ensure(slot * (uint64_t)c->world));
-    CHK(c->h_send.ensure(slot));
-    CHK(c->h_counts.ensure((size_t)c->world * 8));
-    // only the bytes that exist travel to the device: header + n records
+    // ---- agreement 1: arguments ----------------------------------------------------------------------------------------
+    int mine = PBSGPU_OK;
+    if ((!recs && n) || n > cap_records || cap_records == 0) mine = PBSGPU_E_INVALID;
+    CHK(comm_agree(c, mine, mine == PBSGPU_OK ? n : 0, cap_records));
+    if (const int v = comm_verdict(c); v != PBSGPU_OK) return v;
+    const CommHeader *hh = c->h_hdr.as<CommHeader>() + 1;
+    uint64_t total = 0, own_first = 0, maxn = 0;
+    std::vector<uint64_t> cnt((size_t)c->world);
+    bool caps_agree = true;
+    for (int r = 0; r < c->world; ++r) {
+        caps_agree &= hh[r].cap == cap_records;
+        cnt[(size_t)r] = hh[r].n;
+        if (r == c->rank) own_first = total;
+        total += hh[r].n;
+        maxn = std::max(maxn, hh[r].n);
+    }
+    if (!caps_agree) return PBSGPU_E_INVALID;  // (every rank sees the same headers: every rank returns here)
+    std::memset(stats, 0, sizeof(*stats));
+    if (total == 0) return PBSGPU_OK;
+    if (total >= (1ull << 32)) return PBSGPU_E_INVALID;
+    const uint64_t slot = kSlotHeader + maxn * sizeof(pbsgpu_record);
+    // ---- agreement 2: memory -------------------------------------------------------------------------------------------
+    mine = PBSGPU_OK;
+    if (slot * (uint64_t)c->world >= (1ull << 40)) mine = PBSGPU_E_INVALID;
+    if (mine == PBSGPU_OK) mine = c->send.ensure(slot);
+    if (mine == PBSGPU_OK) mine = c->recv.ensure(slot * (uint64_t)c->world);
+    if (mine == PBSGPU_OK) mine = c->h_send.ensure(slot);
+    if (mine == PBSGPU_OK) mine = c->dense.ensure(total * sizeof(pbsgpu_record));
+    CHK(comm_agree(c, mine, n, cap_records));
+    if (const int v = comm_verdict(c); v != PBSGPU_OK) return v;
+    // ---- the exchange: header + n records from the host, the rest of the slot zeroed on the device ----------------------
     uint8_t *hs = c->h_send.as<uint8_t>();
     std::memset(hs, 0, kSlotHeader);
     std::memcpy(hs, &n, 8);
     if (n) std::memcpy(hs + kSlotHeader, recs, n * sizeof(pbsgpu_record));
-    HIPCHK(hipMemcpyAsync(c->send.p, hs, kSlotHeader + n * sizeof(pbsgpu_record), hipMemcpyHostToDevice, c->st));
+    const uint64_t used = kSlotHeader + n * sizeof(pbsgpu_record);
+    HIPCHK(hipMemcpyAsync(c->send.p, hs, used, hipMemcpyHostToDevice, c->st));
+    if (used < slot) HIPCHK(hipMemsetAsync(c->send.as<uint8_t>() + used, 0, slot - used, c->st));
     if (const ncclResult_t rc = rccl().AllGather(c->send.p, c->recv.p, slot, ncclUint8, c->comm, c->st); rc != ncclSuccess)
         return comm_fail("ncclAllGather", rc);
-    // the counts of all ranks (8 bytes each) decide the compaction
-    uint64_t *hc = c->h_counts.as<uint64_t>();
-    for (int r = 0; r < c->world; ++r)
-        HIPCHK(hipMemcpyAsync(hc + r, c->recv.as<uint8_t>() + (uint64_t)r * slot, 8, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    uint64_t total = 0, own_first = 0;
-    for (int r = 0; r < c->world; ++r) {
-        if (hc[r] > cap_records) return PBSGPU_E_INVALID;  // a rank used another capacity: the slots do not line up
-        if (r == c->rank) own_first = total;
-        total += hc[r];
-    }
-    std::memset(stats, 0, sizeof(*stats));
-    if (total == 0) return PBSGPU_OK;
-    if (total >= (1ull << 32)) return PBSGPU_E_INVALID;
     // compact the slots' records into one dense array (piece-table copy on the device), then the ordinary device dedup
-    CHK(c->dense.ensure(total * sizeof(pbsgpu_record)));
     constexpr uint64_t kPiece = 4ull << 20;
     std::vector<pbsk::PackItem> items;
     uint64_t dst = 0;
     for (int r = 0; r < c->world; ++r) {
-        const uint64_t bytes = hc[r] * sizeof(pbsgpu_record), src = (uint64_t)r * slot + kSlotHeader;
+        const uint64_t bytes = cnt[(size_t)r] * sizeof(pbsgpu_record), src = (uint64_t)r * slot + kSlotHeader;
         for (uint64_t o = 0; o < bytes; o += kPiece)
             items.push_back(pbsk::PackItem{src + o, dst + o, std::min<uint64_t>(kPiece, bytes - o), 0u, 0u});
         dst += bytes;

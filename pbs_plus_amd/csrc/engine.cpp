@@ -17,42 +17,122 @@ __attribute__((constructor)) static void pbsgpu_default_hw_queues() { setenv("GP
 
 namespace pbse {
 std::atomic<int> g_last_hip_error{0};
-std::atomic<int> g_services{0};
 
 namespace {
-std::mutex g_grave_mu;
-std::vector<void *> g_grave_dev, g_grave_host;
+constexpr int kMaxDevices = 64;
+struct Graveyard {
+    std::mutex svc_mu;               // service start <-> flush: no service may start on the device while parked memory is being
+                                     // freed (a hipFree issued then would wait for a kernel that only ends on request)
+    std::atomic<int> services{0};    // page-ring services launched on the device and not yet known to have ended
+    std::atomic<int> park_request{0};
+    std::atomic<uint32_t> park_gen{0};  // requests raised so far (a ring honours each request once)
+    std::mutex mu;                   // the lists below
+    std::vector<void *> dev, host;
+    uint64_t dev_bytes = 0, cap_bytes = 0;
+};
+Graveyard g_grave[kMaxDevices];
+
+// the device a pointer belongs to (device memory, or pinned host memory allocated under a device); the calling thread's
+// current device when HIP cannot tell
+int device_of(const void *p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) == hipSuccess && a.device >= 0 && a.device < kMaxDevices) return a.device;
+    (void)hipGetLastError();
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) (void)hipGetLastError();
+    return (d >= 0 && d < kMaxDevices) ? d : 0;
+}
+
+// really free what was parked on `device` — only with no service running there, and with none able to start meanwhile
+void graveyard_flush(int device) {
+    Graveyard &g = g_grave[device];
+    std::lock_guard<std::mutex> hold(g.svc_mu);
+    if (g.services.load(std::memory_order_acquire) > 0) return;  // (one started since the caller looked: its end flushes)
+    std::vector<void *> d, h;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        d.swap(g.dev);
+        h.swap(g.host);
+        g.dev_bytes = 0;
+    }
+    g.park_request.store(0, std::memory_order_release);
+    if (d.empty() && h.empty()) return;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    if (have_cur && cur != device) (void)hipSetDevice(device);
+    for (void *p : d) (void)hipFree(p);
+    for (void *p : h) (void)hipHostFree(p);
+    if (have_cur && cur != device) (void)hipSetDevice(cur);
+}
 }  // namespace
+
+void service_started(int device) {
+    if (device < 0 || device >= kMaxDevices) return;
+    Graveyard &g = g_grave[device];
+    std::lock_guard<std::mutex> hold(g.svc_mu);  // (a flush in progress finishes first: milliseconds)
+    g.services.fetch_add(1, std::memory_order_acq_rel);
+}
+
+void service_ended(int device) {
+    if (device < 0 || device >= kMaxDevices) return;
+    if (g_grave[device].services.fetch_sub(1, std::memory_order_acq_rel) == 1) graveyard_flush(device);
+}
+
+int services_running(int device) {
+    return (device >= 0 && device < kMaxDevices) ? g_grave[device].services.load(std::memory_order_acquire) : 0;
+}
+
+uint32_t service_park_generation(int device) {
+    if (device < 0 || device >= kMaxDevices) return 0;
+    Graveyard &g = g_grave[device];
+    return g.park_request.load(std::memory_order_acquire) ? g.park_gen.load(std::memory_order_acquire) : 0u;
+}
 
 void dev_free(void *p) {
     if (!p) return;
-    if (g_services.load(std::memory_order_acquire) > 0) {
-        std::lock_guard<std::mutex> lk(g_grave_mu);
-        g_grave_dev.push_back(p);
-        return;
+    const int device = device_of(p);
+    Graveyard &g = g_grave[device];
+    if (g.services.load(std::memory_order_acquire) > 0) {
+        // how much is parked decides when the device's rings are asked to let go of their services
+        size_t size = 0;
+        hipDeviceptr_t base = nullptr;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
+            (void)hipGetLastError();
+            size = 0;
+        }
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.services.load(std::memory_order_acquire) > 0) {  // (still: a flush takes g.mu after the count reached zero)
+            if (g.cap_bytes == 0) {  // default: an eighth of the device's memory
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess) g.cap_bytes = std::max<uint64_t>(tot / 8, 1ull << 30);
+                else g.cap_bytes = 8ull << 30;
+            }
+            uint64_t cap = g.cap_bytes;
+            if (const char *v = getenv("PBSGPU_GRAVEYARD_MIB")) cap = (uint64_t)(std::max(1.0, atof(v)) * 1048576.0);
+            g.dev.push_back(p);
+            g.dev_bytes += size;
+            if (g.dev_bytes > cap && g.park_request.load(std::memory_order_relaxed) == 0) {
+                g.park_gen.fetch_add(1, std::memory_order_acq_rel);
+                g.park_request.store(1, std::memory_order_release);
+            }
+            return;
+        }
     }
     (void)hipFree(p);
 }
 
 void host_free(void *p) {
     if (!p) return;
-    if (g_services.load(std::memory_order_acquire) > 0) {
-        std::lock_guard<std::mutex> lk(g_grave_mu);
-        g_grave_host.push_back(p);
-        return;
+    const int device = device_of(p);
+    Graveyard &g = g_grave[device];
+    if (g.services.load(std::memory_order_acquire) > 0) {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.services.load(std::memory_order_acquire) > 0) {
+            g.host.push_back(p);
+            return;
+        }
     }
     (void)hipHostFree(p);
-}
-
-void graveyard_flush() {
-    std::vector<void *> d, h;
-    {
-        std::lock_guard<std::mutex> lk(g_grave_mu);
-        d.swap(g_grave_dev);
-        h.swap(g_grave_host);
-    }
-    for (void *p : d) (void)hipFree(p);
-    for (void *p : h) (void)hipHostFree(p);
 }
 }  // namespace pbse
 using namespace pbse;

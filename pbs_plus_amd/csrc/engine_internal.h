@@ -46,13 +46,19 @@ extern std::atomic<int> g_last_hip_error;
 
 // hipFree / hipHostFree wait for the WHOLE device — including a page ring's persistent SHA-256 service, which only ends
 // on request: a free issued while a service runs would block until someone stops it (for ever, if the caller is the
-// thread that would). Every release in this library therefore goes through these two: while any service is running the
-// pointer is parked in a graveyard and really freed when the last service has stopped (ring.cpp: quiesce / park / the
-// service's own stop) or at engine teardown.
-extern std::atomic<int> g_services;   // page-ring services launched and not yet known to have ended
+// thread that would). Every release in this library therefore goes through dev_free / host_free: while a service runs ON
+// THE DEVICE THE MEMORY BELONGS TO the pointer is parked in that device's graveyard and really freed when the device's last
+// service has stopped (ring.cpp: quiesce / park / the service's own stop); a device without a running service frees at once
+// (round 5: services and graveyard are tracked per device — a service on GPU 0 no longer parks the frees of GPU 1).
+// Parked DEVICE bytes are bounded: beyond the cap (an eighth of the device's memory, PBSGPU_GRAVEYARD_MIB) the device's
+// rings are asked to park their services (service_park_generation, honoured once per request by the next pump), the last one to end frees
+// everything and the services start again with the next round.
+void service_started(int device);     // a page-ring service is about to be launched (waits for a flush in progress)
+void service_ended(int device);       // ... is known to have ended; frees the device's parked memory when it was the last
+int services_running(int device);
+uint32_t service_park_generation(int device);  // 0 = no request pending, else the number of the pending request
 void dev_free(void *p);
 void host_free(void *p);
-void graveyard_flush();               // really free what was parked (call with no service running)
 
 // growable device buffer
 struct DevBuf {

@@ -92,9 +92,13 @@ struct SuggFeed {
     uint32_t absolute, open_end;
 };
 // Page-ring rounds (ring_kernels.inc): segments are the streams' open chunks + new pages in LOGICAL coordinates
-// ((slot << 40) | offset), suggested offsets are relative to the stream's byte 0, a segment's end is the stream's end only
+// ((slot << kRingOffBits) | offset), suggested offsets are relative to the stream's byte 0, a segment's end is the stream's end only
 // when its RingSeg says final, and the walk reports per segment what the round leaves behind (all null otherwise).
-constexpr uint64_t kRingOffMask = (1ull << 40) - 1ull;  // logical coordinates of a ring round: (stream slot << 40) | offset
+// logical coordinates of a ring round: (stream slot << kRingOffBits) | offset. A ring has at most 4096 stream slots (12 bits),
+// which leaves 52 bits = 4 PiB per stream (rounds 3-4: 40 bits = 1 TiB, which a payload stream without a forced cut — a
+// fresh multi-TiB backup, a tape conversion — could exceed)
+constexpr unsigned kRingOffBits = 52;
+constexpr uint64_t kRingOffMask = (1ull << kRingOffBits) - 1ull;
 struct RingSeg;
 struct ResolveRing {
     const RingSeg *segs_in = nullptr;
@@ -234,7 +238,7 @@ enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsTileq = 
 // One physical page of a round (host-written, mapped pinned memory; read by the round's kernels).
 struct RingPage {
     uint64_t phys_off;     // byte offset of the page BODY from the arena base (a 128-byte pad precedes and follows it)
-    uint64_t logical;      // (stream slot << 40) | offset of the page's first byte within its stream
+    uint64_t logical;      // (stream slot << kRingOffBits) | offset of the page's first byte within its stream
     uint32_t valid;        // bytes of the page that belong to the stream (== page size except a stream's last page)
     uint32_t slot;         // stream slot
     uint32_t phys;         // physical page index
@@ -267,7 +271,7 @@ struct RingSeg {
     uint64_t origin;       // payload position of the stream's byte 0 (suggested boundaries on the absolute reader grid)
 };
 // Device-resident state of a stream slot.
-constexpr uint64_t kRingMaxStream = 1ull << 40;  // logical coordinates are (stream slot << 40) | offset
+constexpr uint64_t kRingMaxStream = 1ull << kRingOffBits;  // logical coordinates are (stream slot << kRingOffBits) | offset
 constexpr uint32_t kRingPT = 512;      // page-table window per stream (open chunk <= 2 pages + new pages of one round)
 struct RingStreamState {
     uint64_t c;            // start of the open chunk (logical offset in the stream)

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const
     if (ring_seg_fail && tile_cnt[t] > cap) ring_seg_fail[ring_pages[t / ring_tpp].seg] = 1u;
     const uint32_t *sl = tile_slots + t * cap;
     const uint64_t base = tile_off[t];
-    // page ring: candidates are reported in LOGICAL stream coordinates ((slot << 40) | offset), pages ascending
+    // page ring: candidates are reported in LOGICAL stream coordinates ((slot << kRingOffBits) | offset), pages ascending
     const uint64_t tbase = ring_pages ? ring_pages[t / ring_tpp].logical + (t % ring_tpp) * (uint64_t)tile_bytes
                                       : t * (uint64_t)tile_bytes;
     if (c <= 48) {  // the normal case (a handful of candidates per tile): rank by comparison
@@ -861,7 +861,7 @@ hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, co
 // The walk of ONE segment by ONE wave (all 64 lanes call it with the same arguments). Returns the number of records;
 // WRITE: record k goes to recs[rbase + k] (lane 0), `seg` is stored in its segment field.
 // Page-ring rounds (rr.segs_in != null; ring_kernels.inc): the segment is a stream's open chunk + its new pages in logical
-// coordinates ((slot << 40) | offset); suggested offsets are relative to the STREAM's byte 0; the segment's end is the
+// coordinates ((slot << kRingOffBits) | offset); suggested offsets are relative to the STREAM's byte 0; the segment's end is the
 // stream's end only if RingSeg::final; and the walk reports what the round leaves behind: is the last record the still-open
 // chunk (it is unless the serial chunker cuts exactly at the current end: a max-size chunk, a candidate or a winning
 // suggested boundary there), where that chunk starts, and — reader-buffer rule only — the hash candidate inside it that a

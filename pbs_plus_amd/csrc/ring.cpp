@@ -69,7 +69,8 @@ void ring_service_ended(pbsgpu_ring *r) {
         (void)pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs);
         (void)hipEventRecord(r->ev_reset, r->cs);
     }
-    if (g_services.fetch_sub(1, std::memory_order_acq_rel) == 1) graveyard_flush();
+    r->parked_for_flush = false;
+    service_ended(r->eng->device);  // (the device's last service: memory parked by dev_free / host_free is freed now)
 }
 
 // Did the service stop on its own (idle timeout, kernels.hip)? Then wait the few microseconds until the kernel is gone.
@@ -143,7 +144,7 @@ void ring_reap_rounds(pbsgpu_ring *r) {
                 const uint32_t *cw = reinterpret_cast<const uint32_t *>(cells + (size_t)c * 64);
                 if (cw[11] == 0) continue;  // the round's open chunk: no record
                 const uint32_t slot = cw[10];
-                if (slot >= r->slots.size()) continue;
+                if (slot >= r->slots.size() || r->slots[slot].zombie) continue;  // (a closed failed stream: nobody polls it)
                 r->slots[slot].cells.push_back(CellRef{c, ri.seq});
                 ri.live_cells++;
                 r->st.chunks++;
@@ -159,6 +160,14 @@ void ring_reap_rounds(pbsgpu_ring *r) {
             r->tail_seen = hs->tail;
         }
         for (uint32_t s : ri.finals) r->slots[s].final_done = true;
+        // the round no longer refers to its streams' slots: a slot whose failed stream was closed in the meantime (zombie)
+        // becomes reusable with the LAST such round — never earlier, or this loop would have applied the dead stream's
+        // failure / final / cells to the slot's next occupant
+        for (uint32_t s : ri.seg_slots) {
+            StreamSlot &sl = r->slots[s];
+            if (sl.rounds_ref) sl.rounds_ref--;
+            if (sl.zombie && sl.rounds_ref == 0) sl = StreamSlot{};
+        }
         r->inflight_bytes -= ri.new_bytes;
         ri.reaped = true;
         r->input_busy[ri.input] = false;
@@ -184,6 +193,13 @@ int ring_launch_services(pbsgpu_ring *r) {
 
 int ring_start_service(pbsgpu_ring *r) {
     if (r->svc == SvcState::Running) return PBSGPU_OK;
+    if (r->svc == SvcState::Stopping && r->parked_for_flush) {
+        // parked because memory waits in the device's graveyard for the services to END: a new launch queued right behind
+        // the old one would keep the device's service count above zero for ever — wait for the old one (at most the chain
+        // of the chunks its lanes hold, ~0.5 s; a rare memory-pressure event), let the frees happen, then start afresh
+        HIPCHK(hipStreamSynchronize(r->ss));
+        ring_service_ended(r);
+    }
     if (r->svc == SvcState::Stopping) {
         // parked, its end not yet observed: the new service goes behind the old one's END and a reset (its lanes may hold
         // claims beyond the tail that the reset hands out again) — all on the device, nobody waits here
@@ -191,7 +207,7 @@ int ring_start_service(pbsgpu_ring *r) {
         HIPCHK(pbsk::launch_ring_reset(r->ctl.as<pbsk::RingCtl>(), r->cs));
         HIPCHK(hipEventRecord(r->ev_reset, r->cs));
     } else {
-        g_services.fetch_add(1, std::memory_order_acq_rel);  // (Stopped: the queue was reset when the last service ended)
+        service_started(r->eng->device);  // (Stopped: the queue was reset when the last service ended)
     }
     r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
     r->defer_t0 = 0;
@@ -267,7 +283,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
             pbsk::RingPage p{};
             p.phys = q.phys;
             p.phys_off = (uint64_t)q.phys * r->stride + 128u;
-            p.logical = ((uint64_t)si << 40) | (q.k * r->page_bytes);
+            p.logical = ((uint64_t)si << pbsk::kRingOffBits) | (q.k * r->page_bytes);
             p.valid = q.valid;
             p.slot = si;
             p.seg = ns;
@@ -313,6 +329,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
         recbase[ns] = (uint32_t)cells_needed;
         cells_needed += ((uint64_t)take * r->page_bytes + e->cfg.max) / minsz + 2;
         ri.seg_slots.push_back(si);
+        s.rounds_ref++;
         sg[ns++] = g;
     }
     if (ns == 0) return PBSGPU_OK;
@@ -571,12 +588,12 @@ int ring_park(pbsgpu_ring *r) {
 }
 
 int ring_commit_dep(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final, hipEvent_t dep) {
-    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    if (!r || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed) return PBSGPU_E_STATE;
     if (nbytes > r->page_bytes || (nbytes != r->page_bytes && !final)) return PBSGPU_E_INVALID;  // only a stream's last page is short
-    if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;  // 1 TiB per stream (40-bit logical offsets)
+    if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;  // 4 PiB per stream (52-bit logical offsets)
     if (nbytes == 0) {
         if (s.reserved >= 0) {  // nothing written: the page goes back
             r->free_pages.push_back((uint32_t)s.reserved);
@@ -838,7 +855,7 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
         HIPCHK(pbsk::launch_ring_stop(r->ctl.as<pbsk::RingCtl>(), r->cs));
         HIPCHK(hipEventRecord(r->ev_reset, r->cs));
         CHK(ring_launch_services(r));
-        g_services.fetch_add(1, std::memory_order_acq_rel);
+        service_started(r->eng->device);
         r->svc = SvcState::Running;
         r->st.service_launches++;
         HIPCHK(hipStreamSynchronize(r->ss));
@@ -848,6 +865,12 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
         ring_reap_free(r);
         ring_reap_rounds(r);
         return r->error;
+    }
+    if (r->svc == SvcState::Stopped && r->deferred_bytes > 0) {
+        // rounds were cut AHEAD of the service (a lone bulk stream on an idle ring: ring_enqueue_round): their chunks sit in
+        // the queue with no service to hash them. "Everything enqueued is hashed" needs one: start it, then stop it behind
+        // what is published, like a running one (round 5; before that fill -> pump -> quiesce -> poll saw no records)
+        CHK(ring_start_service(r));
     }
     if (r->svc == SvcState::Running) {
         CHK(ring_service_check(r, false));  // (it may have stopped on its own in the meantime)
@@ -880,7 +903,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         if (r->cs && r->ss) (void)pbsgpu_ring_quiesce(r);
         if (r->svc != SvcState::Stopped) {  // quiesce failed half-way (HIP error): the count must not leak
             r->svc = SvcState::Stopped;
-            g_services.fetch_sub(1, std::memory_order_acq_rel);
+            service_ended(r->eng->device);
         }
         if (r->ss) (void)hipStreamDestroy(r->ss);
         if (r->xs) (void)hipStreamDestroy(r->xs);
@@ -918,6 +941,11 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
 
 int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
     if (!r || !stream) return PBSGPU_E_INVALID;
+    for (auto &s : r->slots)
+        if (s.zombie) {  // a closed failed stream still holds its slot: have its last rounds finished?
+            ring_reap_rounds(r);
+            break;
+        }
     for (uint32_t i = 0; i < r->slots.size(); ++i)
         if (!r->slots[i].open) {
             r->slots[i] = StreamSlot{};
@@ -931,7 +959,7 @@ int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
 }
 
 int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
-    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    if (!r || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     if (s.failed) {  // a failed stream may be closed at any time: what it still holds goes back, its record list is incomplete
         for (const CellRef &cr : s.cells)
@@ -942,7 +970,19 @@ int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
                 }
         s.cells.clear();
         if (s.reserved >= 0) r->free_pages.push_back((uint32_t)s.reserved);
+        // Rounds enqueued before the failure was seen may still carry segments of this stream (the device answers them
+        // with seg_status = 1, and the host applies that — and `final`, and any stray cell — BY SLOT INDEX when it reaps
+        // them): the slot stays taken until the last of them has been reaped (ring_reap_rounds), so that a stream opened
+        // next can never inherit any of it
+        const uint32_t refs = s.rounds_ref;
         s = StreamSlot{};
+        if (refs) {
+            s.open = true;
+            s.failed = true;
+            s.zombie = true;
+            s.reported = true;
+            s.rounds_ref = refs;
+        }
         return PBSGPU_E_DENSITY;
     }
     if (!s.final_done || !s.cells.empty()) return PBSGPU_E_STATE;  // finish it and poll its records first
@@ -951,7 +991,7 @@ int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
 }
 
 int pbsgpu_ring_reserve(pbsgpu_ring *r, uint32_t stream, void **dptr, uint64_t *cap) {
-    if (!r || !dptr || !cap || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    if (!r || !dptr || !cap || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
@@ -969,7 +1009,7 @@ int pbsgpu_ring_commit(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int fin
 }
 
 int pbsgpu_ring_suggest(pbsgpu_ring *r, uint32_t stream, uint64_t offset) {
-    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    if (!r || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed) return PBSGPU_E_STATE;
@@ -982,7 +1022,7 @@ int pbsgpu_ring_suggest(pbsgpu_ring *r, uint32_t stream, uint64_t offset) {
 
 int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, int final,
                      uint64_t *taken) {
-    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open || kind > 4) return PBSGPU_E_INVALID;
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].live() || kind > 4) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     *taken = 0;
     if (s.failed) return PBSGPU_E_DENSITY;
@@ -1026,7 +1066,7 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
 // calls pass NULL / 0 and continue. Otherwise like pbsgpu_ring_fill.
 int pbsgpu_ring_fill_pieces(pbsgpu_ring *r, uint32_t stream, const pbsgpu_fill_piece *pieces, uint32_t npieces, uint64_t nbytes,
                             int final, uint64_t *taken) {
-    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
     static_assert(sizeof(pbsgpu_fill_piece) == sizeof(pbsk::FillPiece), "piece layout");
     StreamSlot &s = r->slots[stream];
     *taken = 0;
@@ -1094,6 +1134,16 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
     }
     ring_reap_free(r);
     ring_reap_rounds(r);
+    if (r->svc == SvcState::Running) {
+        // parked frees on this device have passed their cap (dev_free): every ring lets go of its service once per request;
+        // the last one to end frees the memory, the next round starts the service again
+        const uint32_t gen = service_park_generation(r->eng->device);
+        if (gen && gen != r->park_gen_seen) {
+            r->park_gen_seen = gen;
+            CHK(ring_park(r));
+            if (r->svc == SvcState::Stopping) r->parked_for_flush = true;
+        }
+    }
     bool any_round = false;
     for (int i = 0; i < 4; ++i) {
         bool did = false;
@@ -1123,7 +1173,7 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
 }
 
 int pbsgpu_ring_poll(pbsgpu_ring *r, uint32_t stream, pbsgpu_record *out, uint64_t cap, uint64_t *n, int *finished) {
-    if (!r || !n || stream >= r->slots.size() || !r->slots[stream].open || (!out && cap)) return PBSGPU_E_INVALID;
+    if (!r || !n || stream >= r->slots.size() || !r->slots[stream].live() || (!out && cap)) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     ring_heartbeat(r);
     ring_reap_rounds(r);
@@ -1148,7 +1198,7 @@ int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint6
     *nfinished = 0;
     for (uint32_t si = 0; si < r->slots.size(); ++si) {
         StreamSlot &s = r->slots[si];
-        if (!s.open || s.reported) continue;
+        if (!s.live() || s.reported) continue;
         ring_pop_records(r, si, out, cap, n);
         if ((s.final_done || s.failed) && s.cells.empty() && *nfinished < fcap) {
             finished[(*nfinished)++] = si;

@@ -53,6 +53,12 @@ struct StreamSlot {
     uint64_t origin = 0;                  // payload position of the stream's byte 0 (absolute reader grid of suggested boundaries)
     std::deque<uint64_t> sugg;            // suggested boundaries still of interest (stream offsets, ascending)
     void *owner = nullptr;                // the stream writer's section that feeds this slot (stream.cpp)
+    uint32_t rounds_ref = 0;              // enqueued rounds not yet reaped that carry a segment of this stream
+    bool zombie = false;                  // a FAILED stream that was closed while rounds still referred to its slot: the slot
+                                          // answers PBSGPU_E_INVALID to every call and is not handed out again until the last of
+                                          // those rounds has been reaped (round 5; before that the next stream opened into the
+                                          // slot inherited the dead stream's failure, its `final` and its stray record cells)
+    bool live() const { return open && !zombie; }
 };
 
 struct RoundInfo {
@@ -119,6 +125,8 @@ struct pbsgpu_ring {
     uint32_t rounds_enq = 0;              // mirrored into the heartbeat block for the service's self-stop handshake
     double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
     double idle_since_ms = 0;
+    uint32_t park_gen_seen = 0;           // last graveyard park request this ring honoured (engine_internal.h: dev_free)
+    bool parked_for_flush = false;        // ... and its service was parked for it: the next start waits for that service's END
     bool defer_service = false;           // PBSGPU_RING_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
     double lone_defer_ms = 25.0;          // a lone bulk stream's rounds are cut ahead of the service start for at most this long (0 = off)
     double defer_t0 = 0;                  // when the current deferral began (0 = none)

@@ -268,7 +268,7 @@ int ring_drain(pbsgpu_ring *r) {
     thread_local std::vector<pbsgpu_record> buf(4096);
     for (uint32_t si = 0; si < r->slots.size(); ++si) {
         StreamSlot &sl = r->slots[si];
-        if (!sl.open) continue;
+        if (!sl.live()) continue;  // (free, or a closed failed stream whose last rounds are still in flight)
         Section *sec = static_cast<Section *>(sl.owner);  // null: its stream was destroyed in an error state — discard
         for (;;) {
             uint64_t n = 0;
