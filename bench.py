@@ -682,6 +682,7 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
             o = ring_files_run(b, rank, local_rank, world, ctx, name[5:])
             res[name] = {"value": o["value"], "unit": o["unit"], "steps": o["steps"], "ms_per_step": o["ms_per_step"],
                          "workload": o["config"]["workload"], "feed_phase": o["roofline"]["feed_phase"],
+                         "service_cus": {"pair": o["config"].get("sha_service_cus"), "express": o["config"].get("express_cus")},
                          "records_match_gpu": o.get("cpu_baseline", {}).get("records_match_gpu"),
                          "records_checked": o.get("cpu_baseline", {}).get("records_checked"),
                          "results": o.get("results"), "leg_seconds": round(time.perf_counter() - t0, 1)}
@@ -1126,7 +1127,10 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
                                    "(40 % of the segments exact copies of an earlier one, device dedup over the pass; "
                                    "BASELINE.json configs[3])")),
                    "files_per_step": per_step, "file_bytes": fbytes, "streams_feeding": feeding,
-                   "resident_bytes_per_gpu": int(st1["pages_total"]) * int(st1["page_bytes"])},
+                   "resident_bytes_per_gpu": int(st1["pages_total"]) * int(st1["page_bytes"]),
+                   # the split between the pair and the express service follows the share of bytes in long chunks the ring
+                   # has seen (decided when a service starts: here after the warm-up step)
+                   "sha_service_cus": int(st1["sha_cus"]), "express_cus": ring.express()[0]},
         "roofline": {"kernel": "k_sha256_pair<RingSource,false>", "bound": "valu",
                      "achieved": round(float(st1["service_bytes_last"]) / max(float(st1["service_ms_last"]), 1e-9) / 1e6, 1),
                      "peak": round(SHA_VALU_GBS, 1), "unit": "GB/s",

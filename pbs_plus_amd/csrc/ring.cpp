@@ -148,6 +148,8 @@ void ring_reap_rounds(pbsgpu_ring *r) {
                 r->slots[slot].cells.push_back(CellRef{c, ri.seq});
                 ri.live_cells++;
                 r->st.chunks++;
+                r->obs_bytes += (double)cw[11];
+                if (r->long_bytes && cw[11] >= r->long_bytes) r->obs_long_bytes += (double)cw[11];
             }
             if (hs->nfailed) {
                 const volatile uint32_t *ss = r->in_segstat(ri.input);
@@ -191,6 +193,31 @@ int ring_launch_services(pbsgpu_ring *r) {
     return PBSGPU_OK;
 }
 
+// The express form hashes a chunk 1.37x sooner at 0.70 of the pair form's throughput per CU (2.99 vs 4.28 GiB/s per CU,
+// DESIGN.md 5.6). For a share s of the bytes in long chunks both services are equally busy when the express service holds
+//   (s / 2.99) / (s / 2.99 + (1 - s) / 4.28)   of the services' CUs:
+// 7 % = 16 CUs for random data (s = 0.05: the default), 59 % = 112 CUs for a corpus with half its bytes in zero runs or
+// periodic files (BASELINE configs[2]: measured 429 GiB/s with 16 express CUs, 441 / 475 / 490 with 48 / 80 / 112 — every
+// page of such a file is held for the chain of a 16 MiB chunk, 0.49 s on a pair lane, 0.34 s on an express pair, and the
+// arena binds). Called when a service starts: the observation window is what was published since the last decision
+// (at least 8 GiB), halved afterwards so that the split follows the data with some memory.
+void ring_adapt_split(pbsgpu_ring *r) {
+    if (!r->split_auto || r->xs == nullptr || r->long_bytes == 0 || r->obs_bytes < 8.0 * 1073741824.0) return;
+    const double s = std::min(1.0, r->obs_long_bytes / r->obs_bytes);
+    const double fx = (s / 2.99) / (s / 2.99 + (1.0 - s) / 4.28);
+    // (x 0.9: the pair lanes help out with long chunks whenever every express pair is busy, the express pairs never take a
+    // short chunk — too few express CUs cost little, too many leave the pair service short: configs[2] measured 490 GiB/s at
+    // 112 express CUs, 469 at 120, 445 at 128)
+    int xp = (int)(0.9 * fx * (double)r->svc_cus / 8.0 + 0.5) * 8;  // whole XCD rows: other counts leave the XCDs unevenly loaded
+    xp = std::max(16, std::min(xp, (int)r->svc_cus - 32));
+    r->obs_bytes *= 0.5;
+    r->obs_long_bytes *= 0.5;
+    if (std::abs(xp - (int)r->xp_cus) < 16) return;  // hysteresis
+    r->xp_cus = (uint32_t)xp;
+    r->sha_cus = r->svc_cus - r->xp_cus;
+    r->st.sha_cus = r->sha_cus;
+}
+
 int ring_start_service(pbsgpu_ring *r) {
     if (r->svc == SvcState::Running) return PBSGPU_OK;
     if (r->svc == SvcState::Stopping && r->parked_for_flush) {
@@ -210,6 +237,7 @@ int ring_start_service(pbsgpu_ring *r) {
         service_started(r->eng->device);  // (Stopped: the queue was reset when the last service ended)
     }
     r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
+    ring_adapt_split(r);
     r->defer_t0 = 0;
     hb_words(r)[pbsk::kHbClaim] = r->tail_seen;
     CHK(ring_launch_services(r));
@@ -686,6 +714,10 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (sha + xp > svc_max) sha = std::max(1, svc_max - xp);
         r->xp_cus = (uint32_t)xp;
         r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1 - xp));
+        r->svc_cus = r->sha_cus + r->xp_cus;
+        r->split_auto = xp > 0 && !o.sha_cus && !o.express_cus && !getenv("PBSGPU_RING_SHA_CUS") && !getenv("PBSGPU_RING_XP_CUS") &&
+                        r->svc_cus >= 96;
+        if (const char *v = getenv("PBSGPU_RING_SPLIT_AUTO")) r->split_auto = r->split_auto && atoi(v) != 0;
         r->round_pages = o.round_pages ? o.round_pages : 256;
         if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
         r->round_pages = std::min(r->round_pages, r->npages);

@@ -118,6 +118,13 @@ struct pbsgpu_ring {
     uint32_t scan_set = 0;                // scan set of the next round
     int bulk_prio = 0;                    // HIP priority of the refill and scan streams (lowest: the control side goes first)
     uint32_t xp_cus = 0;
+    // The split between the two services follows the DATA (round 5): the share of the published bytes that sits in long
+    // chunks (>= long_bytes) is observed as rounds are reaped, and every service START — the ring was idle, nothing is in
+    // flight, the change is free — picks the express share that balances the two services' CU-time for that share
+    // (ring_adapt_split). Only when neither the options nor the environment fixed the counts.
+    bool split_auto = false;
+    uint32_t svc_cus = 0;                 // CUs of both services together (constant)
+    double obs_bytes = 0, obs_long_bytes = 0;
     hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr, ev_xsvc1 = nullptr;
     hipEvent_t ev_fill[pbse::kRingInputs] = {};
     std::vector<hipEvent_t> ev_pool;      // page dependency events (ring_event_get / ring_event_put)

@@ -329,3 +329,49 @@ def test_digest_set_reduce_reports_bad_arguments_collectively(gpu_lib, O):
     assert np.array_equal(dup, want_dup) and stats == want_stats
     comm.close()
     eng.close()
+
+
+def test_service_split_follows_the_share_of_bytes_in_long_chunks(gpu_lib, O):
+    """The ring starts with 16 express CUs (right for random data: 5 % of its bytes sit in chunks >= 13/16 of the maximum).
+    A corpus of zero runs is ALL max-size chunks: every page is then held for a full chain, and the express form's chain is
+    1.37x shorter. Every service start re-balances the two services from what the ring has published since the last
+    decision; the records stay bit-exact whatever the split (zero runs through express pairs, random files through both)."""
+    from pbs_plus_amd import PageRing
+
+    avg = 4 << 20
+    eng = _engine(avg)
+    ring = PageRing(eng)
+    cfg = O.new_config(avg)
+    xp0, long_from = ring.express()
+    pair0 = ring.stats()["sha_cus"]
+    assert xp0 == 16 and long_from == (16 << 20) * 13 // 16, (xp0, long_from)
+    fsz = 256 << 20
+    zero_jobs = [(1000 + i, 1, fsz + 4096 * i) for i in range(64)]          # 16 GiB of zero runs: nothing but 16 MiB chunks
+    got = ring.ingest_synthetic(zero_jobs, timeout_s=120.0, concurrent=32)
+    ring.quiesce()
+    assert ring.express()[0] == xp0                                        # (a running service is never re-balanced)
+    want0 = O.chunk_and_digest(cfg, O.fill(zero_jobs[5][2], zero_jobs[5][0], 1), [(0, zero_jobs[5][2])])
+    _assert_same(got[5], want0, "zero file, default split")
+    # the next service start sees 100 % of the bytes in long chunks
+    mixed = [(2000, 4, fsz + 77), (2001, 1, fsz), (2002, 3, fsz + 12345), (2003, 1, 3 * fsz)]
+    got = ring.ingest_synthetic(mixed, timeout_s=120.0)
+    xp1 = ring.express()[0]
+    st = ring.stats()
+    assert xp1 >= 96 and xp1 % 8 == 0 and st["sha_cus"] + xp1 == pair0 + xp0, (xp1, st)
+    for j, g in zip(mixed, got):
+        _assert_same(g, O.chunk_and_digest(cfg, O.fill(j[2], j[0], j[1]), [(0, j[2])]), ("after re-balancing", j))
+    ring.quiesce()
+    # ... and back: 48 GiB of random-like files dominate the (halved) memory of the zero runs
+    rnd = [(3000 + i, 4, 2 * fsz) for i in range(96)]
+    got = ring.ingest_synthetic(rnd, timeout_s=120.0, concurrent=32)
+    ring.quiesce()
+    _assert_same(got[7], O.chunk_and_digest(cfg, O.fill(rnd[7][2], rnd[7][0], 4), [(0, rnd[7][2])]), "random file")
+    got = ring.ingest_synthetic([(4000, 4, fsz)], timeout_s=60.0)
+    xp2 = ring.express()[0]
+    assert 16 <= xp2 < xp1 and ring.stats()["sha_cus"] + xp2 == pair0 + xp0, (xp1, xp2)
+    _assert_same(got[0], O.chunk_and_digest(cfg, O.fill(fsz, 4000, 4), [(0, fsz)]), "after re-balancing back")
+    ring.quiesce()
+    st = ring.stats()
+    assert st["pages_free"] == st["pages_total"], st
+    ring.close()
+    eng.close()
