@@ -701,7 +701,14 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
         b.archives = archives
         t0 = time.perf_counter()
         try:
-            o = hostfeed_run(b, rank, local_rank, world, ctx)
+            # Each host-fed leg in a process of its own: ONE engine per process is what a host looks like (the Go agent keeps
+            # one for its lifetime), and a process that has created and destroyed several engines before — as this line's
+            # earlier legs do — feeds up to 15 % slower (the same leg: 42.2 GiB/s alone, 36.8 as the third engine of its
+            # process, 34.6 as the eighth; profiles/r05_hostfeed_leg_isolation.log). PBS_BENCH_HF_INPROC=1: in this process.
+            if os.environ.get("PBS_BENCH_HF_INPROC"):
+                o = hostfeed_run(b, rank, local_rank, world, ctx)
+            else:
+                o = _hostfeed_subprocess(b, local_rank)
             res[label] = {"value": o["value"], "unit": o["unit"], "producers": producers, "archives_per_producer": archives,
                           "bytes": int(o["config"]["bytes"]),
                           "frac_of_measured_h2d": o["roofline"]["frac_of_measured_h2d"],
@@ -715,6 +722,26 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
             res[label] = {"error": repr(exc)}
     res["total_seconds"] = round(time.perf_counter() - t_all, 1)
     return res
+
+
+def _hostfeed_subprocess(b, local_rank):
+    """One host-fed leg as `bench.py --workload hostfeed ...` in a fresh process on the same GPU; returns its JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "hostfeed", "--gpus", "1", "--producers", str(b.producers),
+           "--steps", str(b.steps), "--warmup", str(b.warmup), "--archives", str(b.archives), "--avg", str(b.avg),
+           "--seed", str(b.seed), "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PBS_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    if "HIP_VISIBLE_DEVICES" not in env and local_rank:
+        env["HIP_VISIBLE_DEVICES"] = str(local_rank)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    if os.environ.get("PBS_BENCH_HF_TRACE"):
+        sys.stderr.write(r.stderr)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    raise RuntimeError(f"host-fed leg failed (rc {r.returncode}): {r.stderr[-400:]}")
 
 
 def cabi_reduce_check(eng, recs, ctx):
