@@ -540,6 +540,12 @@ pbsk::RingSource pbsgpu_ring::source() const {
     // (measured with a queue-length rule instead: ring_manyfiles 441 -> 418 GiB/s, drain 0.50 -> 0.58 s)
     q.long_spill = 0u;
     q.xp_pairs = xp_cus * 64u;
+    // ... unless the express service is LARGE (the split has followed a corpus of long chunks, ring_adapt_split): with
+    // thousands of express pairs one comes free every few dozen microseconds (6 656 pairs x 0.34 s per 16 MiB chunk: one per
+    // 50 us), so a long chunk near the head of the queue is on an express pair — and done 0.15 s sooner than on a pair lane —
+    // almost at once. The pair lanes then only see what is queued beyond xp_pairs / 16 (<= 21 ms of waiting).
+    if (xp_cus >= 32) q.long_spill = q.xp_pairs / 16u;
+    if (const char *v = getenv("PBSGPU_RING_LONG_SPILL")) q.long_spill = (uint32_t)std::max(0, atoi(v));
     q.ctl = ctl.as<pbsk::RingCtl>();
     q.cells = cells.as<uint8_t>();
     q.pending = pending.as<uint32_t>();
