@@ -556,7 +556,12 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
     q.heartbeat = heartbeat.as<uint32_t>();
     {   // poll period of waves that carry work (power of two; 1 = every step, the behaviour before round 4)
-        int every = 8;
+        // A free lane waits up to `every` block steps (1.75 us each) for its next look at the queue: kept below 0.4 % of the
+        // chain of a MINIMUM-size chunk — 8 for small chunkers (tests), 64 at the production average of 4 MiB (min 1 MiB =
+        // 16 384 steps). Measured on the driver's command: every 8th step 610.5 / 609.7, every 32nd 617.0 GiB/s, drain
+        // 0.430 -> 0.409 s (profiles/r05_ab_long_spill_and_poll.log; round 4: 1 -> 8: 606 -> 615).
+        const uint64_t min_steps = std::min<uint64_t>(eng->effmin, eng->cfg.min) / 64u;
+        int every = (int)std::min<uint64_t>(64, std::max<uint64_t>(8, pow2_at_least(min_steps / 256u + 1u) / 2u));
         if (const char *v = getenv("PBSGPU_RING_POLL_EVERY")) every = std::max(1, atoi(v));
         q.poll_mask = pow2_at_least((uint64_t)every) - 1u;
     }
