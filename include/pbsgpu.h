@@ -300,8 +300,9 @@ int pbsgpu_stream_write_marker(pbsgpu_stream *s, const struct pbsgpu_payload_for
  * guarantees that no chunk is left behind) and the next pump starts it again.
  * Failure containment: a stream whose data overflows a scan tile's candidate slots (more than one candidate per 128 bytes
  * over a whole tile: a crafted short period) fails ALONE — its calls answer PBSGPU_E_DENSITY after the records cut before
- * the failure, its pages are released — every other stream of the ring goes on. A stream is limited to 1 TiB
- * (40-bit offsets inside a round); PBSGPU_E_INVALID beyond. */
+ * the failure, its pages are released — every other stream of the ring goes on; the failed stream's slot is handed to a
+ * new stream only after every round that still refers to it has been reaped. A stream is limited to 4 PiB (52-bit offsets
+ * inside a round, 12 bits for the slot); PBSGPU_E_INVALID beyond. */
 typedef struct pbsgpu_ring pbsgpu_ring;
 typedef struct pbsgpu_ring_options {
     uint64_t arena_bytes;  /* device memory for pages; 0 = what is free minus 8 GiB */

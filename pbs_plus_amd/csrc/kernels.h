@@ -344,8 +344,18 @@ struct RingRound {
 // (`fill_st` / `fill_ev`: the synthetic producer's own stream and the event the cut waits for; null = same stream)
 // (`scan_st` / `scan_ev`: the scan's own stream — head pads + scan of this round may overlap the control kernel of the
 // previous one — and the event the control stream waits for; null = everything in order on `st`)
+// (`stage`: the round's host-written tables — pages, segments, record bases, suggested-offset index — are copied from mapped
+// pinned memory into device memory by the round's FIRST kernel, and r.pages / r.segs_in / r.seg_rec_base / r.sugg_idx point
+// at the copies; null = the kernels read the mapped host memory itself, as in rounds 3-4)
+struct RingStage {
+    const uint8_t *src;          // the input block in mapped pinned memory
+    uint8_t *dst;                // its device mirror (same layout)
+    uint32_t off[4], len[4];     // spans to copy (64-byte aligned offsets, lengths rounded up to 16 inside the block's padding)
+    const RingPage *pages_host;  // host view of the page table (launch_ring_round looks at do_fill)
+};
 hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st, hipStream_t fill_st = nullptr,
-                             hipEvent_t fill_ev = nullptr, hipStream_t scan_st = nullptr, hipEvent_t scan_ev = nullptr);
+                             hipEvent_t fill_ev = nullptr, hipStream_t scan_st = nullptr, hipEvent_t scan_ev = nullptr,
+                             const RingStage *stage = nullptr);
 // the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
 hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st);
 hipError_t launch_ring_service_xp(const RingSource &q, unsigned workgroups, hipStream_t st);

@@ -483,7 +483,28 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     if (r->ps && r->ctl_used[set])  // this scan set's previous user must have been resolved before the scan overwrites it
         if (hipStreamWaitEvent(r->ps, r->ev_ctl[set], 0) != hipSuccess) return fail(PBSGPU_E_HIP);
     {
-        const hipError_t he = pbsk::launch_ring_round(rr, e->num_cus, r->cs, r->fs, r->ev_fill[in], r->ps, r->ps ? r->ev_scan[in] : nullptr);
+        // (PBSGPU_RING_FILL_SERIAL=1, experiments: the synthetic refill in stream order behind the previous round's scan instead
+        // of beside it on its own stream)
+        static const bool fill_serial = []() { const char *v = getenv("PBSGPU_RING_FILL_SERIAL"); return v && atoi(v) != 0; }();
+        pbsk::RingStage stg{};
+        if (r->stage_inputs) {
+            const uint8_t *hb = r->in((uint32_t)in);
+            uint8_t *db = r->in_dev((uint32_t)in);
+            stg.src = hb;
+            stg.dst = db;
+            stg.off[0] = (uint32_t)r->in_pages_off;   stg.len[0] = np * (uint32_t)sizeof(pbsk::RingPage);
+            stg.off[1] = (uint32_t)r->in_segs_off;    stg.len[1] = ns * (uint32_t)sizeof(pbsk::RingSeg);
+            stg.off[2] = (uint32_t)r->in_recbase_off; stg.len[2] = (ns + 1u) * 4u;
+            stg.off[3] = (uint32_t)r->in_suggidx_off; stg.len[3] = rr.sugg_idx ? (ns + 1u) * 4u : 0u;
+            stg.pages_host = pg;
+            auto mirror = [&](const void *hp) { return db + (reinterpret_cast<const uint8_t *>(hp) - hb); };
+            rr.pages = reinterpret_cast<const pbsk::RingPage *>(mirror(pg));
+            rr.segs_in = reinterpret_cast<const pbsk::RingSeg *>(mirror(sg));
+            rr.seg_rec_base = reinterpret_cast<const uint32_t *>(mirror(recbase));
+            if (rr.sugg_idx) rr.sugg_idx = reinterpret_cast<const uint32_t *>(mirror(suggidx));
+        }
+        const hipError_t he = pbsk::launch_ring_round(rr, e->num_cus, r->cs, fill_serial ? nullptr : r->fs, r->ev_fill[in], r->ps,
+                                                      r->ps ? r->ev_scan[in] : nullptr, r->stage_inputs ? &stg : nullptr);
         if (he != hipSuccess) {
             g_last_hip_error.store((int)he);
             return fail(PBSGPU_E_HIP);
@@ -811,6 +832,9 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->in_status_off = al64(r->in_suggidx_off + ((size_t)r->max_streams + 1) * 4);
         r->input_stride = r->in_status_off + 64;
         CHK(r->inputs.ensure(r->input_stride * kRingInputs));
+        // PBSGPU_RING_STAGE_INPUTS=0: the round's kernels read their tables from mapped host memory (rounds 3-4), for A/B runs
+        if (const char *v = getenv("PBSGPU_RING_STAGE_INPUTS")) r->stage_inputs = atoi(v) != 0;
+        if (r->stage_inputs) CHK(r->inputs_dev.ensure(r->input_stride * kRingInputs));
         std::memset(r->inputs.p, 0, r->input_stride * kRingInputs);
         // Three priorities: the services highest (their own hardware-queue pool: nothing may queue behind a kernel that only
         // ends on request), the CONTROL side of the rounds normal, the producers of bulk work — synthetic refill, scan —
@@ -968,7 +992,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         for (auto ev : r->ev_pool) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
                           &r->tile_slots, &r->tile_cnt2, &r->tile_slots2, &r->tileq, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
-                          &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->seg_fail})
+                          &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->seg_fail, &r->inputs_dev})
             b->release();
         r->cells.release();
         r->heartbeat.release();

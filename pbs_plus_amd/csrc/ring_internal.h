@@ -101,6 +101,8 @@ struct pbsgpu_ring {
     pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
     pbse::DevBuf tile_cnt2, tile_slots2, tileq;  // second set of the scan side (rounds alternate) + the two tile-queue counters
     pbse::DevBuf seg_ecand_in, seg_ecand, seg_fail;
+    pbse::DevBuf inputs_dev;  // device mirror of `inputs` (the round tables are staged once per round: k_ring_stage)
+    bool stage_inputs = true;
     // mapped pinned
     pbse::PinnedBuf cells, free_fifo, inputs, heartbeat;
     std::vector<pbse::PinnedBuf> piece_tab;      // per stream slot: the piece table of a synthetic edited stream (fill_pieces)
@@ -153,6 +155,7 @@ struct pbsgpu_ring {
     uint64_t svc_bytes0 = 0;
 
     uint8_t *in(uint32_t i) const { return inputs.as<uint8_t>() + (size_t)i * input_stride; }
+    uint8_t *in_dev(uint32_t i) const { return inputs_dev.as<uint8_t>() + (size_t)i * input_stride; }
     pbsk::RingPage *in_pages(uint32_t i) const { return reinterpret_cast<pbsk::RingPage *>(in(i) + in_pages_off); }
     pbsk::RingSeg *in_segs(uint32_t i) const { return reinterpret_cast<pbsk::RingSeg *>(in(i) + in_segs_off); }
     uint32_t *in_segstat(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_segstat_off); }
