@@ -1231,12 +1231,14 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
 
 
 def load_traffic_ring():
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as f:   # PMC passes on the ring's own kernels (round 4)
-            tj = json.load(f)
-        return {"ratio": float(tj["ring"]["hbm_bytes_per_algorithmic_byte"]), "note": tj["ring"]["note"]}
-    except Exception:
-        return None
+    for name in ("r05_traffic.json", "r04_traffic.json"):   # PMC passes on the ring's own kernels (newest round first)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tj = json.load(f)
+            return {"ratio": float(tj["ring"]["hbm_bytes_per_algorithmic_byte"]), "note": tj["ring"]["note"]}
+        except Exception:
+            continue
+    return None
 
 
 def ring_cpu_baseline(a, kept, single, file_bytes, kind, seed_of):

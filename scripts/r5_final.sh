@@ -28,6 +28,25 @@ timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ
 $EXP counters $(db $OUT/pmc_sq) $OUT/pmc_sq_ring.csv
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python3 $ROOT/scripts/r4_ring_pmc.py 48 4 > $OUT/ring_pmc_fetch.json 2> $OUT/ring_pmc_fetch.err
 $EXP counters $(db $OUT/pmc_fetch) $OUT/pmc_fetch_size_ring.csv
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python3 $ROOT/scripts/r4_ring_pmc.py 48 4 > $OUT/ring_pmc_write.json 2> $OUT/ring_pmc_write.err
+$EXP counters $(db $OUT/pmc_write) $OUT/pmc_write_size_ring.csv
+python3 $ROOT/scripts/r5_traffic.py $OUT/pmc_fetch_size_ring.csv $OUT/pmc_write_size_ring.csv $OUT/ring_pmc_fetch.json $OUT/traffic.json
 find $OUT -name "*.db" -delete; find $OUT -type d -empty -delete
 grep -i "sha256" $OUT/pmc_sq_ring.csv $OUT/pmc_fetch_size_ring.csv | sed 's/void pbsk:://' | cut -c1-230
 cat $OUT/ring_pmc_sq.json | cut -c1-400
+# the N-rank code path of bench.py on the one GPU there is: (1) RCCL with ONE rank (process group, barriers, collectives, C-ABI reduce),
+# (2) two ranks sharing the GPU over gloo, spawned by bench.py itself (--gpus 2 without a launcher)
+cd $ROOT
+( PBS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --gpus 1 --steps 4 --warmup 1 --no-extras --no-cpu-baseline > $out/bench_force_dist_nccl_1rank.json 2> $out/bench_force_dist_nccl_1rank.err; echo "force_dist rc=$?" )
+( PBS_BENCH_BACKEND=gloo timeout 250 python bench.py --gpus 2 --steps 3 --warmup 1 --arena-gib 96 --ring-sha-cus 64 --no-extras > $out/bench_gloo_2ranks_one_gpu.json 2> $out/bench_gloo_2ranks_one_gpu.err; echo "gloo2 rc=$?" )
+python3 - <<PY
+import json
+for n in ('bench_force_dist_nccl_1rank', 'bench_gloo_2ranks_one_gpu'):
+    try:
+        for l in open('$out/%s.json' % n):
+            if l.startswith('{'):
+                d = json.loads(l); print(n, d['value'], 'n_gpus', d['n_gpus'], 'scaling', d.get('scaling'), (d.get('results') or {}).get('c_abi_digest_reduce'), (d.get('cpu_baseline') or {}).get('all_ranks'))
+    except Exception as e:
+        print(n, 'no line', e)
+PY
+tail -2 $out/bench_force_dist_nccl_1rank.err $out/bench_gloo_2ranks_one_gpu.err | cut -c1-300
