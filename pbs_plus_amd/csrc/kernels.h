@@ -228,6 +228,11 @@ struct RingSource {
     uint32_t xp;
     uint32_t long_spill;
     uint32_t xp_pairs;         // lane pairs of the express service (its CUs x 64)
+    // While fewer than 3/4 of the express pairs hold or await a chunk (one file alone, the first rounds of a burst) chunks from
+    // `long_lo` bytes on go express too: under load the threshold is what 16 CUs can take (13/16 of the maximum), but a lone
+    // 64 GiB file ends with the pair chain of its longest chunk BELOW that threshold (12.9 MiB: 0.37 s) although hundreds
+    // of express pairs sit idle (0 = off).
+    uint32_t long_lo;
 };
 constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHbRoundsEnq = 33;
 

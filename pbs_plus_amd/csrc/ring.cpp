@@ -239,6 +239,7 @@ int ring_start_service(pbsgpu_ring *r) {
     r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
     ring_adapt_split(r);
     r->defer_t0 = 0;
+    r->defer_idle_since = 0;
     hb_words(r)[pbsk::kHbClaim] = r->tail_seen;
     CHK(ring_launch_services(r));
     r->svc_t0 = now_ms();
@@ -566,6 +567,13 @@ pbsk::RingSource pbsgpu_ring::source() const {
     // 50 us), so a long chunk near the head of the queue is on an express pair — and done 0.15 s sooner than on a pair lane —
     // almost at once. The pair lanes then only see what is queued beyond xp_pairs / 16 (<= 21 ms of waiting).
     if (xp_cus >= 32) q.long_spill = q.xp_pairs / 16u;
+    // light load (fewer than 3/4 of the express pairs taken): chunks from 11/16 of the maximum on go express too — bulk rings
+    // only (the stream writer's ring already sends every chunk >= half the maximum express). One 64 GiB file alone: ~400 chunks
+    // >= 11 MiB for 1 024 pairs; its last record then waits for the express chain of a 16 MiB chunk (0.34 s), not for the pair
+    // chain of a 12.9 MiB one (0.37 s).
+    q.long_lo = (xp_cus && long_lo_auto) ? (uint32_t)((uint64_t)eng->cfg.max * 11 / 16) : 0u;
+    if (const char *v = getenv("PBSGPU_RING_LONG_LO_BYTES")) q.long_lo = xp_cus ? (uint32_t)std::max(0L, atol(v)) : 0u;
+    if (q.long_lo >= q.long_bytes) q.long_lo = 0u;
     if (const char *v = getenv("PBSGPU_RING_LONG_SPILL")) q.long_spill = (uint32_t)std::max(0, atoi(v));
     q.ctl = ctl.as<pbsk::RingCtl>();
     q.cells = cells.as<uint8_t>();
@@ -762,6 +770,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (const char *v = getenv("PBSGPU_RING_AUTOPARK_MS")) r->autopark_ms = std::max(0.0, atof(v));
         if (const char *v = getenv("PBSGPU_RING_DEFER_SERVICE")) r->defer_service = atoi(v) != 0;
         if (const char *v = getenv("PBSGPU_RING_LONE_DEFER_MS")) r->lone_defer_ms = std::max(0.0, atof(v));
+        if (const char *v = getenv("PBSGPU_RING_DEFER_GRACE_MS")) r->defer_grace_ms = std::max(0.0, atof(v));
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
@@ -792,6 +801,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // (OFF by default: measured +0.8 % on the bench line for +40 ms of single-file latency — the drain is not made of
         // late-starting long chunks; kept as a switch)
         r->long_bytes = r->xp_cus ? (long_bytes_hint ? long_bytes_hint : (uint32_t)((uint64_t)e->cfg.max * 13 / 16)) : 0;
+        r->long_lo_auto = long_bytes_hint == 0;  // (a ring with its own threshold — the stream writer's — keeps it)
         if (const char *v = getenv("PBSGPU_RING_LONG_BYTES")) r->long_bytes = (uint32_t)std::max(0L, atol(v));
         if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);
@@ -1224,7 +1234,15 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
         bool waiting = false;
         for (auto &s : r->slots) waiting |= s.open && !s.ready.empty();
         const uint64_t lanes_worth = (uint64_t)r->sha_cus * 128u * (uint64_t)r->eng->cfg.avg;
-        if ((!any_round && !waiting) || now_ms() - r->defer_t0 >= r->lone_defer_ms || r->deferred_bytes >= lanes_worth)
+        const double t = now_ms();
+        bool idle_long_enough = false;
+        if (!any_round && !waiting) {
+            if (r->defer_idle_since == 0) r->defer_idle_since = t;
+            idle_long_enough = t - r->defer_idle_since >= r->defer_grace_ms;
+        } else {
+            r->defer_idle_since = 0;
+        }
+        if (idle_long_enough || t - r->defer_t0 >= r->lone_defer_ms || r->deferred_bytes >= lanes_worth)
             CHK(ring_start_service(r));
     }
     if (r->autopark_ms > 0 && r->svc == SvcState::Running) {  // nothing anywhere in the ring: give the CUs (and hipFree) back
