@@ -239,7 +239,6 @@ int ring_start_service(pbsgpu_ring *r) {
     r->svc = SvcState::Running;  // (from here on an error leaves a service count behind that quiesce / destroy settle)
     ring_adapt_split(r);
     r->defer_t0 = 0;
-    r->defer_idle_since = 0;
     hb_words(r)[pbsk::kHbClaim] = r->tail_seen;
     CHK(ring_launch_services(r));
     r->svc_t0 = now_ms();
@@ -770,7 +769,6 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (const char *v = getenv("PBSGPU_RING_AUTOPARK_MS")) r->autopark_ms = std::max(0.0, atof(v));
         if (const char *v = getenv("PBSGPU_RING_DEFER_SERVICE")) r->defer_service = atoi(v) != 0;
         if (const char *v = getenv("PBSGPU_RING_LONE_DEFER_MS")) r->lone_defer_ms = std::max(0.0, atof(v));
-        if (const char *v = getenv("PBSGPU_RING_DEFER_GRACE_MS")) r->defer_grace_ms = std::max(0.0, atof(v));
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
@@ -1234,15 +1232,11 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
         bool waiting = false;
         for (auto &s : r->slots) waiting |= s.open && !s.ready.empty();
         const uint64_t lanes_worth = (uint64_t)r->sha_cus * 128u * (uint64_t)r->eng->cfg.avg;
-        const double t = now_ms();
-        bool idle_long_enough = false;
-        if (!any_round && !waiting) {
-            if (r->defer_idle_since == 0) r->defer_idle_since = t;
-            idle_long_enough = t - r->defer_idle_since >= r->defer_grace_ms;
-        } else {
-            r->defer_idle_since = 0;
-        }
-        if (idle_long_enough || t - r->defer_t0 >= r->lone_defer_ms || r->deferred_bytes >= lanes_worth)
+        // (Round 5 tried a 1 ms grace before "nothing waiting" ends the deferral — a feeder that commits a round's worth, pumps
+        // and polls in a loop has nothing waiting after every pump, so its cut-ahead ends with the first poll: the file's last
+        // bytes are cut ~7 ms sooner, its first chunks start ~25 ms later; one file alone 487-500 vs 496-502 ms on the same box,
+        // the driver's line 589-592 vs 593-595: no gain, not kept. profiles/r05_ab_defer_grace.log)
+        if ((!any_round && !waiting) || now_ms() - r->defer_t0 >= r->lone_defer_ms || r->deferred_bytes >= lanes_worth)
             CHK(ring_start_service(r));
     }
     if (r->autopark_ms > 0 && r->svc == SvcState::Running) {  // nothing anywhere in the ring: give the CUs (and hipFree) back

@@ -138,12 +138,8 @@ struct pbsgpu_ring {
     uint32_t park_gen_seen = 0;           // last graveyard park request this ring honoured (engine_internal.h: dev_free)
     bool parked_for_flush = false;        // ... and its service was parked for it: the next start waits for that service's END
     bool defer_service = false;           // PBSGPU_RING_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
-    double lone_defer_ms = 40.0;          // a lone bulk stream's rounds are cut ahead of the service start for at most this long (0 = off)
+    double lone_defer_ms = 25.0;          // a lone bulk stream's rounds are cut ahead of the service start for at most this long (0 = off)
     double defer_t0 = 0;                  // when the current deferral began (0 = none)
-    double defer_grace_ms = 1.0;          // ... and it ends once NOTHING has been waiting to be cut for this long (a feeder that
-                                          // commits a round's worth, pumps and polls in a loop has nothing waiting after every
-                                          // pump: without the grace its cut-ahead ended with the first poll)
-    double defer_idle_since = 0;          // when the ring first found nothing waiting during the current deferral (0 = not yet)
     uint64_t deferred_bytes = 0;          // bytes cut while no service was running (they are the next launch's work)
     double idle_timeout_s = 0;            // > 0: the service's own idle stop (default 20 s; PBSGPU_RING_IDLE_TIMEOUT_S overrides)
     // host bookkeeping
