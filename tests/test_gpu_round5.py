@@ -375,3 +375,59 @@ def test_service_split_follows_the_share_of_bytes_in_long_chunks(gpu_lib, O):
     assert st["pages_free"] == st["pages_total"], st
     ring.close()
     eng.close()
+
+
+@pytest.mark.parametrize("staged", [True, False])
+def test_round_tables_staged_or_read_from_host_memory(gpu_lib, O, monkeypatch, staged):
+    """The round's first kernel (k_ring_stage) copies the host-written page / segment / record-base tables into device memory and
+    every other kernel of the round reads the copy; PBSGPU_RING_STAGE_INPUTS=0 keeps rounds 3-4's reads of the mapped host memory.
+    Same streams, same records either way: nine streams of every generator kind (empty, 1-byte, 63-byte, page-exact ones among
+    them) through a 24-page ring, two at a time, so that pages, slots and input blocks are all re-used many times."""
+    from pbs_plus_amd import PageRing
+
+    if not staged:
+        monkeypatch.setenv("PBSGPU_RING_STAGE_INPUTS", "0")
+    avg = 4096
+    eng = _engine(avg)
+    ring = PageRing(eng, arena_bytes=24 * (65536 + 256), page_bytes=65536, max_streams=4, sha_cus=4, round_pages=6)
+    jobs = [(921, 0, (1 << 20) + 5), (922, 1, 300 * 1024), (923, 3, 700 * 1024 + 3), (924, 0, 0), (925, 0, 63), (926, 2, 65536),
+            (927, 0, 65536 * 3), (928, 4, 65536 * 2 + 1), (929, 0, 1)]
+    got = ring.ingest_synthetic(jobs, timeout_s=60.0, concurrent=2)
+    ring.quiesce()
+    cfg = O.new_config(avg)
+    for j, g in zip(jobs, got):
+        want = O.chunk_and_digest(cfg, O.fill(j[2], j[0], j[1]), [(0, j[2])]) if j[2] else np.zeros(0, dtype=O.RECORD_DTYPE)
+        _assert_same(g, want, ("staged" if staged else "host tables", j))
+    st = ring.stats()
+    assert st["pages_free"] == st["pages_total"] and st["pages_recycled"] == st["pages_enqueued"], st
+    ring.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("light_load_rule", [True, False])
+def test_one_file_alone_sends_its_longer_chunks_express(gpu_lib, O, monkeypatch, light_load_rule):
+    """Under load the express service takes chunks of at least 13/16 of the maximum (what its 16 CUs can keep up with); while
+    fewer than 3/4 of its lane pairs are taken — one file alone on an idle ring — chunks from 11/16 of the maximum go express
+    too, so that the file's last record waits for the express chain of its longest chunk and not for the pair chain of one
+    just below the threshold. Which queue a chunk took is visible in the long queue's tail (cumulative); the records are the
+    oracle's either way."""
+    import re
+    from pbs_plus_amd import PageRing
+
+    if not light_load_rule:
+        monkeypatch.setenv("PBSGPU_RING_LONG_LO_BYTES", "0")
+    avg = 4 << 20
+    eng = _engine(avg)
+    ring = PageRing(eng)
+    assert ring.express() == (16, (16 << 20) * 13 // 16)
+    n = 6 * GiB + 4096
+    got = ring.ingest_synthetic([(515, 4, n)], timeout_s=120.0)[0]
+    ring.quiesce()
+    ltail = int(re.search(r"ltail=(\d+)", ring.debug()).group(1))
+    n13 = int((got["size"] >= (16 << 20) * 13 // 16).sum())
+    n11 = int((got["size"] >= (16 << 20) * 11 // 16).sum())
+    assert n11 > n13 > 0, (n11, n13)                      # (the file has chunks between the two thresholds)
+    assert ltail == (n11 if light_load_rule else n13), (ltail, n11, n13)
+    _assert_same(got, O.chunk_and_digest(O.new_config(avg), O.fill(n, 515, 4), [(0, n)]), "one file alone")
+    ring.close()
+    eng.close()
