@@ -240,7 +240,7 @@ constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHb
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)
 enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsTileq = 6 /* u64 */, kRsCount = 10 };
 
-// One physical page of a round (host-written, mapped pinned memory; read by the round's kernels).
+// One physical page of a round (host-written into mapped pinned memory; the round's kernels read the device copy k_ring_stage makes).
 struct RingPage {
     uint64_t phys_off;     // byte offset of the page BODY from the arena base (a 128-byte pad precedes and follows it)
     uint64_t logical;      // (stream slot << kRingOffBits) | offset of the page's first byte within its stream
@@ -303,7 +303,7 @@ struct RingRound {
     uint32_t effmin, cmin, maxsz, cap;
     uint32_t thr;
     const uint32_t *table_rot;
-    // this round's inputs (mapped pinned)
+    // this round's inputs (device copies of the host-written tables; the mapped pinned originals with PBSGPU_RING_STAGE_INPUTS=0)
     const RingPage *pages;
     uint32_t npages;
     const RingSeg *segs_in;
