@@ -950,8 +950,9 @@ def ring_run(a, rank, local_rank, world, ctx):
                 "parallelism": (f"{world} rank(s), one per GPU, files independent, digest-set all-gather per file"
                                 if world > 1 else "1 GPU")},
             "roofline": {
-                "kernel": "k_sha256_pair<RingSource,false> (the persistent SHA-256 service: ONE launch spans the timed region; "
-                          "the cut rounds — k_ring_fill, k_scan3, resolve — run beside it on the other CUs)",
+                "kernel": "k_sha256_pair<RingSource,false> (the persistent SHA-256 service: ONE launch spans the timed region, the "
+                          "express service k_sha256_xpair<RingSource> beside it on its own CUs; the cut rounds — k_ring_stage, "
+                          "k_ring_fill, k_scan3, k_ring_control — run on the CUs the services leave free)",
                 # the contract's roofline: algorithmic bytes of the dominant kernel / its duration against the HBM peak
                 # (BASELINE.json quotes % of the HBM roofline). What actually bounds SHA-256 on this chip — integer issue
                 # slots, and the serial chain inside a chunk — is in `valu` beside it.
@@ -969,11 +970,17 @@ def ring_run(a, rank, local_rank, world, ctx):
                     "seconds": round(t_fed - t0, 4), "GiBps": round(a.steps * file_bytes / GiB / max(t_fed - t0, 1e-9), 1),
                     "drain_seconds": round(elapsed - (t_fed - t0), 4),
                     "note": "timed region = feed phase (idle ring -> last page of the last file in a cut round; pages are cut, "
-                            "hashed and recycled all the while) + drain (the last chunks' serial SHA-256 chains, up to one "
-                            "max-size chunk = ~0.45 s, with no new work: a fixed cost per timed region whatever its length)"},
+                            "hashed and recycled all the while) + drain (the last chunks' serial SHA-256 chains with no new work — "
+                            "a max-size chunk on an express pair ~0.34 s, a chunk just under the express threshold on a pair lane "
+                            "~0.37 s: a fixed cost per timed region whatever its length)"},
                 "path": {"achieved": round(gbs, 1), "frac_of_valu_peak": round(gbs / SHA_VALU_GBS, 4),
                          "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                          "note": "whole timed region incl. ramp-up from an idle ring and the drain of the last chunks"},
+                "cu_time_budget": {"service_cu_ms_per_GiB": 233, "scan_cu_ms_per_GiB": 50, "refill_cu_ms_per_GiB": 28,
+                                   "chip_ceiling_GiBps": 823,
+                                   "note": "kernel traces of this command (profiles/r05_kernel_trace_bench_default*.csv.gz, "
+                                           "scripts/r5_trace_regimes.py): 311 CU-ms per GiB over the three kernels -> 256 CUs / 311 = "
+                                           "823 GiB/s however the CUs are split; the feed phase runs at ~0.93 of it (refill: bench only)"},
                 "traffic": None if tr is None else int(tr["ratio"] * svc_bytes),
                 "traffic_note": None if tr is None else tr["note"],
                 "algorithmic_bytes_per_launch": int(svc_bytes),
