@@ -420,7 +420,7 @@ def test_one_file_alone_sends_its_longer_chunks_express(gpu_lib, O, monkeypatch,
     eng = _engine(avg)
     ring = PageRing(eng)
     assert ring.express() == (16, (16 << 20) * 13 // 16)
-    n = 6 * GiB + 4096
+    n = 3 * GiB + 4096            # 827 chunks: 13 of at least 13/16 of the maximum, 19 of at least 11/16
     got = ring.ingest_synthetic([(515, 4, n)], timeout_s=120.0)[0]
     ring.quiesce()
     ltail = int(re.search(r"ltail=(\d+)", ring.debug()).group(1))
