@@ -634,8 +634,8 @@ func (e *Engine) XXH3Files(buf []byte, offsets, lengths []uint64) ([]uint64, err
 // a DMA, a peer GPU or a kernel). HOST bytes go through PayloadStream (pbsgpu_stream_*), which is a client of the engine's
 // own ring: pinned staging, H2D straight into a reserved page, the same cut rounds and SHA-256 service.
 // The goroutine may block in a Read for as long as it likes: a ring that is not called for the idle timeout stops its idle
-// service by itself and the next Pump starts it again (nothing is lost); Park does so at once. A stream whose data
-// overflows the candidate provisioning (a crafted short period) fails alone with ErrDensity, the others go on.
+// service by itself and the next Pump starts it again (nothing is lost); Park does so at once. No byte content fails
+// a stream: candidate-dense data (a crafted short period) is cut exactly, by on-demand re-scans inside the cut round.
 type Ring struct {
 	h   *C.pbsgpu_ring
 	eng *Engine

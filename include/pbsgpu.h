@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBSGPU_ABI_VERSION 4
+#define PBSGPU_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------- */
 #define PBSGPU_OK 0
@@ -47,7 +47,8 @@ extern "C" {
 #define PBSGPU_E_CAPACITY (-5)     /* caller's output buffer too small (needed size reported) */
 #define PBSGPU_E_BUSY (-6)         /* pbsgpu_submit_*: all in-flight tickets used, collect one first (nothing else returns it) */
 #define PBSGPU_E_TICKET (-7)       /* unknown / already collected ticket */
-#define PBSGPU_E_DENSITY (-8)      /* candidate density exceeded every retry capacity */
+/* (-8 is retired: it was PBSGPU_E_DENSITY until ABI v4 — no byte content fails a call any more: candidate-dense data is
+ * resolved exactly by on-demand re-scans, on every path) */
 #define PBSGPU_E_STATE (-9)        /* call not valid in the handle's current state */
 
 const char *pbsgpu_strerror(int status);
@@ -217,10 +218,11 @@ int pbsgpu_chunker_reset(pbsgpu_chunker *c);
  * straight into a reserved page; cut rounds, the persistent SHA-256 service, page-granular
  * release and record delivery are shared. `window_bytes` is accepted for
  * compatibility and ignored (rounds 1-3: bytes per private device window).
- * A stream whose DATA defeats the candidate provisioning (a crafted short period: more
- * than one candidate per 128 bytes over a whole scan tile) fails with PBSGPU_E_DENSITY from
- * its next call; records cut before that point are still delivered, other streams are
- * not affected. Such data goes through pbsgpu_submit_* (capacity retry). */
+ * No byte content makes a call fail (the reference's WriteEntryReader has no content-dependent
+ * error either: internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836): data
+ * with more candidates than a scan tile has slots (periodic / crafted: one per 128 bytes and
+ * more) is resolved exactly by on-demand re-scans inside the cut round — slower for that
+ * stretch, bit-identical to the serial chunker. */
 typedef struct pbsgpu_stream pbsgpu_stream;
 int pbsgpu_stream_create(pbsgpu_engine *eng, uint64_t window_bytes, pbsgpu_stream **out);
 void pbsgpu_stream_destroy(pbsgpu_stream *s);
@@ -298,11 +300,10 @@ int pbsgpu_stream_write_marker(pbsgpu_stream *s, const struct pbsgpu_payload_for
  * PBSGPU_RING_IDLE_TIMEOUT_S (default 20 s) while its service has nothing to do — a writer in a blocking tape read,
  * internal/tapeio/converter.go:672-680 — loses NOTHING: the service stops on its own (a handshake with the host
  * guarantees that no chunk is left behind) and the next pump starts it again.
- * Failure containment: a stream whose data overflows a scan tile's candidate slots (more than one candidate per 128 bytes
- * over a whole tile: a crafted short period) fails ALONE — its calls answer PBSGPU_E_DENSITY after the records cut before
- * the failure, its pages are released — every other stream of the ring goes on; the failed stream's slot is handed to a
- * new stream only after every round that still refers to it has been reaped. A stream is limited to 4 PiB (52-bit offsets
- * inside a round, 12 bits for the slot); PBSGPU_E_INVALID beyond. */
+ * Candidate-dense data (more than one candidate per 128 bytes over a whole scan tile: a crafted short period) is cut
+ * exactly like everything else: the control kernel re-scans such a tile on demand for the one candidate the cut rule needs
+ * (ABI v4 failed the stream with PBSGPU_E_DENSITY). A stream is limited to 4 PiB (52-bit offsets inside a round, 12 bits
+ * for the slot); PBSGPU_E_INVALID beyond. */
 typedef struct pbsgpu_ring pbsgpu_ring;
 typedef struct pbsgpu_ring_options {
     uint64_t arena_bytes;  /* device memory for pages; 0 = what is free minus 8 GiB */
@@ -364,8 +365,7 @@ int pbsgpu_ring_poll(pbsgpu_ring *ring, uint32_t stream, pbsgpu_record *out, uin
  * once in `finished` (up to fcap per call); close them afterwards. */
 int pbsgpu_ring_poll_any(pbsgpu_ring *ring, pbsgpu_record *out, uint64_t cap, uint64_t *n, uint32_t *finished, uint32_t fcap,
                          uint32_t *nfinished);
-/* Release a finished, fully polled stream's slot. A FAILED stream may be closed at any time: the slot is released and the
- * call answers PBSGPU_E_DENSITY (its record list is incomplete). */
+/* Release a finished, fully polled stream's slot (PBSGPU_E_STATE before that). */
 int pbsgpu_ring_close(pbsgpu_ring *ring, uint32_t stream);
 /* Suggested boundary (see pbsgpu_submit_device_suggested) at `offset` bytes from the stream's start; ascending; announce
  * it before the bytes around it are committed. The reader-buffer rule of pbsgpu_engine_set_suggested_feed applies. */

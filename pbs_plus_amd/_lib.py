@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpbsgpu.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0
-E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_CAPACITY, E_BUSY, E_TICKET, E_DENSITY, E_STATE = range(-1, -10, -1)
+E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_CAPACITY, E_BUSY, E_TICKET, _E_RETIRED_8, E_STATE = range(-1, -10, -1)  # (-8 was E_DENSITY until ABI v4)
 
 
 class PbsGpuError(RuntimeError):

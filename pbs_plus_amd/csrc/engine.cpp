@@ -174,13 +174,20 @@ uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes) {
     const uint32_t tile_bytes = pbsk::scan_tile_bytes(nbytes);
     // a corpus that needed a larger per-tile capacity once tends to need it again: start there
     const uint32_t hint = e->cap_hint.load(std::memory_order_relaxed);
-    if (hint && e->cap_hint_tile.load(std::memory_order_relaxed) == tile_bytes) return hint;
     // expected candidates per wave tile = 3 * tile / (mask + 1); leave generous headroom
     const double lambda = 3.0 * tile_bytes / ((double)e->cfg.mask + 1.0);
     double want = 4.0 * lambda + 16.0;
     uint32_t cap = 8;
     while (cap < want) cap <<= 1;
+    if (hint > cap && e->cap_hint_tile.load(std::memory_order_relaxed) == tile_bytes) return std::min(hint, cap_limit(e, tile_bytes));
     return cap;
+}
+
+uint32_t cap_limit(const pbsgpu_engine *e, uint32_t tile_bytes) {
+    const double lambda = 3.0 * tile_bytes / ((double)e->cfg.mask + 1.0);
+    uint32_t capv = 8;
+    while (capv < 4.0 * lambda + 16.0) capv <<= 1;
+    return std::min<uint32_t>(std::max<uint32_t>(capv * 2, tile_bytes / 128), tile_bytes);
 }
 
 int set_device(const pbsgpu_engine *e) {
@@ -267,7 +274,7 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
     const uint64_t extent = nbytes + lead;
     const uint32_t tile_bytes = pbsk::scan_tile_bytes(nbytes);
     const uint64_t ntiles = (extent + tile_bytes - 1) / tile_bytes;
-    if (ntiles * (uint64_t)cap >= (1ull << 32)) return PBSGPU_E_DENSITY;
+    if (ntiles * (uint64_t)cap >= (1ull << 32)) return PBSGPU_E_CAPACITY;  // (> 0.5 TB in one batch at the capacity limit)
     CHK(s.tile_cnt.ensure((size_t)ntiles * 4 + 16));
     CHK(s.tile_off.ensure((size_t)ntiles * 4 + 16));
     CHK(s.tile_slots.ensure((size_t)ntiles * cap * 4 + 16));
@@ -306,6 +313,7 @@ int enqueue_candidates(pbsgpu_engine *e, Slot &s, const uint8_t *dptr, uint64_t 
 // phase 1 of a batch: candidates -> compaction -> min/max (+ suggested boundary) resolution (records without digests)
 static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     s.cap = cap;
+    s.dense_mode = cap >= cap_limit(e, pbsk::scan_tile_bytes(s.nbytes));
     CHK(s.seg_cnt.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.seg_off.ensure((size_t)s.nseg * 4 + 16));
     CHK(s.recs.ensure((size_t)s.rec_cap * sizeof(pbsgpu_record) + 64));
@@ -344,7 +352,21 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
         while (big_nodes < 2 * expect + 2) big_nodes <<= 1;
         while ((1ull << big_levels) < (uint64_t)big_nodes + 1) ++big_levels;
     }
-    const bool par_ok = s.nseg == 1 && !s.nsugg && !par_off && s.nbytes >= par_min;
+    // at the capacity limit some tile may overflow: only the serial walks know how to ask such a tile (DenseTiles)
+    pbsk::DenseTiles dzv{};
+    const uint32_t lead = (uint32_t)((uintptr_t)s.dptr & 127u);
+    const uint32_t tile_bytes = pbsk::scan_tile_bytes(s.nbytes);
+    const uint64_t ntiles = (s.nbytes + lead + tile_bytes - 1) / tile_bytes;
+    if (s.dense_mode) {
+        dzv.tile_cnt = s.tile_cnt.as<uint32_t>();
+        dzv.cap = cap;
+        dzv.tile_bytes = tile_bytes;
+        dzv.table_rot = e->d_table_rot;
+        dzv.thr = e->thr;
+        dzv.base = s.dptr;
+    }
+    const pbsk::DenseTiles *dz = s.dense_mode ? &dzv : nullptr;
+    const bool par_ok = s.nseg == 1 && !s.nsugg && !par_off && s.nbytes >= par_min && !s.dense_mode;
     if (par_ok && big_nodes && s.par.ensure(pbsk::resolve_par_scratch_bytes(big_nodes, big_levels)) == PBSGPU_OK) {
         HIPCHK(pbsk::launch_resolve_single_par_grid(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, e->effmin, e->cfg.max,
                                                     sc + SC_ZERO, sc + SC_NREC, s.recs.as<pbsgpu_record>(), s.rec_cap,
@@ -357,15 +379,15 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     } else if (s.nseg == 1) {  // one stream: records start at 0, a single walk writes them and their count
         HIPCHK(pbsk::launch_resolve_single(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, e->effmin, e->cfg.max,
                                            sc + SC_ZERO, sc + SC_NREC, s.recs.as<pbsgpu_record>(), s.rec_cap, sg,
-                                           s.stream));
+                                           s.stream, dz, lead, ntiles));
     } else {
         HIPCHK(pbsk::launch_resolve_count(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin,
-                                          e->cfg.max, s.seg_cnt.as<uint32_t>(), sg, s.stream));
+                                          e->cfg.max, s.seg_cnt.as<uint32_t>(), sg, s.stream, dz, lead, ntiles));
         HIPCHK(pbsk::launch_exclusive_scan(s.seg_cnt.as<uint32_t>(), s.nseg, 0xffffffffu, s.seg_off.as<uint32_t>(),
                                            sc + SC_NREC, nullptr, s.scan_tmp.as<uint32_t>(), s.stream));
         HIPCHK(pbsk::launch_resolve_write(s.dense.as<uint64_t>(), sc + SC_NCAND, dsegs, s.nseg, e->effmin,
                                           e->cfg.max, s.seg_off.as<uint32_t>(), s.recs.as<pbsgpu_record>(),
-                                          s.rec_cap, sg, s.stream));
+                                          s.rec_cap, sg, s.stream, dz, lead, ntiles));
     }
     HIPCHK(hipEventRecord(s.ev[EV_RESOLVE1], s.stream));
     return PBSGPU_OK;
@@ -376,7 +398,8 @@ static int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     uint32_t *sc = s.scalars.as<uint32_t>();
     const pbsgpu_segment *dsegs = s.segs_dev();
     HIPCHK(pbsk::launch_order(s.dptr, dsegs, s.recs.as<pbsgpu_record>(), sc + SC_NREC, e->cfg.max, s.order.as<uint4>(),
-                              sc + SC_WGLIMIT, e->num_cus, sc + SC_MAXCNT, s.cap, e->sha_slack_pct, s.stream));
+                              sc + SC_WGLIMIT, e->num_cus, s.dense_mode ? nullptr : sc + SC_MAXCNT, s.cap, e->sha_slack_pct,
+                              s.stream));  // (dense mode: the cut list is exact whatever the tiles found — hash it)
     // form of the hash kernel: issue-bound (dense) or chain-bound (sparse), from what the host knows at submit time —
     // the bytes of the batch and the longest chain the chunker can produce
     const uint64_t longest = std::min<uint64_t>(e->cfg.max, std::max<uint64_t>(s.nbytes, 1)) / 64 + 1;
@@ -562,21 +585,30 @@ static int submit_common(pbsgpu_engine *e, const void *ptr, bool host, uint64_t 
     return PBSGPU_OK;
 }
 
-// wait for a slot; re-run with a larger per-tile capacity if any tile overflowed
+// wait for a slot; re-run with a larger per-tile capacity if any tile overflowed — up to the capacity limit (cap_limit): a
+// batch scanned THERE is resolved exactly whatever its tiles found (enqueue_cut: dense_mode), so at most one more run follows
 static int sync_slot(pbsgpu_engine *e, Slot &s) {
     if (s.synced) return PBSGPU_OK;
+    const uint32_t tile_bytes = pbsk::scan_tile_bytes(s.nbytes);
+    const uint32_t limit = cap_limit(e, tile_bytes);
     for (;;) {
         HIPCHK(hipStreamSynchronize(s.stream));
         const uint32_t *hs = s.h_scalars.as<uint32_t>();
-        if (hs[SC_MAXCNT] <= s.cap) {
+        if (hs[SC_MAXCNT] <= s.cap || s.dense_mode) {
+            if (s.dense_mode && hs[SC_MAXCNT] <= s.cap / 2 && e->cap_hint_tile.load(std::memory_order_relaxed) == tile_bytes) {
+                // the corpus has calmed down: the next batch starts lower again (and gets the parallel resolve back)
+                uint32_t cap = 8;
+                while (cap < hs[SC_MAXCNT]) cap <<= 1;
+                e->cap_hint.store(cap, std::memory_order_relaxed);  // (default_cap never goes below the nominal figure)
+            }
             s.ncand = hs[SC_NCAND];
             s.nrec = hs[SC_NREC];
             break;
         }
         uint32_t cap = s.cap;
-        while (cap < hs[SC_MAXCNT]) cap <<= 1;
-        if (cap > pbsk::scan_tile_bytes(s.nbytes)) cap = pbsk::scan_tile_bytes(s.nbytes);
-        e->cap_hint_tile.store(pbsk::scan_tile_bytes(s.nbytes), std::memory_order_relaxed);
+        while (cap < hs[SC_MAXCNT] && cap < limit) cap <<= 1;
+        if (cap > limit) cap = limit;
+        e->cap_hint_tile.store(tile_bytes, std::memory_order_relaxed);
         e->cap_hint.store(cap, std::memory_order_relaxed);
         s.retries++;
         int st = enqueue_pipeline(e, s, cap);

@@ -186,6 +186,7 @@ struct Slot {
     bool sugg_open_end = false;
     bool host_submit = false;
     uint32_t retries = 0;
+    bool dense_mode = false;  // scanned at the capacity limit: the resolve walks re-scan overflowed tiles on demand (DenseTiles)
     uint64_t nrec = 0, ncand = 0;
 
     int init(hipStream_t borrowed = nullptr);  // stream (unless borrowed) + events
@@ -246,6 +247,9 @@ struct pbsgpu_engine {
 namespace pbse {
 
 uint32_t default_cap(const pbsgpu_engine *e, uint64_t nbytes);
+// largest per-tile slot capacity a scan is given: one candidate per 128 bytes (or twice the chunker's nominal provisioning,
+// whichever is larger). Tiles beyond it are resolved by on-demand re-scans (DenseTiles, kernels.h), never by more memory.
+uint32_t cap_limit(const pbsgpu_engine *e, uint32_t tile_bytes);
 int set_device(const pbsgpu_engine *e);
 bool is_device_pointer(const void *p);
 

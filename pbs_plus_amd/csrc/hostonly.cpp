@@ -66,7 +66,6 @@ const char *pbsgpu_strerror(int status) {
     case PBSGPU_E_CAPACITY: return "output buffer too small";
     case PBSGPU_E_BUSY: return "all in-flight slots busy";
     case PBSGPU_E_TICKET: return "unknown ticket";
-    case PBSGPU_E_DENSITY: return "candidate density exceeds capacity";
     case PBSGPU_E_STATE: return "invalid state";
     default: return "unknown status";
     }

@@ -51,8 +51,7 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 // dense, ascending candidate END offsets (caller coordinates) from the per-tile slots
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
-                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st,
-                          const struct RingPage *ring_pages = nullptr, uint32_t ring_tpp = 0, uint32_t *ring_seg_fail = nullptr);
+                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st);
 
 // one long stream without suggested boundaries: the cut chain followed by pointer doubling (kernels.hip); `scratch` holds
 // resolve_par_scratch_bytes(node_cap, levels); falls back to the serial walk when there are more candidates than node_cap - 1
@@ -99,28 +98,48 @@ struct SuggFeed {
 // fresh multi-TiB backup, a tape conversion — could exceed)
 constexpr unsigned kRingOffBits = 52;
 constexpr uint64_t kRingOffMask = (1ull << kRingOffBits) - 1ull;
-struct RingSeg;
-struct ResolveRing {
-    const RingSeg *segs_in = nullptr;
-    const uint32_t *seg_fail = nullptr;   // 1 = skip the segment (its stream failed)
-    const uint64_t *ecand_in = nullptr;   // carried hash candidate of the open chunk (~0 = none)
-    uint64_t *ecand_out = nullptr;        // written by the write pass when the segment produced records:
-    uint32_t *open_out = nullptr;         //   1 = the last record is the still-open chunk
-    uint64_t *newc_out = nullptr;         //   start of the open chunk (stream offset) after this round
+struct RingPage;
+// Exact handling of candidate-DENSE scan tiles (periodic / crafted data). A tile records at most `cap` of its candidates; a
+// tile that found more (tile_cnt[t] > cap) leaves an arbitrary SUBSET in the dense list — every entry a true candidate, some
+// missing. The cut rule only ever needs ONE thing from such a tile: the first candidate at or behind a given position. So the
+// resolve walk re-scans on demand (kernels.hip: dense_refine / dense_first_hit): whenever the stretch it is about to skip —
+// [s + effmin, first listed candidate) — touches an overflowed tile, one wave computes the window hashes of that part of the
+// tile (64 lanes x 64 positions per step, the scan's own pre-rotated table and threshold) and takes the first hit. Nothing
+// fails and nothing is re-run: the reference's writer never fails on byte content either
+// (transfer.ArchiveWriter.WriteEntryReader: internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836).
+struct DenseTiles {
+    const uint32_t *tile_cnt = nullptr;  // true candidate count per tile; null = no tile of this launch overflowed
+    uint32_t cap = 0, tile_bytes = 0;
+    const uint32_t *table_rot = nullptr;
+    uint32_t thr = 0;
+    const uint8_t *base = nullptr;       // flat byte range: caller byte x at base[x] (any alignment); page ring: the arena
+    const RingPage *pages = nullptr;     // page ring: the round's page table (tile t lies in entry t / tpp)
+    uint32_t tpp = 0;
+};
+// where the tiles of ONE segment's walk lie: END offset E (the walk's coordinates) belongs to tile
+// first_tile + (E - 1 - L0 + lead) / tile_bytes, for E > L0 (flat range: L0 = 0, lead = caller pointer & 127, the scan's
+// tiles start at the 128-byte line of byte 0; page ring: L0 = logical offset of the segment's first NEW page, lead = 0)
+struct DenseSeg {
+    uint64_t L0 = 0, first_tile = 0, ntiles = 0;
+    uint32_t lead = 0;
 };
 
 // min/max resolution, one wave per segment. count pass -> seg_cnt; write pass -> recs[seg_off[s] + k]
+// (`dz`: the batch was scanned at the capacity limit and some tile overflowed — the walks consult the tiles, see DenseTiles;
+// `maxcnt` = the device word that holds the largest tile count, `lead` = caller pointer & 127)
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt,
-                                const Suggested &sg, hipStream_t st, const ResolveRing *rr = nullptr, unsigned lds_tag = 0);
+                                const Suggested &sg, hipStream_t st, const DenseTiles *dz = nullptr, uint32_t lead = 0,
+                                uint64_t ntiles = 0);
 hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st,
-                                const ResolveRing *rr = nullptr, unsigned lds_tag = 0);
+                                const DenseTiles *dz = nullptr, uint32_t lead = 0, uint64_t ntiles = 0);
 
 hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
-                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st);
+                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st,
+                                 const DenseTiles *dz = nullptr, uint32_t lead = 0, uint64_t ntiles = 0);
 
 // SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
 // `queue` is a device uint32 that must be zero at launch.
@@ -189,7 +208,7 @@ struct alignas(64) RingCtl {   // device memory, one 64-byte line
     };
     uint32_t head;         // next queue position to hand out
     uint32_t free_count;   // pages reported free so far
-    uint32_t error;        // sticky, ring-wide: a round overflowed its record / cell capacity (never a single stream's fault)
+    uint32_t error;        // sticky, ring-wide: a round overflowed its record / cell capacity (the host's bound was wrong)
     uint32_t rounds_done;  // rounds published so far (k_ring_publish); the service compares it with the host's count of
                            // enqueued rounds before it stops on its own
     uint32_t xp_busy;      // express service: lane pairs that hold a chunk right now (the pair service's lanes take a long
@@ -283,18 +302,16 @@ struct RingStreamState {
     uint64_t end;          // bytes received so far
     uint64_t ecand;        // ~0 or: the hash candidate inside the open chunk that a suggested boundary beyond the bytes
                            // seen so far pre-empts (reader-buffer rule); it is not rescanned, so it is carried here
-    uint32_t failed;       // a scan tile of this stream overflowed its candidate slots: the stream is dropped, its pages
-    uint32_t pad;          // are released, every other stream of the ring goes on
+    uint32_t pad[2];
     uint32_t pt[kRingPT];  // logical page k -> physical page, at [k % kRingPT]
 };
 struct RingRoundStatus {   // mapped pinned: written last by a round
     uint32_t seq;          // round number + 1
     uint32_t nrec;         // record cells written (open chunks included as void cells)
     uint32_t ncand;
-    uint32_t error;        // 2 = record / cell capacity (ring-wide); a candidate overflow only fails ITS stream (seg_status)
+    uint32_t error;        // 2 = record / cell capacity (ring-wide: the host's own bound was wrong, never the data's fault)
     uint32_t tail;         // queue tail after this round
-    uint32_t nfailed;      // segments of this round whose stream failed (seg_status[s] = 1)
-    uint32_t pad[2];
+    uint32_t pad[3];
 };
 struct RingRound {
     // geometry / constants
@@ -333,8 +350,6 @@ struct RingRound {
     uint32_t *seg_open;        // per segment: 1 = the round left an open chunk
     uint64_t *seg_ecand_in;    // per segment: RingStreamState::ecand before / after this round
     uint64_t *seg_ecand;
-    uint32_t *seg_fail;        // per segment: 1 = the stream is (or has just) failed
-    uint32_t *seg_status;      // mapped pinned, per segment: the host's copy of seg_fail
     // suggested boundaries (optional): sugg[sugg_idx[s] .. sugg_idx[s+1]) ascending, offsets within stream s
     const uint64_t *sugg;
     const uint32_t *sugg_idx;

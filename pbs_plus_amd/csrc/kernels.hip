@@ -791,20 +791,14 @@ hipError_t launch_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t clamp,
 __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const uint32_t *tile_off,
                                                  const uint32_t *tile_slots, uint32_t cap, uint64_t ntiles,
                                                  uint32_t lead, uint64_t *dense, uint64_t dense_cap,
-                                                 uint32_t tile_bytes, const RingPage *ring_pages, uint32_t ring_tpp,
-                                                 uint32_t *ring_seg_fail) {
+                                                 uint32_t tile_bytes) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
-    const uint32_t c = min(tile_cnt[t], cap);
+    const uint32_t c = min(tile_cnt[t], cap);  // (a tile that found more keeps the first `cap` it recorded: see DenseTiles)
     if (c == 0) return;
-    // page ring: a tile that overflowed its slot list fails the STREAM that owns the page, nothing else (the slots it did
-    // record land in that stream's logical range of the dense list, where only its own, skipped, segment would look)
-    if (ring_seg_fail && tile_cnt[t] > cap) ring_seg_fail[ring_pages[t / ring_tpp].seg] = 1u;
     const uint32_t *sl = tile_slots + t * cap;
     const uint64_t base = tile_off[t];
-    // page ring: candidates are reported in LOGICAL stream coordinates ((slot << kRingOffBits) | offset), pages ascending
-    const uint64_t tbase = ring_pages ? ring_pages[t / ring_tpp].logical + (t % ring_tpp) * (uint64_t)tile_bytes
-                                      : t * (uint64_t)tile_bytes;
+    const uint64_t tbase = t * (uint64_t)tile_bytes;
     if (c <= 48) {  // the normal case (a handful of candidates per tile): rank by comparison
         for (uint32_t j = 0; j < c; ++j) {
             const uint32_t vj = sl[j];
@@ -836,13 +830,12 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t *tile_cnt, const
 
 hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, const uint32_t *tile_slots,
                           uint32_t cap, uint64_t ntiles, uint32_t lead, uint64_t nbytes, uint64_t *dense,
-                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st, const RingPage *ring_pages,
-                          uint32_t ring_tpp, uint32_t *ring_seg_fail) {
+                          uint64_t dense_cap, uint32_t tile_bytes, hipStream_t st) {
     (void)nbytes;
     if (ntiles == 0) return hipSuccess;
     const uint64_t nb = (ntiles + 255) / 256;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), ring_pages ? 1024u : 0u, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
-                       lead, dense, dense_cap, tile_bytes, ring_pages, ring_tpp, ring_seg_fail);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)nb), dim3(256), 0, st, tile_cnt, tile_off, tile_slots, cap, ntiles,
+                       lead, dense, dense_cap, tile_bytes);
     return hipGetLastError();
 }
 
@@ -858,9 +851,102 @@ hipError_t launch_compact(const uint32_t *tile_cnt, const uint32_t *tile_off, co
 // the first suggested boundary b with min <= b - s <= max; boundaries with b - s < min are dropped for good. For
 // min >= 65 they behave exactly like extra candidates; the separate list keeps the min = 64 corner (hash cuts need
 // chunk_size >= 65, a suggested one only >= min) exact.
+// ---- candidate-dense tiles: the first TRUE candidate of a stretch of one tile, on demand (see DenseTiles, kernels.h) ----
+// All 64 lanes call it with the same arguments. q = the byte at the END of the first window (the window of position i is
+// q[i - 63 .. i]); n positions. Returns the index of the first position whose window hash passes the break test, ~0u if none.
+// One wave, rows of 256 bytes (one aligned dword per lane, coalesced), the prefix form the scan kernels use:
+//   Q(x) = rotl(Q(x - 1), 1) ^ t(x)   (t = pre-rotated table value of byte x),   h(x) = Q(x) ^ Q(x - 64)   (64 = 0 mod 32)
+// Q inside a lane's 4 bytes is 3 rotate-xor steps; across lanes an inclusive scan with a rotation of 4 bits per lane (six
+// shuffle steps: 4, 8, 16, then 32 / 64 / 128 = 0 bits); Q(x - 64) is the same byte of the lane 16 below. Lanes 0-15 of a
+// row only warm the prefix up, so rows advance by 192 bytes. A dword that holds no byte of [first window start, last
+// window end] is never read (the caller's buffer may begin or end right there). ~90 instructions and 11 shuffles per 192
+// positions, a dozen VGPRs: this is the cold path of the resolve walk and must not cost the walk its registers.
+__device__ __forceinline__ uint32_t dense_first_hit(const uint8_t *q, const uint32_t n, const uint32_t *__restrict__ tab,
+                                                    const uint32_t thr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint8_t *w0 = q - 63;                                        // first byte of the first window
+    const uint32_t sh = (uint32_t)((uintptr_t)w0 & 3u);
+    const uint8_t *a0 = w0 - sh - 4;                                   // row 0 starts one dword early: position 0 ends at byte
+                                                                       // sh + 67 >= 64 of its row, i.e. in a lane >= 16
+    const uintptr_t lo_dw = (uintptr_t)(w0 - sh), hi_dw = (uintptr_t)(q + (n - 1u)) & ~(uintptr_t)3;  // first / last dword with a needed byte
+    auto load_row = [&](const uint32_t r) -> uint32_t {
+        const uintptr_t A = (uintptr_t)a0 + 192u * (uintptr_t)r + 4u * lane;
+        const uintptr_t Ac = min(max(A, lo_dw), hi_dw);
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(Ac);
+        return (A == Ac) ? v : 0u;
+    };
+    const uint32_t rows = (n + sh + 3u) / 192u + 1u;                   // positions of row r: 192 r + 4 lane + k - sh - 67
+    uint32_t w = load_row(0);
+    for (uint32_t r = 0; r < rows; ++r) {
+        const uint32_t wn = (r + 1u < rows) ? load_row(r + 1u) : 0u;   // next row's bytes in flight behind this row's arithmetic
+        const uint32_t t0 = tab[w & 0xffu], t1 = tab[(w >> 8) & 0xffu], t2 = tab[(w >> 16) & 0xffu], t3 = tab[w >> 24];
+        const uint32_t q0 = t0;
+        const uint32_t q1 = __builtin_rotateleft32(q0, 1) ^ t1;
+        const uint32_t q2 = __builtin_rotateleft32(q1, 1) ^ t2;
+        const uint32_t q3 = __builtin_rotateleft32(q2, 1) ^ t3;
+        uint32_t X = q3;                                               // inclusive scan over the lanes' 4-byte sums
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(X, d, 64);
+            if ((int)lane >= d) X ^= __builtin_rotateleft32(y, (4 * d) & 31);
+        }
+        uint32_t Xp = __shfl_up(X, 1, 64);
+        if (lane == 0) Xp = 0;
+        const uint32_t Q[4] = {q0 ^ __builtin_rotateleft32(Xp, 1), q1 ^ __builtin_rotateleft32(Xp, 2),
+                               q2 ^ __builtin_rotateleft32(Xp, 3), q3 ^ __builtin_rotateleft32(Xp, 4)};
+        uint32_t first = ~0u;
+        const uint32_t i0 = 192u * r + 4u * lane - sh - 67u;          // position of byte 0 of this lane (wraps below 0: masked)
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            const uint32_t h = Q[k] ^ __shfl_up(Q[k], 16, 64);
+            const uint32_t i = i0 + (uint32_t)k;
+            if (lane >= 16u && h >= thr && i < n) first = i;           // (i < n also rejects the wrapped "negative" positions)
+        }
+        const unsigned long long m = __ballot(first != ~0u);
+        if (m) return __shfl(first, __ffsll((long long)m) - 1, 64);    // lanes are in position order
+        w = wn;
+    }
+    return ~0u;
+}
+
+// The walk is about to take `c` (first LISTED candidate >= tlo, ~0 = none) as the next hash cut unless the maximum (`lim` =
+// min(s + max, B)) comes first. Tiles that overflowed their slots may hold an unlisted candidate before that: the first
+// one in [tlo, min(c - 1, lim)] is returned instead of c. Wave-uniform.
+__device__ __forceinline__ uint64_t dense_refine(const DenseTiles &d, const DenseSeg &ds, const uint64_t tlo, const uint64_t lim,
+                                                 const uint64_t c) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lo = max(tlo, ds.L0 + 1u);  // (page ring: older pages hold no candidate at or behind tlo)
+    const uint64_t hi = min(c - 1u, lim);
+    if (ds.ntiles == 0 || lo > hi) return c;
+    // tile coordinates x = E - L0 + lead (>= 1): tile k holds the END offsets x in (k * tile_bytes, (k + 1) * tile_bytes]
+    const uint64_t lo_x = lo - ds.L0 + ds.lead, hi_x = min(hi - ds.L0 + ds.lead, ds.ntiles * d.tile_bytes);
+    if (lo_x > hi_x) return c;
+    const uint64_t ta = (lo_x - 1u) / d.tile_bytes, tb = (hi_x - 1u) / d.tile_bytes;
+    for (uint64_t t0 = ta; t0 <= tb; t0 += 64u) {
+        const uint64_t t = t0 + lane;
+        unsigned long long m = __ballot(t <= tb && d.tile_cnt[ds.first_tile + t] > d.cap);
+        while (m) {
+            const uint64_t tt = t0 + (uint64_t)(__ffsll((long long)m) - 1);
+            m &= m - 1ull;
+            const uint64_t qlo_x = max(lo_x, tt * d.tile_bytes + 1u), qhi_x = min(hi_x, (tt + 1u) * d.tile_bytes);
+            const uint64_t E0 = ds.L0 + qlo_x - ds.lead;  // the stretch's first END offset, in the walk's coordinates
+            const uint8_t *q;
+            if (d.pages) {
+                const RingPage &pe = d.pages[(ds.first_tile + tt) / d.tpp];
+                q = d.base + pe.phys_off + (E0 - 1u - pe.logical);
+            } else {
+                q = d.base + (E0 - 1u);
+            }
+            const uint32_t r = dense_first_hit(q, (uint32_t)(qhi_x - qlo_x + 1u), d.table_rot, d.thr);
+            if (r != ~0u) return E0 + r;
+        }
+    }
+    return c;
+}
+
 // The walk of ONE segment by ONE wave (all 64 lanes call it with the same arguments). Returns the number of records;
 // WRITE: record k goes to recs[rbase + k] (lane 0), `seg` is stored in its segment field.
-// Page-ring rounds (rr.segs_in != null; ring_kernels.inc): the segment is a stream's open chunk + its new pages in logical
+// Page-ring rounds (`ring`; ring_kernels.inc): the segment is a stream's open chunk + its new pages in logical
 // coordinates ((slot << kRingOffBits) | offset); suggested offsets are relative to the STREAM's byte 0; the segment's end is the
 // stream's end only if RingSeg::final; and the walk reports what the round leaves behind: is the last record the still-open
 // chunk (it is unless the serial chunker cuts exactly at the current end: a max-size chunk, a candidate or a winning
@@ -874,7 +960,7 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
                                                  const uint64_t *sugg, const uint64_t sbeg, const uint64_t send,
                                                  const uint32_t cmin, const SuggFeed fr, const bool ring,
                                                  const uint64_t ecand_first, bool *last_real_out, uint64_t *last_start_out,
-                                                 uint64_t *ecand_out) {
+                                                 uint64_t *ecand_out, const DenseTiles &dz, const DenseSeg &ds) {
     const int lane = threadIdx.x & 63;
     uint64_t s = A;
     uint32_t k = 0;
@@ -909,6 +995,7 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
             wb += 64;
             cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
         }
+        if (__builtin_expect(dz.tile_cnt != nullptr, 0)) c = dense_refine(dz, ds, tlo, min(thi, B), c);  // (some tile overflowed its slots)
         if (s == A && ecand_first != ~0ull) c = ecand_first;  // older than every listed candidate, >= tlo by construction
         const uint64_t e0 = (c < thi) ? c : thi;  // where the hash / max rule cuts, were the bytes there
         uint64_t e = (e0 > B) ? B : e0;
@@ -970,65 +1057,60 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
     return k;
 }
 
+// (`dz` non-null tile_cnt: the batch was scanned at the capacity LIMIT and `*maxcnt_p` tells whether any tile overflowed it)
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_resolve(const uint64_t *cands, const uint32_t *ncand_p,
                                                  const pbsgpu_segment *segs, uint32_t nseg, uint32_t effmin,
                                                  uint32_t maxsz, uint32_t *seg_cnt, const uint32_t *seg_off,
                                                  pbsgpu_record *recs, uint64_t rec_cap, const uint64_t *sugg,
                                                  const uint32_t *sugg_idx, uint32_t cmin, const uint32_t *gate,
-                                                 SuggFeed fr, ResolveRing rr) {
+                                                 SuggFeed fr, DenseTiles dz, DenseSeg ds) {
     const uint32_t seg = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (seg >= nseg) return;
     if (gate && *gate == 0) return;  // fallback launch behind k_resolve_par: only if that kernel handed the job back
-    if (rr.seg_fail && rr.seg_fail[seg]) {  // page ring: the stream of this segment has failed, it produces nothing
-        if (lane == 0 && seg_cnt) seg_cnt[seg] = 0;
-        return;
-    }
     __builtin_amdgcn_s_setprio(2);  // a latency-bound serial walk: do not queue behind throughput waves on this SIMD
     const uint64_t n = *ncand_p;
     const uint64_t A = segs[seg].offset, B = A + segs[seg].length;
-    const bool ring = rr.segs_in != nullptr;
-    if (ring) {
-        fr.open_end = rr.segs_in[seg].final ? 0u : 1u;
-        fr.origin = rr.segs_in[seg].origin;
-    }
     bool last_real;
     uint64_t last_start, ecand;
     const uint32_t k = resolve_walk<WRITE>(cands, n, A, B, seg, effmin, maxsz, WRITE ? (uint64_t)seg_off[seg] : 0, recs, rec_cap,
-                                           sugg, sugg ? sugg_idx[seg] : 0, sugg ? sugg_idx[seg + 1] : 0, cmin, fr, ring,
-                                           rr.ecand_in ? rr.ecand_in[seg] : ~0ull, &last_real, &last_start, &ecand);
+                                           sugg, sugg ? sugg_idx[seg] : 0, sugg ? sugg_idx[seg + 1] : 0, cmin, fr, false, ~0ull,
+                                           &last_real, &last_start, &ecand, dz, ds);
     if (lane == 0 && seg_cnt) seg_cnt[seg] = k;  // count pass; also the single-segment write pass (count -> *nrec)
-    if (WRITE && ring && lane == 0 && k > 0 && rr.open_out) {
-        const bool open = !rr.segs_in[seg].final && !last_real;
-        rr.open_out[seg] = open ? 1u : 0u;
-        rr.newc_out[seg] = (open ? last_start : B) & kRingOffMask;
-        rr.ecand_out[seg] = open ? ecand : ~0ull;
+}
+
+static DenseSeg flat_dense_seg(const DenseTiles *dz, uint32_t lead, uint64_t ntiles) {
+    DenseSeg ds{};
+    if (dz) {
+        ds.lead = lead;
+        ds.ntiles = ntiles;
     }
+    return ds;
 }
 
 hipError_t launch_resolve_count(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, uint32_t *seg_cnt, const Suggested &sg,
-                                hipStream_t st, const ResolveRing *rr, unsigned lds_tag) {
+                                hipStream_t st, const DenseTiles *dz, uint32_t lead, uint64_t ntiles) {
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
-    hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), lds_tag, st, cands, ncand, segs, nseg, effmin,
+    hipLaunchKernelGGL((k_resolve<false>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
                        maxsz, seg_cnt, (const uint32_t *)nullptr, (pbsgpu_record *)nullptr, (uint64_t)0, sg.offsets,
                        sg.index, sg.cmin, (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end},
-                       rr ? *rr : ResolveRing{});
+                       dz ? *dz : DenseTiles{}, flat_dense_seg(dz, lead, ntiles));
     return hipGetLastError();
 }
 
 hipError_t launch_resolve_write(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                 uint32_t nseg, uint32_t effmin, uint32_t maxsz, const uint32_t *seg_off,
                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st,
-                                const ResolveRing *rr, unsigned lds_tag) {
+                                const DenseTiles *dz, uint32_t lead, uint64_t ntiles) {
     if (nseg == 0) return hipSuccess;
     const uint64_t nb = ((uint64_t)nseg * 64 + 255) / 256;
-    hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), lds_tag, st, cands, ncand, segs, nseg, effmin,
+    hipLaunchKernelGGL((k_resolve<true>), dim3((unsigned)nb), dim3(256), 0, st, cands, ncand, segs, nseg, effmin,
                        maxsz, (uint32_t *)nullptr, seg_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin,
                        (const uint32_t *)nullptr, SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end},
-                       rr ? *rr : ResolveRing{});
+                       dz ? *dz : DenseTiles{}, flat_dense_seg(dz, lead, ntiles));
     return hipGetLastError();
 }
 
@@ -1302,7 +1384,7 @@ hipError_t launch_resolve_single_par_grid(const uint64_t *cands, const uint32_t 
     // the serial walk, gated: runs only if there were more candidates than nodes (*fallback != 0)
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
                        rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback,
-                       SuggFeed{1, 0, 0, 0}, ResolveRing{});
+                       SuggFeed{1, 0, 0, 0}, DenseTiles{}, DenseSeg{});
     return hipGetLastError();
 }
 
@@ -1322,17 +1404,19 @@ hipError_t launch_resolve_single_par(const uint64_t *cands, const uint32_t *ncan
     // the serial walk, gated: runs only if the parallel kernel handed the job back (*fallback != 0)
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec, zero_off, recs,
                        rec_cap, (const uint64_t *)nullptr, (const uint32_t *)nullptr, 0u, (const uint32_t *)fallback,
-                       SuggFeed{1, 0, 0, 0}, ResolveRing{});
+                       SuggFeed{1, 0, 0, 0}, DenseTiles{}, DenseSeg{});
     return hipGetLastError();
 }
 
 // one segment: its records start at index 0, so a single walk writes them and the count (-> *nrec)
 hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, const pbsgpu_segment *segs,
                                  uint32_t effmin, uint32_t maxsz, const uint32_t *zero_off, uint32_t *nrec,
-                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st) {
+                                 pbsgpu_record *recs, uint64_t rec_cap, const Suggested &sg, hipStream_t st,
+                                 const DenseTiles *dz, uint32_t lead, uint64_t ntiles) {
     hipLaunchKernelGGL((k_resolve<true>), dim3(1), dim3(64), 0, st, cands, ncand, segs, 1u, effmin, maxsz, nrec,
                        zero_off, recs, rec_cap, sg.offsets, sg.index, sg.cmin, (const uint32_t *)nullptr,
-                       SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end}, ResolveRing{});
+                       SuggFeed{sg.feed, sg.origin, sg.absolute, sg.open_end}, dz ? *dz : DenseTiles{},
+                       flat_dense_seg(dz, lead, ntiles));
     return hipGetLastError();
 }
 

@@ -21,9 +21,11 @@
 //   * digests and record fields land in host-visible record cells; pbsgpu_ring_poll hands them out per stream, in order.
 // One thread drives a ring (like one goroutine owns a writer, internal/tapeio/converter.go:672-680).
 //
-// Failure containment: a stream whose data overflows a scan tile's candidate slots fails ALONE (PBSGPU_E_DENSITY from
-// its own calls, its pages released on the device); a host that stops calling for longer than the idle timeout finds the
-// service gone and the ring healthy — the next round starts it again.
+// No byte content fails a stream: a scan tile that finds more candidates than it has slots (periodic / crafted data) is
+// resolved exactly by an on-demand re-scan inside the control kernel (DenseTiles, kernels.h) — like the reference's writer,
+// which has no content-dependent error (internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836).
+// A host that stops calling for longer than the idle timeout finds the service gone and the ring healthy — the next round
+// starts it again.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -112,21 +114,6 @@ void ring_reap_free(pbsgpu_ring *r) {
     }
 }
 
-// a stream has failed on the device (candidate overflow): what the host still holds of it goes back
-void ring_fail_stream(pbsgpu_ring *r, uint32_t slot) {
-    StreamSlot &s = r->slots[slot];
-    if (s.failed) return;
-    s.failed = true;
-    for (auto &q : s.ready) {
-        r->free_pages.push_back(q.phys);
-        r->ready_bytes -= q.valid;
-        if (q.dep) ring_event_put(r, q.dep);
-    }
-    s.ready.clear();
-    s.zero_final = false;
-    s.sugg.clear();
-}
-
 // round results in order: record cells to their streams, finished streams, input tables reusable
 void ring_reap_rounds(pbsgpu_ring *r) {
     for (auto &ri : r->rounds) {
@@ -135,7 +122,7 @@ void ring_reap_rounds(pbsgpu_ring *r) {
         if (hs->seq != ri.seq) break;  // rounds complete in order
         std::atomic_thread_fence(std::memory_order_acquire);
         if (hs->error) {
-            r->error = PBSGPU_E_DENSITY;  // record / cell capacity of a round exceeded: the ring's own bound was wrong
+            r->error = PBSGPU_E_STATE;  // record / cell capacity of a round exceeded: the ring's own bound was wrong
         } else {
             const uint32_t n = hs->nrec;
             const uint8_t *cells = r->cells.as<uint8_t>();
@@ -144,17 +131,12 @@ void ring_reap_rounds(pbsgpu_ring *r) {
                 const uint32_t *cw = reinterpret_cast<const uint32_t *>(cells + (size_t)c * 64);
                 if (cw[11] == 0) continue;  // the round's open chunk: no record
                 const uint32_t slot = cw[10];
-                if (slot >= r->slots.size() || r->slots[slot].zombie) continue;  // (a closed failed stream: nobody polls it)
+                if (slot >= r->slots.size()) continue;
                 r->slots[slot].cells.push_back(CellRef{c, ri.seq});
                 ri.live_cells++;
                 r->st.chunks++;
                 r->obs_bytes += (double)cw[11];
                 if (r->long_bytes && cw[11] >= r->long_bytes) r->obs_long_bytes += (double)cw[11];
-            }
-            if (hs->nfailed) {
-                const volatile uint32_t *ss = r->in_segstat(ri.input);
-                for (size_t s = 0; s < ri.seg_slots.size(); ++s)
-                    if (ss[s]) ring_fail_stream(r, ri.seg_slots[s]);
             }
             r->st.candidates += hs->ncand;
             r->pub_positions += (uint32_t)(hs->tail - r->tail_seen);
@@ -162,14 +144,6 @@ void ring_reap_rounds(pbsgpu_ring *r) {
             r->tail_seen = hs->tail;
         }
         for (uint32_t s : ri.finals) r->slots[s].final_done = true;
-        // the round no longer refers to its streams' slots: a slot whose failed stream was closed in the meantime (zombie)
-        // becomes reusable with the LAST such round — never earlier, or this loop would have applied the dead stream's
-        // failure / final / cells to the slot's next occupant
-        for (uint32_t s : ri.seg_slots) {
-            StreamSlot &sl = r->slots[s];
-            if (sl.rounds_ref) sl.rounds_ref--;
-            if (sl.zombie && sl.rounds_ref == 0) sl = StreamSlot{};
-        }
         r->inflight_bytes -= ri.new_bytes;
         ri.reaped = true;
         r->input_busy[ri.input] = false;
@@ -297,7 +271,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     const uint64_t look = feed > 1 ? (uint64_t)e->cfg.max : 0;  // reader-buffer rule: boundaries just beyond the bytes matter too
     for (uint32_t si = 0; si < r->slots.size() && np < r->round_pages; ++si) {
         StreamSlot &s = r->slots[si];
-        if (!s.open || s.failed || (s.ready.empty() && !s.zero_final)) continue;
+        if (!s.open || (s.ready.empty() && !s.zero_final)) continue;
         pbsk::RingSeg g{};
         g.slot = si;
         g.first_page = np;
@@ -356,8 +330,6 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
         }
         recbase[ns] = (uint32_t)cells_needed;
         cells_needed += ((uint64_t)take * r->page_bytes + e->cfg.max) / minsz + 2;
-        ri.seg_slots.push_back(si);
-        s.rounds_ref++;
         sg[ns++] = g;
     }
     if (ns == 0) return PBSGPU_OK;
@@ -441,8 +413,6 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.seg_open = r->seg_open.as<uint32_t>();
     rr.seg_ecand_in = r->seg_ecand_in.as<uint64_t>();
     rr.seg_ecand = r->seg_ecand.as<uint64_t>();
-    rr.seg_fail = r->seg_fail.as<uint32_t>();
-    rr.seg_status = r->in_segstat((uint32_t)in);
     rr.sugg = sugg_dev;
     rr.sugg_idx = sugg_dev ? suggidx : nullptr;
     rr.sugg_feed = feed;
@@ -655,9 +625,8 @@ int ring_park(pbsgpu_ring *r) {
 }
 
 int ring_commit_dep(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int final, hipEvent_t dep) {
-    if (!r || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
+    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
-    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed) return PBSGPU_E_STATE;
     if (nbytes > r->page_bytes || (nbytes != r->page_bytes && !final)) return PBSGPU_E_INVALID;  // only a stream's last page is short
     if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;  // 4 PiB per stream (52-bit logical offsets)
@@ -773,13 +742,14 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
         // configs[2]'s repeating 4 KiB files have one per 4 KiB). 12 bytes per slot: ~400 MB at the default round size.
-        // Data beyond that (a crafted short period) fails ITS stream, nothing else.
+        // A tile beyond that (a crafted short period) keeps what fits and is re-scanned on demand by the resolve walk
+        // (DenseTiles, kernels.h): slower for that stretch, exact all the same.
         const double lambda = 3.0 * r->tile_bytes / ((double)e->cfg.mask + 1.0);
         uint32_t capv = 8;
         while (capv < 4.0 * lambda + 16.0) capv <<= 1;
         r->cap = std::min<uint32_t>(std::max<uint32_t>(capv * 2, r->tile_bytes / 128), r->tile_bytes);
         const uint64_t ntiles = (uint64_t)r->round_pages * r->tpp;
-        if (ntiles * r->cap >= (1ull << 32)) return PBSGPU_E_DENSITY;
+        if (ntiles * r->cap >= (1ull << 32)) return PBSGPU_E_INVALID;  // (round_pages far beyond anything an arena holds)
         const uint32_t minsz = std::min(e->effmin, e->cfg.min);
         r->dense_cap = ntiles * r->cap;
         r->rec_cap = ((uint64_t)r->round_pages * r->page_bytes + (uint64_t)r->max_streams * e->cfg.max) / minsz +
@@ -824,7 +794,6 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         CHK(r->seg_open.ensure((size_t)r->max_streams * 4 + 16));
         CHK(r->seg_ecand_in.ensure((size_t)r->max_streams * 8 + 16));
         CHK(r->seg_ecand.ensure((size_t)r->max_streams * 8 + 16));
-        CHK(r->seg_fail.ensure((size_t)r->max_streams * 4 + 16));
         CHK(r->recs.ensure((size_t)r->rec_cap * sizeof(pbsgpu_record) + 64));
         CHK(r->cells.ensure((size_t)r->ncells * 64));
         CHK(r->heartbeat.ensure(256));
@@ -834,8 +803,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         auto al64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
         r->in_pages_off = 0;
         r->in_segs_off = al64((size_t)r->round_pages * sizeof(pbsk::RingPage));
-        r->in_segstat_off = al64(r->in_segs_off + (size_t)r->max_streams * sizeof(pbsk::RingSeg));
-        r->in_recbase_off = al64(r->in_segstat_off + (size_t)r->max_streams * 4);
+        r->in_recbase_off = al64(r->in_segs_off + (size_t)r->max_streams * sizeof(pbsk::RingSeg));
         r->in_suggidx_off = al64(r->in_recbase_off + ((size_t)r->max_streams + 1) * 4);
         r->in_status_off = al64(r->in_suggidx_off + ((size_t)r->max_streams + 1) * 4);
         r->input_stride = r->in_status_off + 64;
@@ -1000,7 +968,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         for (auto ev : r->ev_pool) (void)hipEventDestroy(ev);
         for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
                           &r->tile_slots, &r->tile_cnt2, &r->tile_slots2, &r->tileq, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
-                          &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->seg_fail, &r->inputs_dev})
+                          &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->inputs_dev})
             b->release();
         r->cells.release();
         r->heartbeat.release();
@@ -1016,11 +984,6 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
 
 int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
     if (!r || !stream) return PBSGPU_E_INVALID;
-    for (auto &s : r->slots)
-        if (s.zombie) {  // a closed failed stream still holds its slot: have its last rounds finished?
-            ring_reap_rounds(r);
-            break;
-        }
     for (uint32_t i = 0; i < r->slots.size(); ++i)
         if (!r->slots[i].open) {
             r->slots[i] = StreamSlot{};
@@ -1034,41 +997,16 @@ int pbsgpu_ring_open(pbsgpu_ring *r, uint32_t *stream) {
 }
 
 int pbsgpu_ring_close(pbsgpu_ring *r, uint32_t stream) {
-    if (!r || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
+    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
-    if (s.failed) {  // a failed stream may be closed at any time: what it still holds goes back, its record list is incomplete
-        for (const CellRef &cr : s.cells)
-            for (auto &ri : r->rounds)
-                if (ri.seq == cr.round_idx) {
-                    ri.live_cells--;
-                    break;
-                }
-        s.cells.clear();
-        if (s.reserved >= 0) r->free_pages.push_back((uint32_t)s.reserved);
-        // Rounds enqueued before the failure was seen may still carry segments of this stream (the device answers them
-        // with seg_status = 1, and the host applies that — and `final`, and any stray cell — BY SLOT INDEX when it reaps
-        // them): the slot stays taken until the last of them has been reaped (ring_reap_rounds), so that a stream opened
-        // next can never inherit any of it
-        const uint32_t refs = s.rounds_ref;
-        s = StreamSlot{};
-        if (refs) {
-            s.open = true;
-            s.failed = true;
-            s.zombie = true;
-            s.reported = true;
-            s.rounds_ref = refs;
-        }
-        return PBSGPU_E_DENSITY;
-    }
     if (!s.final_done || !s.cells.empty()) return PBSGPU_E_STATE;  // finish it and poll its records first
     s.open = false;
     return PBSGPU_OK;
 }
 
 int pbsgpu_ring_reserve(pbsgpu_ring *r, uint32_t stream, void **dptr, uint64_t *cap) {
-    if (!r || !dptr || !cap || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
+    if (!r || !dptr || !cap || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
-    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
     if (r->error != PBSGPU_OK) return r->error;
     uint32_t phys = 0;
@@ -1084,9 +1022,8 @@ int pbsgpu_ring_commit(pbsgpu_ring *r, uint32_t stream, uint64_t nbytes, int fin
 }
 
 int pbsgpu_ring_suggest(pbsgpu_ring *r, uint32_t stream, uint64_t offset) {
-    if (!r || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
+    if (!r || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
-    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed) return PBSGPU_E_STATE;
     if (!s.sugg.empty() && offset < s.sugg.back()) return PBSGPU_E_INVALID;  // ascending
     // a boundary at or before bytes that are already in a round can no longer take part in those rounds' cuts: it must be
@@ -1097,10 +1034,9 @@ int pbsgpu_ring_suggest(pbsgpu_ring *r, uint32_t stream, uint64_t offset) {
 
 int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t kind, uint64_t nbytes, int final,
                      uint64_t *taken) {
-    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].live() || kind > 4) return PBSGPU_E_INVALID;
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open || kind > 4) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     *taken = 0;
-    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
     if (r->error != PBSGPU_OK) return r->error;
     if (s.bytes_committed + nbytes > pbsk::kRingMaxStream) return PBSGPU_E_INVALID;
@@ -1141,11 +1077,10 @@ int pbsgpu_ring_fill(pbsgpu_ring *r, uint32_t stream, uint64_t seed, uint32_t ki
 // calls pass NULL / 0 and continue. Otherwise like pbsgpu_ring_fill.
 int pbsgpu_ring_fill_pieces(pbsgpu_ring *r, uint32_t stream, const pbsgpu_fill_piece *pieces, uint32_t npieces, uint64_t nbytes,
                             int final, uint64_t *taken) {
-    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].live()) return PBSGPU_E_INVALID;
+    if (!r || !taken || stream >= r->slots.size() || !r->slots[stream].open) return PBSGPU_E_INVALID;
     static_assert(sizeof(pbsgpu_fill_piece) == sizeof(pbsk::FillPiece), "piece layout");
     StreamSlot &s = r->slots[stream];
     *taken = 0;
-    if (s.failed) return PBSGPU_E_DENSITY;
     if (s.final_committed || s.reserved >= 0) return PBSGPU_E_STATE;
     if (r->error != PBSGPU_OK) return r->error;
     if (pieces) {
@@ -1252,22 +1187,20 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
 }
 
 int pbsgpu_ring_poll(pbsgpu_ring *r, uint32_t stream, pbsgpu_record *out, uint64_t cap, uint64_t *n, int *finished) {
-    if (!r || !n || stream >= r->slots.size() || !r->slots[stream].live() || (!out && cap)) return PBSGPU_E_INVALID;
+    if (!r || !n || stream >= r->slots.size() || !r->slots[stream].open || (!out && cap)) return PBSGPU_E_INVALID;
     StreamSlot &s = r->slots[stream];
     ring_heartbeat(r);
     ring_reap_rounds(r);
     *n = 0;
     ring_pop_records(r, stream, out, cap, n);
     while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
-    if (finished) *finished = (!s.failed && s.final_done && s.cells.empty()) ? 1 : 0;
-    if (r->error != PBSGPU_OK) return r->error;
-    return (s.failed && s.cells.empty()) ? PBSGPU_E_DENSITY : PBSGPU_OK;  // what was cut before the failure is still delivered
+    if (finished) *finished = (s.final_done && s.cells.empty()) ? 1 : 0;
+    return r->error;
 }
 
 // Records of ANY open stream (each stream's in its own order), `segment` = stream id — for callers that drive hundreds
 // or thousands of short streams (one per file) and cannot afford to ask every one of them after every pump. A stream
-// that has ended and handed out its last record is reported once in `finished`; so is a stream that FAILED (its close
-// then answers PBSGPU_E_DENSITY).
+// that has ended and handed out its last record is reported once in `finished`.
 int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint64_t *n, uint32_t *finished, uint32_t fcap,
                          uint32_t *nfinished) {
     if (!r || !n || !nfinished || (!out && cap) || (!finished && fcap)) return PBSGPU_E_INVALID;
@@ -1277,9 +1210,9 @@ int pbsgpu_ring_poll_any(pbsgpu_ring *r, pbsgpu_record *out, uint64_t cap, uint6
     *nfinished = 0;
     for (uint32_t si = 0; si < r->slots.size(); ++si) {
         StreamSlot &s = r->slots[si];
-        if (!s.live() || s.reported) continue;
+        if (!s.open || s.reported) continue;
         ring_pop_records(r, si, out, cap, n);
-        if ((s.final_done || s.failed) && s.cells.empty() && *nfinished < fcap) {
+        if (s.final_done && s.cells.empty() && *nfinished < fcap) {
             finished[(*nfinished)++] = si;
             s.reported = true;
         }
@@ -1320,11 +1253,11 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
     for (uint32_t i = 0; i < r->slots.size(); ++i) {
         const StreamSlot &s = r->slots[i];
         if (!s.open) continue;
-        put("stream %u: committed=%llu enqueued=%llu final_committed=%d final_enqueued=%d final_done=%d failed=%d ready=%zu cells=%zu "
-            "out=%llu | device c=%llu end=%llu failed=%u\n", i, (unsigned long long)s.bytes_committed,
-            (unsigned long long)s.bytes_enqueued, (int)s.final_committed, (int)s.final_enqueued, (int)s.final_done, (int)s.failed,
+        put("stream %u: committed=%llu enqueued=%llu final_committed=%d final_enqueued=%d final_done=%d ready=%zu cells=%zu "
+            "out=%llu | device c=%llu end=%llu\n", i, (unsigned long long)s.bytes_committed,
+            (unsigned long long)s.bytes_enqueued, (int)s.final_committed, (int)s.final_enqueued, (int)s.final_done,
             s.ready.size(), s.cells.size(), (unsigned long long)s.records_out, (unsigned long long)sts[i].c,
-            (unsigned long long)sts[i].end, sts[i].failed);
+            (unsigned long long)sts[i].end);
         if (!s.cells.empty()) {
             const uint8_t *c = r->cells.as<uint8_t>() + (size_t)s.cells.front().cell * 64;
             pbsgpu_record rec;

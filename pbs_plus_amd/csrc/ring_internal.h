@@ -38,7 +38,6 @@ struct CellRef {
 struct StreamSlot {
     bool open = false;
     bool fresh = true;                    // no round has carried this stream yet (device state starts from zero)
-    bool failed = false;                  // a scan tile overflowed its candidate slots: this stream only (PBSGPU_E_DENSITY)
     uint64_t next_k = 0;                  // next logical page
     uint64_t bytes_committed = 0;
     uint64_t bytes_enqueued = 0;          // stream length after the rounds enqueued so far
@@ -53,12 +52,6 @@ struct StreamSlot {
     uint64_t origin = 0;                  // payload position of the stream's byte 0 (absolute reader grid of suggested boundaries)
     std::deque<uint64_t> sugg;            // suggested boundaries still of interest (stream offsets, ascending)
     void *owner = nullptr;                // the stream writer's section that feeds this slot (stream.cpp)
-    uint32_t rounds_ref = 0;              // enqueued rounds not yet reaped that carry a segment of this stream
-    bool zombie = false;                  // a FAILED stream that was closed while rounds still referred to its slot: the slot
-                                          // answers PBSGPU_E_INVALID to every call and is not handed out again until the last of
-                                          // those rounds has been reaped (round 5; before that the next stream opened into the
-                                          // slot inherited the dead stream's failure, its `final` and its stray record cells)
-    bool live() const { return open && !zombie; }
 };
 
 struct RoundInfo {
@@ -69,7 +62,6 @@ struct RoundInfo {
     uint32_t live_cells = 0;              // cells handed to streams and not yet polled
     bool reaped = false;
     std::vector<uint32_t> finals;         // slots whose stream ended with this round
-    std::vector<uint32_t> seg_slots;      // slot of every segment of the round
     uint64_t new_bytes = 0;               // stream bytes this round added
 };
 
@@ -100,7 +92,7 @@ struct pbsgpu_ring {
     uint32_t lslots = 0, long_bytes = 0;
     pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
     pbse::DevBuf tile_cnt2, tile_slots2, tileq;  // second set of the scan side (rounds alternate) + the two tile-queue counters
-    pbse::DevBuf seg_ecand_in, seg_ecand, seg_fail;
+    pbse::DevBuf seg_ecand_in, seg_ecand;
     pbse::DevBuf inputs_dev;  // device mirror of `inputs` (the round tables are staged once per round: k_ring_stage)
     bool stage_inputs = true;
     bool long_lo_auto = false;  // RingSource::long_lo from the chunker's maximum (bulk rings)
@@ -109,8 +101,7 @@ struct pbsgpu_ring {
     std::vector<pbse::PinnedBuf> piece_tab;      // per stream slot: the piece table of a synthetic edited stream (fill_pieces)
     std::vector<uint32_t> piece_n;
     pbse::PinnedBuf sugg_in[pbse::kRingInputs];  // suggested offsets of the round built in input i (grown on demand)
-    size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_segstat_off = 0, in_recbase_off = 0, in_suggidx_off = 0,
-           in_status_off = 0;
+    size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_recbase_off = 0, in_suggidx_off = 0, in_status_off = 0;
     hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
     hipStream_t xs = nullptr;             // the EXPRESS service (two lanes per chunk, long chunks only) when xp_cus > 0
     hipStream_t ps = nullptr;             // scan side of the cut rounds (head pads + scan): round n + 1 is scanned while round n's
@@ -159,7 +150,6 @@ struct pbsgpu_ring {
     uint8_t *in_dev(uint32_t i) const { return inputs_dev.as<uint8_t>() + (size_t)i * input_stride; }
     pbsk::RingPage *in_pages(uint32_t i) const { return reinterpret_cast<pbsk::RingPage *>(in(i) + in_pages_off); }
     pbsk::RingSeg *in_segs(uint32_t i) const { return reinterpret_cast<pbsk::RingSeg *>(in(i) + in_segs_off); }
-    uint32_t *in_segstat(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_segstat_off); }
     uint32_t *in_recbase(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_recbase_off); }
     uint32_t *in_suggidx(uint32_t i) const { return reinterpret_cast<uint32_t *>(in(i) + in_suggidx_off); }
     pbsk::RingRoundStatus *in_status(uint32_t i) const {

@@ -131,7 +131,6 @@ struct Section {                         // the bytes between two forced cuts = 
     uint64_t base = 0;                   // payload position of its first byte
     bool input_closed = false;           // its last page has been committed
     bool ring_done = false;              // the ring has delivered its last record (slot closed)
-    int error = PBSGPU_OK;
     std::deque<pbsgpu_record> recs;      // filled under ring->mu by whoever drains the ring
 };
 
@@ -183,7 +182,7 @@ struct pbsgpu_stream {
     uint64_t landed = 0;                 // written bytes that have been copied into pages so far
     bool finished = false;               // input closed
     bool drained = false;                // ... and every record has been moved to `out`
-    int error = PBSGPU_OK;               // sticky (a failed section, a ring error)
+    int error = PBSGPU_OK;               // sticky (a HIP / ring error; never the bytes' fault)
     std::deque<uint64_t> suggested;      // announced boundaries (payload positions, ascending) not yet behind the stream
     size_t sugg_fwd = 0;                 // how many of them the current section's ring stream already knows
     std::deque<pbsgpu_record> out;
@@ -268,7 +267,7 @@ int ring_drain(pbsgpu_ring *r) {
     thread_local std::vector<pbsgpu_record> buf(4096);
     for (uint32_t si = 0; si < r->slots.size(); ++si) {
         StreamSlot &sl = r->slots[si];
-        if (!sl.live()) continue;  // (free, or a closed failed stream whose last rounds are still in flight)
+        if (!sl.open) continue;
         Section *sec = static_cast<Section *>(sl.owner);  // null: its stream was destroyed in an error state — discard
         for (;;) {
             uint64_t n = 0;
@@ -276,13 +275,10 @@ int ring_drain(pbsgpu_ring *r) {
             if (sec) sec->recs.insert(sec->recs.end(), buf.begin(), buf.begin() + (long)n);
             if (n < buf.size()) break;
         }
-        if ((sl.final_done || sl.failed) && sl.cells.empty()) {
-            if (sec) {
-                if (sl.failed) sec->error = PBSGPU_E_DENSITY;
-                sec->ring_done = true;
-            }
+        if (sl.final_done && sl.cells.empty()) {
+            if (sec) sec->ring_done = true;
             sl.owner = nullptr;
-            (void)pbsgpu_ring_close(r, si);  // (E_DENSITY for a failed stream: recorded above)
+            (void)pbsgpu_ring_close(r, si);
         }
     }
     while (!r->rounds.empty() && r->rounds.front().reaped && r->rounds.front().live_cells == 0) r->rounds.pop_front();
@@ -300,7 +296,6 @@ void stream_collect(pbsgpu_stream *s) {
             s->out.push_back(o);
         }
         sec->recs.clear();
-        if (sec->error != PBSGPU_OK && s->error == PBSGPU_OK) s->error = sec->error;
         if (!sec->ring_done) break;  // records come out in stream order: later sections wait
         if (sec == s->cur) s->cur = nullptr;
         s->sections.pop_front();
@@ -826,7 +821,7 @@ void pbsgpu_stream_destroy(pbsgpu_stream *s) {
                     if (!sec->ring_done && sec->rid < s->ring->slots.size() && s->ring->slots[sec->rid].owner == sec.get()) {
                         StreamSlot &sl = s->ring->slots[sec->rid];
                         sl.owner = nullptr;
-                        if (!sl.final_committed && !sl.failed) (void)ring_commit_dep(s->ring, sec->rid, 0, 1, nullptr);
+                        if (!sl.final_committed) (void)ring_commit_dep(s->ring, sec->rid, 0, 1, nullptr);
                         // (the slot stays open until its ring stream has ended; the next drain by any stream of the
                         // engine discards what it still delivers and closes it — ring_drain)
                     }

@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 
 
 def test_abi_version_and_strerror(L):
-    assert L.pbsgpu_abi_version() == 4
+    assert L.pbsgpu_abi_version() == 5
     assert L.pbsgpu_strerror(0) == b"ok"
     assert b"device" in L.pbsgpu_strerror(-2)
 
