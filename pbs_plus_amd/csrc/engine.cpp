@@ -28,7 +28,8 @@ struct Graveyard {
     std::atomic<uint32_t> park_gen{0};  // requests raised so far (a ring honours each request once)
     std::mutex mu;                   // the lists below
     std::vector<void *> dev, host;
-    uint64_t dev_bytes = 0, cap_bytes = 0;
+    uint64_t dev_bytes = 0;
+    std::atomic<uint64_t> cap_bytes{0};  // default cap of this device (an eighth of its memory), found at the first parked free
 };
 Graveyard g_grave[kMaxDevices];
 
@@ -98,17 +99,27 @@ void dev_free(void *p) {
         hipDeviceptr_t base = nullptr;
         if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
             (void)hipGetLastError();
-            size = 0;
+            size = 256u << 20;  // unknown: count it as a large block rather than as nothing (the cap errs on the early side)
+        }
+        // the cap: PBSGPU_GRAVEYARD_MIB (debug override, read once) or an eighth of the memory of the device the POINTER
+        // belongs to — not of whatever device the calling thread has current
+        static const uint64_t env_cap = []() -> uint64_t {
+            const char *v = getenv("PBSGPU_GRAVEYARD_MIB");
+            return v ? (uint64_t)(std::max(1.0, atof(v)) * 1048576.0) : 0ull;
+        }();
+        uint64_t dflt = 0;
+        if (env_cap == 0 && g.cap_bytes.load() == 0) {  // (outside g.mu: two HIP calls)
+            int cur = 0;
+            const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+            if (have_cur && cur != device) (void)hipSetDevice(device);
+            size_t fr = 0, tot = 0;
+            dflt = hipMemGetInfo(&fr, &tot) == hipSuccess ? std::max<uint64_t>(tot / 8, 1ull << 30) : (8ull << 30);
+            if (have_cur && cur != device) (void)hipSetDevice(cur);
         }
         std::lock_guard<std::mutex> lk(g.mu);
         if (g.services.load(std::memory_order_acquire) > 0) {  // (still: a flush takes g.mu after the count reached zero)
-            if (g.cap_bytes == 0) {  // default: an eighth of the device's memory
-                size_t fr = 0, tot = 0;
-                if (hipMemGetInfo(&fr, &tot) == hipSuccess) g.cap_bytes = std::max<uint64_t>(tot / 8, 1ull << 30);
-                else g.cap_bytes = 8ull << 30;
-            }
-            uint64_t cap = g.cap_bytes;
-            if (const char *v = getenv("PBSGPU_GRAVEYARD_MIB")) cap = (uint64_t)(std::max(1.0, atof(v)) * 1048576.0);
+            if (g.cap_bytes.load() == 0 && dflt) g.cap_bytes.store(dflt);
+            const uint64_t cap = env_cap ? env_cap : (g.cap_bytes.load() ? g.cap_bytes.load() : (8ull << 30));
             g.dev.push_back(p);
             g.dev_bytes += size;
             if (g.dev_bytes > cap && g.park_request.load(std::memory_order_relaxed) == 0) {

@@ -192,7 +192,8 @@ void ring_adapt_split(pbsgpu_ring *r) {
     r->st.sha_cus = r->sha_cus;
 }
 
-int ring_start_service(pbsgpu_ring *r) {
+// (`force`: quiesce / destroy — the caller is about to wait for the queue to drain, a service must run now)
+int ring_start_service(pbsgpu_ring *r, bool force = false) {
     if (r->svc == SvcState::Running) return PBSGPU_OK;
     if (r->svc == SvcState::Stopping && r->parked_for_flush) {
         // parked because memory waits in the device's graveyard for the services to END: a new launch queued right behind
@@ -201,6 +202,19 @@ int ring_start_service(pbsgpu_ring *r) {
         HIPCHK(hipStreamSynchronize(r->ss));
         ring_service_ended(r);
     }
+    if (r->svc == SvcState::Stopped && !force && service_park_generation(r->eng->device) != 0) {
+        // The park request is STILL pending: other rings of the device (the stream writer's engine ring beside a bulk ring,
+        // two engines) have not let go of their services yet. Starting ours now would put the device's service count back
+        // before theirs has dropped — with several busy rings the count then never reaches zero, nothing is ever freed and
+        // every ring pays its restart stall for nothing (round 5's cap only worked with ONE ring per device). Stay stopped:
+        // rounds are still cut (like the cut-ahead of a lone stream), the next pump asks again, and the last ring to end
+        // flushes. Bounded: a ring that is never called again (its service then stops by its idle timeout, but nobody
+        // observes the end) must not hold the others up for good.
+        const double t = now_ms();
+        if (r->park_wait_t0 == 0) r->park_wait_t0 = t;
+        if (t - r->park_wait_t0 < 400.0) return PBSGPU_OK;
+    }
+    r->park_wait_t0 = 0;
     if (r->svc == SvcState::Stopping) {
         // parked, its end not yet observed: the new service goes behind the old one's END and a reset (its lanes may hold
         // claims beyond the tail that the reset hands out again) — all on the device, nobody waits here
@@ -440,9 +454,8 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     if (!defer) {
         const int st = ring_start_service(r);
         if (st != PBSGPU_OK) return fail(st);
-    } else {
-        r->deferred_bytes += new_bytes;
     }
+    if (r->svc == SvcState::Stopped) r->deferred_bytes += new_bytes;  // cut ahead of the service (or the start waits for a graveyard flush)
     if (r->svc == SvcState::Stopped) rr.scan_blocks = (uint32_t)std::max(1, e->num_cus);  // nobody else on the chip: full width
     else if (r->ps && rr.scan_blocks > 8) rr.scan_blocks -= 1;  // (one CU stays free for the control kernel that runs beside the scan)
     hipStream_t scan_st = r->ps ? r->ps : r->cs;
@@ -913,7 +926,7 @@ int pbsgpu_ring_quiesce(pbsgpu_ring *r) {
         // rounds were cut AHEAD of the service (a lone bulk stream on an idle ring: ring_enqueue_round): their chunks sit in
         // the queue with no service to hash them. "Everything enqueued is hashed" needs one: start it, then stop it behind
         // what is published, like a running one (round 5; before that fill -> pump -> quiesce -> poll saw no records)
-        CHK(ring_start_service(r));
+        CHK(ring_start_service(r, true));
     }
     if (r->svc == SvcState::Running) {
         CHK(ring_service_check(r, false));  // (it may have stopped on its own in the meantime)

@@ -127,6 +127,7 @@ struct pbsgpu_ring {
     double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
     double idle_since_ms = 0;
     uint32_t park_gen_seen = 0;           // last graveyard park request this ring honoured (engine_internal.h: dev_free)
+    double park_wait_t0 = 0;              // since when a start has been waiting for the other rings of the device to let go (ring_start_service)
     bool parked_for_flush = false;        // ... and its service was parked for it: the next start waits for that service's END
     bool defer_service = false;           // PBSGPU_RING_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
     double lone_defer_ms = 25.0;          // a lone bulk stream's rounds are cut ahead of the service start for at most this long (0 = off)
