@@ -1571,6 +1571,35 @@ struct SegmentSource {
 //   * the consumer writes the digest straight into the host-visible record cell and raises the cell's flag.
 // (RingCtl / RingSource: kernels.h)
 
+// A service lane gives a page back: the lane that brings its reference count to zero reports it to the host through the
+// FIFO in mapped pinned memory (release order: every load this lane issued from the page has completed).
+__device__ __forceinline__ void ring_release_page(const RingSource &src, const uint32_t pi) {
+    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == 1u) {
+        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
+        __hip_atomic_store(&src.free_fifo[fs & src.free_mask], ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// A lane's walk over the pages of its chunk (RingSource only; plain words, not a struct: the producers keep them in VGPRs).
+// `base` is virtual: the byte at chunk offset `off` lives at base + off while off < wend; at a crossing the next page id comes
+// from the chunk's descriptor (one dependent load every page_bytes / 64 steps of a lane).
+#define PBS_RING_WALK_STATE                                                                                        \
+    [[maybe_unused]] const uint32_t *wids = nullptr; /* the descriptor's page list */                              \
+    [[maybe_unused]] uint32_t wend = 0;              /* chunk offset at which the current page ends */             \
+    [[maybe_unused]] uint32_t wcur = 0xffffffffu;    /* current physical page */                                   \
+    [[maybe_unused]] uint32_t wpgi = 0, wnpg = 0;    /* next entry of the list, entries */
+// take a chunk: d = its descriptor in the queue, e0 / e1 = the descriptor's first two quads (already loaded), tk = this lane takes it
+#define PBS_RING_WALK_TAKE(tk, d, e0, e1)                                                                                    \
+    base = (tk) ? src.arena + (uint64_t)(e1).x * src.stride + 128u + (e0).x : base;                                         \
+    len = (tk) ? (uint64_t)(e0).y : len;                                                                                     \
+    dst = (tk) ? src.cells + (uint64_t)(e0).z * 64u + 8u : dst;                                                              \
+    wids = (tk) ? reinterpret_cast<const uint32_t *>((d) + 1) : wids;                                                        \
+    wend = (tk) ? src.page_bytes - (e0).x : wend;                                                                            \
+    wcur = (tk) ? (e1).x : wcur;                                                                                             \
+    wpgi = (tk) ? 1u : wpgi;                                                                                                 \
+    wnpg = (tk) ? (e0).w : wnpg;
+
 // Each lane streams one byte range through SHA-256. Per loop trip every busy lane consumes
 // one 64-byte block: the raw dwords of the NEXT block are requested before the current
 // block is compressed, so the HBM/L2 latency of a lane's private stream hides behind the
@@ -1739,10 +1768,9 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         uint64_t len = 0, blk = 0, nblk = 0;  // blk = next block to fetch
         uint8_t *dst = nullptr;
         bool have = false, exhausted = false;
-        // ring service only: second piece of a chunk that crosses into another physical page (virtual base: the byte at
-        // chunk offset `off >= len1` lives at base2 + off), the chunk's page references, the lane's claimed queue position
-        [[maybe_unused]] const uint8_t *base2 = nullptr;
-        [[maybe_unused]] uint32_t len1 = 0, pages = 0xffffffffu, claim = 0;
+        // ring service only: the lane's walk over the pages of its chunk, the lane's claimed queue position
+        PBS_RING_WALK_STATE
+        [[maybe_unused]] uint32_t claim = 0;
         [[maybe_unused]] uint32_t claimed = 0;  // (a word, not a bool: two bool flags set in sibling branches get their stores
                                                 // merged through a selected pointer by the optimiser, which puts both in scratch)
         [[maybe_unused]] unsigned long long idle_since = 0;
@@ -1753,7 +1781,9 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         uint32_t R[D][17];
         uint32_t selv[D], cflag[D];
         uint8_t *dstv[D];
-        [[maybe_unused]] uint32_t pagesv[D];
+        // ring service: pages this slot's block lets go of when it is CONSUMED (every earlier load has completed by then):
+        // relv = the page the lane left with this block, pagesv / extrav = the chunk's last page(s) behind its last block
+        [[maybe_unused]] uint32_t pagesv[D], relv[D], extrav[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
 #pragma unroll
@@ -1761,7 +1791,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             selv[s] = 0x00010203u;
             cflag[s] = 0;
             dstv[s] = nullptr;
-            pagesv[s] = 0xffffffffu;
+            pagesv[s] = relv[s] = extrav[s] = 0xffffffffu;
         }
 
         // Dense form: a wave RESERVES kReserve extra queue positions with every atomic and serves its lanes from that
@@ -1813,18 +1843,14 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                             const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
                             const bool tk = elig && rank < cnt;
                             uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+                            const uint4 *dl = src.ldesc + (uint64_t)((got0 + rank) & src.lmask) * (kRingDescWords / 4u);
                             if (tk) {
-                                e0 = src.ldesc[2u * ((got0 + rank) & src.lmask)];
-                                e1 = src.ldesc[2u * ((got0 + rank) & src.lmask) + 1u];
+                                e0 = dl[0];
+                                e1 = dl[1];
                             }
-                            base = tk ? reinterpret_cast<const uint8_t *>(((uint64_t)e0.y << 32) | e0.x) : base;
-                            base2 = tk ? reinterpret_cast<const uint8_t *>(((uint64_t)e1.y << 32) | e1.x) : base2;
-                            len = tk ? (uint64_t)e0.z : len;
-                            len1 = tk ? e0.w : len1;
-                            dst = tk ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
-                            pages = tk ? e1.w : pages;
+                            PBS_RING_WALK_TAKE(tk, dl, e0, e1)
                             blk = tk ? 0ull : blk;
-                            nblk = tk ? ((uint64_t)e0.z + 8u) / 64u + 1u : nblk;
+                            nblk = tk ? ((uint64_t)e0.y + 8u) / 64u + 1u : nblk;
                             have = have | tk;
                             need = need && !tk;
                         }
@@ -1861,23 +1887,19 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 const bool ready = need && claimed != 0u && (int32_t)(tail - claim) > 0;
                 if (__ballot(ready)) __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+                const uint4 *dm = src.desc + (uint64_t)(claim & src.qmask) * (kRingDescWords / 4u);
                 if (ready) {
-                    d0 = src.desc[2u * (claim & src.qmask)];
-                    d1 = src.desc[2u * (claim & src.qmask) + 1u];
+                    d0 = dm[0];
+                    d1 = dm[1];
                 }
                 // size 0 = a void position (the open chunk of a round): the lane takes another one next time.
                 // (selects and or-updates, no conditional stores: two flags set in sibling branches get their stores merged
                 // through a selected pointer by the optimiser, which moves both flags into scratch memory)
-                const bool got = ready && d0.z != 0u;
+                const bool got = ready && d0.y != 0u;
                 claimed = ready ? 0u : claimed;
-                base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)d0.y << 32) | d0.x) : base;
-                base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)d1.y << 32) | d1.x) : base2;
-                len = got ? (uint64_t)d0.z : len;
-                len1 = got ? d0.w : len1;
-                dst = got ? src.cells + (uint64_t)d1.z * 64u + 8u : dst;
-                pages = got ? d1.w : pages;
+                PBS_RING_WALK_TAKE(got, dm, d0, d1)
                 blk = got ? 0ull : blk;
-                nblk = got ? ((uint64_t)d0.z + 8u) / 64u + 1u : nblk;
+                nblk = got ? ((uint64_t)d0.y + 8u) / 64u + 1u : nblk;
                 have = have | got;
                 // stop: nothing will ever be published at this position. (stop is raised behind the last publish of BOTH queues;
                 // the long queue is looked at again after the fence, so a lane never leaves while long chunks are unclaimed)
@@ -1938,8 +1960,22 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             uint32_t c = 0;
             if (have) {
                 const uint64_t off = blk * 64;
+                [[maybe_unused]] uint32_t rel = 0xffffffffu, extra = 0xffffffffu;
+                if constexpr (Source::kRing) {
+                    // the block starts behind the current page (and the chunk still has bytes there): on to the chunk's next
+                    // page; the page left is given back when THIS block is consumed. (A block that starts in front of the
+                    // boundary reads on into the page's tail pad, which mirrors the next page's first 128 bytes.)
+                    if ((uint32_t)off >= wend && off < len) {
+                        rel = wcur;
+                        wcur = wids[wpgi];
+                        ++wpgi;
+                        base = src.arena + (uint64_t)wcur * src.stride + 128u - wend;
+                        wend += src.page_bytes;
+                    }
+                    // the chunk's last block: a last page that holds fewer than 64 bytes of the chunk is never entered
+                    if (blk + 1 == nblk && wpgi < wnpg) extra = wids[wpgi];
+                }
                 const uint8_t *bb = base;
-                if constexpr (Source::kRing) bb = (off < len1) ? base : base2;  // which physical page holds this block
                 if (off + 64 <= len) {  // pure data block: 4-byte aligned vector loads + funnel selector
                     const uint8_t *p = bb + off;
                     const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
@@ -1957,7 +1993,11 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
                 dstv[s] = dst;
-                if constexpr (Source::kRing) pagesv[s] = pages;
+                if constexpr (Source::kRing) {
+                    pagesv[s] = wcur;
+                    relv[s] = rel;
+                    extrav[s] = extra;
+                }
                 if (++blk == nblk) have = false;
             }
             cflag[s] = c;
@@ -1979,27 +2019,16 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     const uint32_t c = cflag[s];
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
-                        // The chunk's LAST block has arrived in registers: nothing of the chunk will be read from HBM
-                        // again. Drop its page references (release: all earlier loads of this lane have completed);
-                        // whoever brings a page to zero hands it back to the host, which may refill it at once.
-                        // (Round 4 tried letting go of a two-page chunk's FIRST page as soon as its last block there was
-                        // in: no gain — a max-size chunk lives almost entirely in ONE 16.2 MiB page, which it holds for
-                        // its whole 0.46 s either way; configs[2] through the ring 412 vs 422 GiB/s. Removed again.)
-                        if (c & 2u) {
-                            const uint32_t pg = pagesv[s];
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
-                                if (pi != 0xffffu) {
-                                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
-                                                                                __HIP_MEMORY_SCOPE_AGENT);
-                                    if (old == 1u) {
-                                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
-                                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask],
-                                                           ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_SYSTEM);
-                                    }
-                                }
+                        // Progressive release (round 6): the block that took the lane into a NEW page is being expanded — every
+                        // load from the page it left has completed (loads return in order), so that page's reference goes
+                        // now; behind the chunk's LAST block the page it ends in (and a last page the lane never had to
+                        // enter). Whoever brings a page to zero hands it back to the host, which may refill it at once. A
+                        // page's residency is the time the hash needs to pass it, not the chain of the longest chunk on it.
+                        if (c & 1u) {
+                            if (relv[s] != 0xffffffffu) ring_release_page(src, relv[s]);
+                            if (c & 2u) {
+                                ring_release_page(src, pagesv[s]);
+                                if (extrav[s] != 0xffffffffu) ring_release_page(src, extrav[s]);
                             }
                         }
                     }
@@ -2263,15 +2292,18 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
         uint64_t len = 0, blk = 0, nblk = 0;  // blk = the lane's next block (A: even blocks, B: odd blocks)
         uint8_t *dst = nullptr;
         bool have = false, exhausted = false;
-        [[maybe_unused]] const uint8_t *base2 = nullptr;
-        [[maybe_unused]] uint32_t len1 = 0, pages = 0xffffffffu;
+        PBS_RING_WALK_STATE
         [[maybe_unused]] unsigned long long idle_since = 0;
         [[maybe_unused]] uint32_t poll_ctr = 0;
         constexpr int D = 2;
         uint32_t R[D][17];
         uint32_t selv[D], cflag[D];
         uint8_t *dstv[D];
-        [[maybe_unused]] uint32_t pagesv[D];
+        // ring service: pages given back when this slot's block is consumed — by the pair's A lane only (both lanes walk the
+        // chunk's pages for their own blocks; A's blocks are the even ones, so when A has left a page every block of the chunk
+        // in it — B's are one behind — has been loaded): relv = the page A left with this block; pagesv / extrav = the page(s)
+        // the chunk ends in, behind A's last block (B's last block, if it comes later, is consumed in the same step)
+        [[maybe_unused]] uint32_t pagesv[D], relv[D], extrav[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
 #pragma unroll
@@ -2279,7 +2311,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
             selv[s] = 0x00010203u;
             cflag[s] = 0;
             dstv[s] = nullptr;
-            pagesv[s] = 0xffffffffu;
+            pagesv[s] = relv[s] = extrav[s] = 0xffffffffu;
         }
         // `need`: this A lane's PAIR has issued every block of its chunk and wants the next one (B lanes never ask)
         auto acquire = [&](bool need) {
@@ -2304,16 +2336,12 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
                         got = need && rank < cnt;
                         uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+                        const uint4 *dl = src.ldesc + (uint64_t)((got0 + rank) & src.lmask) * (kRingDescWords / 4u);
                         if (got) {
-                            e0 = src.ldesc[2u * ((got0 + rank) & src.lmask)];
-                            e1 = src.ldesc[2u * ((got0 + rank) & src.lmask) + 1u];
+                            e0 = dl[0];
+                            e1 = dl[1];
                         }
-                        base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e0.y << 32) | e0.x) : base;
-                        base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e1.y << 32) | e1.x) : base2;
-                        len = got ? (uint64_t)e0.z : len;
-                        len1 = got ? e0.w : len1;
-                        dst = got ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
-                        pages = got ? e1.w : pages;
+                        PBS_RING_WALK_TAKE(got, dl, e0, e1)
                         if (lane == leader) atomicAdd(&src.ctl->xp_busy, cnt);  // (given back when the chunk's last block is in)
                     }
                 } else {
@@ -2355,14 +2383,17 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     len = ln;
                     dst = reinterpret_cast<uint8_t *>(ds);
                 }
-                if constexpr (Source::kRing) {
-                    const uint64_t b2 = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(base2), srcl, 64);
-                    const uint32_t l1 = (uint32_t)__shfl((int)len1, srcl, 64);
-                    const uint32_t pg = (uint32_t)__shfl((int)pages, srcl, 64);
+                if constexpr (Source::kRing) {  // the B lane walks the same page list for its own (odd) blocks
+                    const uint64_t wi = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(wids), srcl, 64);
+                    const uint32_t we = (uint32_t)__shfl((int)wend, srcl, 64);
+                    const uint32_t wc = (uint32_t)__shfl((int)wcur, srcl, 64);
+                    const uint32_t wn = (uint32_t)__shfl((int)wnpg, srcl, 64);
                     if (pgot) {
-                        base2 = reinterpret_cast<const uint8_t *>(b2);
-                        len1 = l1;
-                        pages = pg;
+                        wids = reinterpret_cast<const uint32_t *>(wi);
+                        wend = we;
+                        wcur = wc;
+                        wpgi = 1u;
+                        wnpg = wn;
                     }
                 }
                 if (pgot) {
@@ -2379,8 +2410,22 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
             uint32_t c = 0;
             if (have) {
                 const uint64_t off = blk * 64;
+                [[maybe_unused]] uint32_t rel = 0xffffffffu, extra = 0xffffffffu, fin = 0xffffffffu;
+                if constexpr (Source::kRing) {
+                    if ((uint32_t)off >= wend && off < len) {  // on to the chunk's next page (see the pair form)
+                        rel = wcur;
+                        wcur = wids[wpgi];
+                        ++wpgi;
+                        base = src.arena + (uint64_t)wcur * src.stride + 128u - wend;
+                        wend += src.page_bytes;
+                    }
+                    if (!roleB && blk + 2 >= nblk) {  // A's last block: the chunk ends in this step
+                        fin = wcur;
+                        if (wpgi < wnpg) extra = wids[wpgi];
+                    }
+                    if (roleB) rel = 0xffffffffu;
+                }
                 const uint8_t *bb = base;
-                if constexpr (Source::kRing) bb = (off < len1) ? base : base2;
                 if (off + 64 <= len) {
                     const uint8_t *p = bb + off;
                     const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
@@ -2398,7 +2443,11 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
                 dstv[s] = dst;
-                if constexpr (Source::kRing) pagesv[s] = pages;
+                if constexpr (Source::kRing) {
+                    pagesv[s] = fin;
+                    relv[s] = rel;
+                    extrav[s] = extra;
+                }
                 blk += 2;
                 if (blk >= nblk) have = false;
             }
@@ -2423,27 +2472,16 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
                         // the chunk's LAST block is in registers (the partner's blocks of this step and all earlier ones
-                        // too: same load instructions, same wait): the pair is free for the service's accounting, and the
-                        // chunk's page references are dropped, as the pair form does
+                        // too: same load instructions, same wait): the pair is free for the service's accounting
                         {
                             const unsigned long long mdone = __ballot((c & 2u) != 0u);
                             if (mdone && lane == (__ffsll((long long)mdone) - 1)) atomicSub(&src.ctl->xp_busy, (uint32_t)__popcll(mdone));
                         }
-                        if (c & 2u) {
-                            const uint32_t pg = pagesv[s];
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
-                                if (pi != 0xffffu) {
-                                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
-                                                                                __HIP_MEMORY_SCOPE_AGENT);
-                                    if (old == 1u) {
-                                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
-                                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask],
-                                                           ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_SYSTEM);
-                                    }
-                                }
+                        if (c & 1u) {  // progressive release, by the A lane (see pagesv above)
+                            if (relv[s] != 0xffffffffu) ring_release_page(src, relv[s]);
+                            if (pagesv[s] != 0xffffffffu) {
+                                ring_release_page(src, pagesv[s]);
+                                if (extrav[s] != 0xffffffffu) ring_release_page(src, extrav[s]);
                             }
                         }
                     }
