@@ -643,6 +643,28 @@ def _copy_args(a, **kw):
     return b
 
 
+def regime_block(ring, p0, p_fed, p1, p2, pair_cus, xp_cus):
+    """roofline.regime: ns per block step of the chains under load and the shader clock they ran at, per phase of the line."""
+    try:
+        D = type(ring).probe_delta
+        out = {"feed_phase": D(p0, p_fed) if p_fed else None, "drain": D(p_fed, p1) if p_fed else None,
+               "timed_region": D(p0, p1), "single_file": D(p1, p2)}
+        pr = (out["timed_region"] or {}).get("pair")
+        if pr:   # a pair-service CU carries 128 chains: 128 x 64 B per block step
+            out["pair_GiBps_per_cu"] = round(128 * 64 / pr["ns_per_block_step"] * 1e9 / GiB, 3)
+            out["pair_cu_ms_per_GiB"] = round(1e3 / out["pair_GiBps_per_cu"], 1)
+        xp = (out["timed_region"] or {}).get("express")
+        if xp:   # an express CU carries 64 chunks on lane pairs
+            out["express_GiBps_per_cu"] = round(64 * 64 / xp["ns_per_block_step"] * 1e9 / GiB, 3)
+        out["note"] = ("ns_per_block_step: wall time per 64-byte block of one chain, averaged over every service wave that was busy "
+                       "throughout a 4096-step interval (pair form floor 1.655-1.75 us alone on an idle chip; express 1.28); "
+                       "sclk_mhz: shader cycles / wall time of the same intervals. A 'slow' box shows up HERE: a lower sclk_mhz "
+                       "or the same clock with more ns per step (see DESIGN.md 6.3 / profiles/r06_slow_regime.log)")
+        return out
+    except Exception as exc:   # (a probe must never take the line down)
+        return {"error": repr(exc)}
+
+
 def extras(a, rank, local_rank, world, ctx, with_batch=False):
     """Short legs of the other BASELINE.json configs and of the host-fed path, folded into the DEFAULT line so that the
     driver's clock sees them too (each at its full single-GPU shape, a few steps, its own oracle check). A leg that fails
@@ -845,6 +867,7 @@ def ring_run(a, rank, local_rank, world, ctx):
             if (opened == nfiles and "t_fed" not in marks and not any(st[1] for st in active.values())
                     and ring.stats()["bytes_enqueued"] >= enq0 + nfiles * file_bytes):
                 marks["t_fed"] = time.perf_counter()     # every byte of the last file is in a cut round
+                marks["probe_fed"] = ring.probe()
                 if os.environ.get("PBS_BENCH_RING_TRACE"):   # queue state at the end of the feed phase (diagnostic)
                     marks["fed_state"] = (ring.debug().splitlines()[0], ring.stats())
             for sid in list(active):
@@ -889,9 +912,11 @@ def ring_run(a, rank, local_rank, world, ctx):
     torch.cuda.synchronize()
     state["timed"], state["first_timed"] = True, state["next_file"]
     st0 = ring.stats()
+    probe0 = ring.probe()
     t0 = time.perf_counter()
     kept = run_files(a.steps, True)
     t_fed = marks.get("t_fed", None)
+    probe_fed = marks.get("probe_fed", None)
     if "fed_state" in marks and rank == 0:
         print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
               "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)
@@ -901,6 +926,7 @@ def ring_run(a, rank, local_rank, world, ctx):
         ctx.dist.barrier()
     elapsed = time.perf_counter() - t0
     st1 = ring.stats()
+    probe1 = ring.probe()
     total_bytes = float(a.steps) * file_bytes
     if ctx.dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.comm_dev)
@@ -922,6 +948,7 @@ def ring_run(a, rank, local_rank, world, ctx):
     single_fed_s = marks.get("t_fed", ts0) - ts0     # every byte of the file in a cut round (then: the chains of its last chunks)
     ring.quiesce()
     single_s = time.perf_counter() - ts0
+    probe2 = ring.probe()
     state["S"] = s_saved
     out = None
     if rank == 0:
@@ -980,11 +1007,14 @@ def ring_run(a, rank, local_rank, world, ctx):
                 "path": {"achieved": round(gbs, 1), "frac_of_valu_peak": round(gbs / SHA_VALU_GBS, 4),
                          "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                          "note": "whole timed region incl. ramp-up from an idle ring and the drain of the last chunks"},
+                # which regime did THIS run land in? (pbsgpu_ring_get_probe: every service wave samples the shader clock and the
+                # wall clock once per 4096 block steps; only intervals in which the wave carried a block in every step count)
+                "regime": regime_block(ring, probe0, probe_fed, probe1, probe2, int(st1["sha_cus"]), ring.express()[0]),
                 "cu_time_budget": {"service_cu_ms_per_GiB": 233, "scan_cu_ms_per_GiB": 50, "refill_cu_ms_per_GiB": 28,
-                                   "chip_ceiling_GiBps": 823,
-                                   "note": "kernel traces of this command (profiles/r05_kernel_trace_bench_default*.csv.gz, "
-                                           "scripts/r5_trace_regimes.py): 311 CU-ms per GiB over the three kernels -> 256 CUs / 311 = "
-                                           "823 GiB/s however the CUs are split; the feed phase runs at ~0.93 of it (refill: bench only)"},
+                                   "chip_ceiling_GiBps": 823, "source": "static: profiles/r05_kernel_trace_bench_default*.csv.gz "
+                                   "(round 5, one box), NOT measured in this run — this run's service figure is regime.pair_cu_ms_per_GiB",
+                                   "note": "311 CU-ms per GiB over the three kernels -> 256 CUs / 311 = 823 GiB/s however the CUs "
+                                           "are split; the feed phase runs at ~0.93 of it (refill: bench only)"},
                 "traffic": None if tr is None else int(tr["ratio"] * svc_bytes),
                 "traffic_note": None if tr is None else tr["note"],
                 "algorithmic_bytes_per_launch": int(svc_bytes),

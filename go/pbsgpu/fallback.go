@@ -56,6 +56,10 @@ type (
 		PagesTotal, PagesFree, Rounds    uint32
 		ServiceMsLast                    float64
 	}
+	RingProbe struct {
+		PairSteps, PairCycles, PairTicks          uint64
+		ExpressSteps, ExpressCycles, ExpressTicks uint64
+	}
 )
 
 func NewConfig(int) (Config, error)               { return Config{}, ErrNotBuilt }
@@ -122,4 +126,5 @@ func (r *Ring) Park() error                                                     
 func (r *Ring) Suggest(uint32, uint64) error                                     { return ErrNotBuilt }
 func (r *Ring) Stats() (RingStats, error)                                        { return RingStats{}, ErrNotBuilt }
 func (r *Ring) Express() (uint32, uint64, error)                                 { return 0, 0, ErrNotBuilt }
+func (r *Ring) Probe() (RingProbe, error)                                        { return RingProbe{}, ErrNotBuilt }
 func (r *Ring) Close()                                                           {}

@@ -807,6 +807,24 @@ func (r *Ring) Express() (cus uint32, longBytes uint64, err error) {
 	return uint32(c), uint64(l), nil
 }
 
+// RingProbe: cumulative regime counters of the ring's two SHA-256 services (pbsgpu_ring_get_probe). Ticks / Steps x 10 = ns
+// per block step of a chain under load (an express step is two blocks), Cycles / Ticks x 100 = the shader clock in MHz.
+type RingProbe struct {
+	PairSteps, PairCycles, PairTicks          uint64
+	ExpressSteps, ExpressCycles, ExpressTicks uint64
+}
+
+// Probe reads the counters (safe while the service runs); read twice and subtract to look at a phase.
+func (r *Ring) Probe() (RingProbe, error) {
+	defer runtime.KeepAlive(r)
+	var p C.pbsgpu_ring_probe
+	if err := check(C.pbsgpu_ring_get_probe(r.h, &p), "ring_get_probe"); err != nil {
+		return RingProbe{}, err
+	}
+	return RingProbe{uint64(p.pair_steps), uint64(p.pair_cycles), uint64(p.pair_ticks), uint64(p.express_steps),
+		uint64(p.express_cycles), uint64(p.express_ticks)}, nil
+}
+
 func (r *Ring) Close() {
 	runtime.SetFinalizer(r, nil)
 	if r.h != nil {

@@ -431,6 +431,13 @@ class PageRing {
         return r;
     }
 
+    // cumulative regime counters of the two services (ns per block step under load, shader clock): pbsgpu_ring_get_probe
+    pbsgpu_ring_probe Probe() const {
+        pbsgpu_ring_probe p{};
+        (void)pbsgpu_ring_get_probe(r_, &p);
+        return p;
+    }
+
   private:
     PageRing(std::shared_ptr<Engine> eng, pbsgpu_ring *r, Sink sink) : eng_(std::move(eng)), r_(r), sink_(std::move(sink)) {}
     PageRing(const PageRing &) = delete;

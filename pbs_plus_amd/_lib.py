@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpbsgpu.so")
+LIB_PATH = os.environ.get("PBSGPU_LIB_PATH") or os.path.join(_HERE, "lib", "libpbsgpu.so")   # (override: A/B builds, scripts/)
 CSRC = os.path.join(_HERE, "csrc")
 
 OK = 0
@@ -96,6 +96,11 @@ class RingStats(C.Structure):
                [("service_ms_last", C.c_double), ("service_ms_total", C.c_double)]
 
 
+class RingProbe(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("pair_steps", "pair_cycles", "pair_ticks", "express_steps", "express_cycles",
+                                          "express_ticks")]
+
+
 class DedupStats(C.Structure):
     _fields_ = [
         ("nrecords", C.c_uint64),
@@ -175,6 +180,7 @@ SYMBOLS = {
     "pbsgpu_ring_get_stats": (C.c_int, [_P, C.POINTER(RingStats)]),
     "pbsgpu_ring_debug": (C.c_int, [_P, C.c_char_p, C.c_uint64]),
     "pbsgpu_ring_express": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "pbsgpu_ring_get_probe": (C.c_int, [_P, C.POINTER(RingProbe)]),
     "pbsgpu_sha256_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_sha256_many_host": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),
     "pbsgpu_xxh3_many_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint32, _P]),

@@ -229,6 +229,11 @@ struct RingSource {
     uint32_t qmask;            // positions - 1 (power of two)
     const uint8_t *arena;      // page p's body starts at arena + p * stride + 128
     uint32_t stride, page_bytes;
+    // Which regime did a run land in? Every producer wave of a service samples clock64() (shader clock) and wall_clock64()
+    // (100 MHz) once per kRingProbeSteps block steps and, if it carried a block in EVERY step of the interval, adds
+    // {steps, shader cycles, wall ticks} to these device counters (3 x u64 per service: pair [0..2], express [3..5]):
+    // ns per block step of a chain under load and the shader clock it ran at, over all busy waves (pbsgpu_ring_probe).
+    unsigned long long *probe;
     // Chunks of at least `long_bytes` go through a second, smaller queue that idle lanes look at FIRST: a max-size chunk
     // hashes for ~0.45 s on one lane, so the later it starts the longer the ring's drain (bench: the last such chunk used
     // to start behind ~0.3 s of queued short chunks). Lanes never wait on this queue (compare-and-swap on lhead only
@@ -264,6 +269,7 @@ struct RingSource {
     uint32_t long_lo;
 };
 constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHbRoundsEnq = 33;
+constexpr uint32_t kRingProbeSteps = 4096;  // block steps between two samples of a service wave (~7 ms)
 
 
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)

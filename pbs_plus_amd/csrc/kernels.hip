@@ -1581,24 +1581,67 @@ __device__ __forceinline__ void ring_release_page(const RingSource &src, const u
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// the services' regime probe (RingSource::probe): called once per block step by a producer wave, wave-uniform
+struct RingProbe {
+    uint32_t n = 0, idle = 0;
+    unsigned long long c0 = 0, w0 = 0;
+};
+__device__ __forceinline__ void ring_probe_step(const RingSource &src, RingProbe &pb, const bool busy, const int slot, const int lane) {
+#ifdef PBS_NO_PROBE
+    return;
+#endif
+    pb.idle |= busy ? 0u : 1u;
+    if (++pb.n < kRingProbeSteps) return;
+    const unsigned long long c = clock64(), w = wall_clock64();
+    if (!pb.idle && pb.w0 != 0ull && lane == 0 && src.probe) {
+        atomicAdd(src.probe + slot, (unsigned long long)kRingProbeSteps);
+        atomicAdd(src.probe + slot + 1, c - pb.c0);
+        atomicAdd(src.probe + slot + 2, w - pb.w0);
+    }
+    pb.n = 0;
+    pb.idle = 0;
+    pb.c0 = c;
+    pb.w0 = w;
+}
 // A lane's walk over the pages of its chunk (RingSource only; plain words, not a struct: the producers keep them in VGPRs).
-// `base` is virtual: the byte at chunk offset `off` lives at base + off while off < wend; at a crossing the next page id comes
-// from the chunk's descriptor (one dependent load every page_bytes / 64 steps of a lane).
+// `base` is virtual: the byte at chunk offset `off` lives at base + off while off < wend. The chunk's page list travels in
+// REGISTERS (wcur + a shift register of the up to 11 pages behind it, filled from the descriptor when the lane takes the
+// chunk): a crossing is a handful of moves. A first version fetched the next page id from the descriptor AT the crossing —
+// a load inside a branch in front of the block loads, and the waitcnt bookkeeping then waited for EVERY outstanding load in
+// every step: the loaded chain went from 1.87 to 2.02 us per block, the driver's line from 620 to 589 GiB/s on the same box
+// (profiles/r06_ab_walk_load_in_branch.log). No load may sit behind a branch on the producer's path.
+#ifndef PBS_WALK_N
+#define PBS_WALK_N 11
+#endif
 #define PBS_RING_WALK_STATE                                                                                        \
-    [[maybe_unused]] const uint32_t *wids = nullptr; /* the descriptor's page list */                              \
+    [[maybe_unused]] uint32_t wq[PBS_WALK_N];        /* the chunk's pages behind the current one, next first */    \
     [[maybe_unused]] uint32_t wend = 0;              /* chunk offset at which the current page ends */             \
     [[maybe_unused]] uint32_t wcur = 0xffffffffu;    /* current physical page */                                   \
-    [[maybe_unused]] uint32_t wpgi = 0, wnpg = 0;    /* next entry of the list, entries */
-// take a chunk: d = its descriptor in the queue, e0 / e1 = the descriptor's first two quads (already loaded), tk = this lane takes it
-#define PBS_RING_WALK_TAKE(tk, d, e0, e1)                                                                                    \
+    [[maybe_unused]] uint32_t wleft = 0;             /* pages behind the current one */                            \
+    _Pragma("unroll") for (int wi_ = 0; wi_ < PBS_WALK_N; ++wi_) wq[wi_] = 0xffffffffu;
+// take a chunk: e0..e3 = its descriptor (already loaded), tk = this lane takes it
+#define PBS_RING_WALK_TAKE(tk, e0, e1, e2, e3)                                                                               \
     base = (tk) ? src.arena + (uint64_t)(e1).x * src.stride + 128u + (e0).x : base;                                         \
     len = (tk) ? (uint64_t)(e0).y : len;                                                                                     \
     dst = (tk) ? src.cells + (uint64_t)(e0).z * 64u + 8u : dst;                                                              \
-    wids = (tk) ? reinterpret_cast<const uint32_t *>((d) + 1) : wids;                                                        \
     wend = (tk) ? src.page_bytes - (e0).x : wend;                                                                            \
     wcur = (tk) ? (e1).x : wcur;                                                                                             \
-    wpgi = (tk) ? 1u : wpgi;                                                                                                 \
-    wnpg = (tk) ? (e0).w : wnpg;
+    wleft = (tk) ? (e0).w - 1u : wleft;                                                                                      \
+    {                                                                                                                        \
+        const uint32_t ids_[11] = {(e1).y, (e1).z, (e1).w, (e2).x, (e2).y, (e2).z, (e2).w, (e3).x, (e3).y, (e3).z, (e3).w};   \
+        _Pragma("unroll") for (int wi_ = 0; wi_ < PBS_WALK_N; ++wi_) wq[wi_] = (tk) ? ids_[wi_] : wq[wi_];                   \
+    }
+// the block at chunk offset `off` starts behind the current page (and the chunk still has bytes there): on to the next page;
+// `rel` = the page left (given back when this block is CONSUMED)
+#define PBS_RING_WALK_CROSS(off, rel)                                                                \
+    if ((uint32_t)(off) >= wend && (off) < len) {                                                    \
+        rel = wcur;                                                                                  \
+        wcur = wq[0];                                                                                \
+        _Pragma("unroll") for (int wi_ = 0; wi_ + 1 < PBS_WALK_N; ++wi_) wq[wi_] = wq[wi_ + 1];      \
+        --wleft;                                                                                     \
+        base = src.arena + (uint64_t)wcur * src.stride + 128u - wend;                                \
+        wend += src.page_bytes;                                                                      \
+    }
 
 // Each lane streams one byte range through SHA-256. Per loop trip every busy lane consumes
 // one 64-byte block: the raw dwords of the NEXT block are requested before the current
@@ -1842,13 +1885,15 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                             __atomic_thread_fence(__ATOMIC_ACQUIRE);
                             const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
                             const bool tk = elig && rank < cnt;
-                            uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+                            uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
                             const uint4 *dl = src.ldesc + (uint64_t)((got0 + rank) & src.lmask) * (kRingDescWords / 4u);
                             if (tk) {
                                 e0 = dl[0];
                                 e1 = dl[1];
+                                e2 = dl[2];
+                                e3 = dl[3];
                             }
-                            PBS_RING_WALK_TAKE(tk, dl, e0, e1)
+                            PBS_RING_WALK_TAKE(tk, e0, e1, e2, e3)
                             blk = tk ? 0ull : blk;
                             nblk = tk ? ((uint64_t)e0.y + 8u) / 64u + 1u : nblk;
                             have = have | tk;
@@ -1886,18 +1931,20 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 const uint32_t tail = (uint32_t)ts, stop = (uint32_t)(ts >> 32);
                 const bool ready = need && claimed != 0u && (int32_t)(tail - claim) > 0;
                 if (__ballot(ready)) __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
                 const uint4 *dm = src.desc + (uint64_t)(claim & src.qmask) * (kRingDescWords / 4u);
                 if (ready) {
                     d0 = dm[0];
                     d1 = dm[1];
+                    d2 = dm[2];
+                    d3 = dm[3];
                 }
                 // size 0 = a void position (the open chunk of a round): the lane takes another one next time.
                 // (selects and or-updates, no conditional stores: two flags set in sibling branches get their stores merged
                 // through a selected pointer by the optimiser, which moves both flags into scratch memory)
                 const bool got = ready && d0.y != 0u;
                 claimed = ready ? 0u : claimed;
-                PBS_RING_WALK_TAKE(got, dm, d0, d1)
+                PBS_RING_WALK_TAKE(got, d0, d1, d2, d3)
                 blk = got ? 0ull : blk;
                 nblk = got ? ((uint64_t)d0.y + 8u) / 64u + 1u : nblk;
                 have = have | got;
@@ -1965,15 +2012,9 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     // the block starts behind the current page (and the chunk still has bytes there): on to the chunk's next
                     // page; the page left is given back when THIS block is consumed. (A block that starts in front of the
                     // boundary reads on into the page's tail pad, which mirrors the next page's first 128 bytes.)
-                    if ((uint32_t)off >= wend && off < len) {
-                        rel = wcur;
-                        wcur = wids[wpgi];
-                        ++wpgi;
-                        base = src.arena + (uint64_t)wcur * src.stride + 128u - wend;
-                        wend += src.page_bytes;
-                    }
+                    PBS_RING_WALK_CROSS(off, rel)
                     // the chunk's last block: a last page that holds fewer than 64 bytes of the chunk is never entered
-                    if (blk + 1 == nblk && wpgi < wnpg) extra = wids[wpgi];
+                    extra = (blk + 1 == nblk && wleft != 0u) ? wq[0] : extra;
                 }
                 const uint8_t *bb = base;
                 if (off + 64 <= len) {  // pure data block: 4-byte aligned vector loads + funnel selector
@@ -2007,6 +2048,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         for (int s = 0; s < D; ++s) prep(s);
         bool running = true;
         [[maybe_unused]] bool wg_busy = false;  // some pair of this workgroup had a block in the previous step
+        [[maybe_unused]] RingProbe probe;
         while (running) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -2099,6 +2141,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                             idle_since = 0;
                         }
                         if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
+                        ring_probe_step(src, probe, any_cur, 0, lane);
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
@@ -2335,13 +2378,15 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         __atomic_thread_fence(__ATOMIC_ACQUIRE);
                         const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
                         got = need && rank < cnt;
-                        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+                        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
                         const uint4 *dl = src.ldesc + (uint64_t)((got0 + rank) & src.lmask) * (kRingDescWords / 4u);
                         if (got) {
                             e0 = dl[0];
                             e1 = dl[1];
+                            e2 = dl[2];
+                            e3 = dl[3];
                         }
-                        PBS_RING_WALK_TAKE(got, dl, e0, e1)
+                        PBS_RING_WALK_TAKE(got, e0, e1, e2, e3)
                         if (lane == leader) atomicAdd(&src.ctl->xp_busy, cnt);  // (given back when the chunk's last block is in)
                     }
                 } else {
@@ -2384,16 +2429,16 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     dst = reinterpret_cast<uint8_t *>(ds);
                 }
                 if constexpr (Source::kRing) {  // the B lane walks the same page list for its own (odd) blocks
-                    const uint64_t wi = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(wids), srcl, 64);
                     const uint32_t we = (uint32_t)__shfl((int)wend, srcl, 64);
                     const uint32_t wc = (uint32_t)__shfl((int)wcur, srcl, 64);
-                    const uint32_t wn = (uint32_t)__shfl((int)wnpg, srcl, 64);
-                    if (pgot) {
-                        wids = reinterpret_cast<const uint32_t *>(wi);
-                        wend = we;
-                        wcur = wc;
-                        wpgi = 1u;
-                        wnpg = wn;
+                    const uint32_t wl = (uint32_t)__shfl((int)wleft, srcl, 64);
+                    wend = pgot ? we : wend;
+                    wcur = pgot ? wc : wcur;
+                    wleft = pgot ? wl : wleft;
+#pragma unroll
+                    for (int j = 0; j < PBS_WALK_N; ++j) {
+                        const uint32_t v = (uint32_t)__shfl((int)wq[j], srcl, 64);
+                        wq[j] = pgot ? v : wq[j];
                     }
                 }
                 if (pgot) {
@@ -2412,18 +2457,11 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                 const uint64_t off = blk * 64;
                 [[maybe_unused]] uint32_t rel = 0xffffffffu, extra = 0xffffffffu, fin = 0xffffffffu;
                 if constexpr (Source::kRing) {
-                    if ((uint32_t)off >= wend && off < len) {  // on to the chunk's next page (see the pair form)
-                        rel = wcur;
-                        wcur = wids[wpgi];
-                        ++wpgi;
-                        base = src.arena + (uint64_t)wcur * src.stride + 128u - wend;
-                        wend += src.page_bytes;
-                    }
-                    if (!roleB && blk + 2 >= nblk) {  // A's last block: the chunk ends in this step
-                        fin = wcur;
-                        if (wpgi < wnpg) extra = wids[wpgi];
-                    }
-                    if (roleB) rel = 0xffffffffu;
+                    PBS_RING_WALK_CROSS(off, rel)  // on to the chunk's next page (see the pair form)
+                    const bool a_last = !roleB && blk + 2 >= nblk;  // A's last block: the chunk ends in this step
+                    fin = a_last ? wcur : fin;
+                    extra = (a_last && wleft != 0u) ? wq[0] : extra;
+                    rel = roleB ? 0xffffffffu : rel;
                 }
                 const uint8_t *bb = base;
                 if (off + 64 <= len) {
@@ -2460,6 +2498,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
         for (int s = 0; s < D; ++s) prep(s);
         bool running = true;
         [[maybe_unused]] bool wg_busy = false;
+        [[maybe_unused]] RingProbe probe;
         while (running) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -2509,6 +2548,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         live = any_cur || !wave_done;
                         if (!any_cur && !wave_done && !wg_busy) __builtin_amdgcn_s_sleep(48);  // (never while the sibling pair works)
                         if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
+                        ring_probe_step(src, probe, any_cur, 3, lane);  // (a step of this form = TWO blocks per chunk)
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();

@@ -533,6 +533,7 @@ pbsk::RingSource pbsgpu_ring::source() const {
     pbsk::RingSource q{};
     q.desc = desc.as<uint4>();
     q.qmask = qslots - 1;
+    q.probe = probe.as<unsigned long long>();
     q.arena = arena.as<uint8_t>();
     q.stride = (uint32_t)stride;
     q.page_bytes = (uint32_t)page_bytes;
@@ -786,6 +787,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
 
         CHK(r->arena.ensure((size_t)r->npages * r->stride + 512));
         CHK(r->ctl.ensure(256));
+        CHK(r->probe.ensure(64));
         CHK(r->streams.ensure((size_t)r->max_streams * sizeof(pbsk::RingStreamState)));
         CHK(r->pending.ensure((size_t)r->npages * 4 + 64));
         CHK(r->desc.ensure((size_t)r->qslots * pbsk::kRingDescWords * 4));
@@ -856,6 +858,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // tail, stream states and page reference counts — pages never came back, lanes waited at positions the tail had
         // been reset below (the one-in-a-few-hundred hang of the small-ring tests).
         HIPCHK(hipMemsetAsync(r->ctl.p, 0, 256, r->cs));
+        HIPCHK(hipMemsetAsync(r->probe.p, 0, 64, r->cs));
         HIPCHK(hipMemsetAsync(r->streams.p, 0, (size_t)r->max_streams * sizeof(pbsk::RingStreamState), r->cs));
         HIPCHK(hipMemsetAsync(r->pending.p, 0, (size_t)r->npages * 4 + 64, r->cs));
         HIPCHK(hipMemsetAsync(r->scalars.p, 0, pbsk::kRsCount * 4 + 64, r->cs));
@@ -991,7 +994,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
             for (auto &q : s.ready)
                 if (q.dep) r->ev_pool.push_back(q.dep);
         for (auto ev : r->ev_pool) (void)hipEventDestroy(ev);
-        for (DevBuf *b : {&r->arena, &r->ctl, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
+        for (DevBuf *b : {&r->arena, &r->ctl, &r->probe, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
                           &r->tile_slots, &r->tile_cnt2, &r->tile_slots2, &r->tileq, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
                           &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->inputs_dev})
             b->release();
@@ -1298,6 +1301,14 @@ int pbsgpu_ring_express(pbsgpu_ring *r, uint32_t *express_cus, uint64_t *long_by
     if (!r) return PBSGPU_E_INVALID;
     if (express_cus) *express_cus = r->xp_cus;
     if (long_bytes) *long_bytes = r->xp_cus ? r->long_bytes : 0;
+    return PBSGPU_OK;
+}
+
+int pbsgpu_ring_get_probe(pbsgpu_ring *r, pbsgpu_ring_probe *out) {
+    if (!r || !out) return PBSGPU_E_INVALID;
+    static_assert(sizeof(pbsgpu_ring_probe) == 48, "six counters");
+    CHK(set_device(r->eng));
+    HIPCHK(hipMemcpy(out, r->probe.p, sizeof(*out), hipMemcpyDeviceToHost));  // (null stream: not ordered against the service)
     return PBSGPU_OK;
 }
 

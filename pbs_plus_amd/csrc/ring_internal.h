@@ -87,7 +87,7 @@ struct pbsgpu_ring {
     uint64_t rec_cap = 0, dense_cap = 0;
     uint32_t qslots = 0, ncells = 0, nfree = 0;
     // device
-    pbse::DevBuf arena, ctl, streams, pending, desc, ldesc;
+    pbse::DevBuf arena, ctl, streams, pending, desc, ldesc, probe;
     uint32_t lslots = 0, long_bytes = 0;
     pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
     pbse::DevBuf tile_cnt2, tile_slots2, tileq;  // second set of the scan side (rounds alternate) + the two tile-queue counters

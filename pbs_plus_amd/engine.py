@@ -592,6 +592,23 @@ class PageRing:
         check(self._L.pbsgpu_ring_express(self._h, C.byref(cus), C.byref(lb)), "ring_express")
         return int(cus.value), int(lb.value)
 
+    def probe(self) -> dict:
+        """Cumulative regime counters of the two services (pbsgpu_ring_get_probe): steps, shader cycles, 100 MHz ticks."""
+        p = _lib.RingProbe()
+        check(self._L.pbsgpu_ring_get_probe(self._h, C.byref(p)), "ring_get_probe")
+        return {k: int(getattr(p, k)) for k, _ in _lib.RingProbe._fields_}
+
+    @staticmethod
+    def probe_delta(a: dict, b: dict) -> dict:
+        """What the services did between two probe() readings: ns per block step and shader clock, per service."""
+        out = {}
+        for svc, blocks in (("pair", 1), ("express", 2)):
+            st, cy, tk = (b[f"{svc}_{k}"] - a[f"{svc}_{k}"] for k in ("steps", "cycles", "ticks"))
+            if st and tk:
+                out[svc] = {"ns_per_block_step": round(tk * 10.0 / st / blocks, 1), "sclk_mhz": round(cy * 100.0 / tk, 1),
+                            "wave_steps_sampled": int(st)}
+        return out
+
     def debug(self) -> str:
         buf = C.create_string_buffer(1 << 16)
         check(self._L.pbsgpu_ring_debug(self._h, buf, len(buf)), "ring_debug")

@@ -226,6 +226,17 @@ class _FakeRing:
     def express(self):
         return (16, 13 << 20)
 
+    def probe(self):
+        self._pn = getattr(self, "_pn", 0) + 1
+        n = 4096 * self._pn
+        return {"pair_steps": n, "pair_cycles": n * 4000, "pair_ticks": n * 178, "express_steps": n, "express_cycles": n * 5800,
+                "express_ticks": n * 256}
+
+    @staticmethod
+    def probe_delta(a, b):
+        import pbs_plus_amd.engine as E
+        return E.PageRing.probe_delta(a, b)
+
     def close(self):
         pass
 
