@@ -71,8 +71,6 @@ def parse():
     ap.add_argument("--ring-streams", type=int, default=4, help="ring: files in flight at once")
     ap.add_argument("--ring-sha-cus", type=int, default=0, help="ring: CUs of the SHA-256 service (0 = library default)")
     ap.add_argument("--ring-round-pages", type=int, default=0)
-    ap.add_argument("--ring-page-tiles", type=int, default=0,
-                    help="ring: page size in scan tiles of 272 KiB (0 = library default: 8 = 2.125 MiB; 61 = the geometry of rounds 3-5)")
     ap.add_argument("--ring-kind", type=int, default=4, help="ring: synthetic generator (4 = cheap ARX, 0 = splitmix64)")
     ap.add_argument("--gib", type=float, default=None, help="bytes per batch in GiB (default: 64; manyfiles 128)")
     ap.add_argument("--slots", type=int, default=None, help="resident batches = batches in flight (default 4; manyfiles 2)")
@@ -812,14 +810,12 @@ def ring_run(a, rank, local_rank, world, ctx):
     file_bytes = int((64.0 if a.gib is None else a.gib) * GiB) & ~15
     arena = 0 if a.arena_gib is None else int(a.arena_gib * GiB)
     ring = pbs_plus_amd.PageRing(eng, arena_bytes=arena, max_streams=max(8, a.ring_streams) * 4, sha_cus=a.ring_sha_cus,
-                                 round_pages=a.ring_round_pages, page_bytes=a.ring_page_tiles * 64 * 34 * 128)
+                                 round_pages=a.ring_round_pages)
     state = {"S": max(1, a.ring_streams), "next_file": 0, "timed": False, "first_timed": 0, "next_reduce": 0}
     # pages a stream may take per turn: a quarter of a round with 4 files in flight (steady state is bounded by the pages that
     # come back, not by this; at the start of a region it lets the first rounds be full ones, which the ring cuts ahead of the
     # service at full chip width)
-    # (in units of the largest chunk rounded up to pages — the page size of rounds 3-5; since round 6 a page is an eighth of that)
-    unit = -(-int(cfg.MaxSize) // int(ring.page_bytes)) * int(ring.page_bytes)
-    quota = max(16, 256 // max(1, a.ring_streams)) * unit
+    quota = max(16, 256 // max(1, a.ring_streams)) * int(ring.page_bytes)
     max_open = max(8, a.ring_streams) * 4
     kind = a.ring_kind
     pending_reduce, extra, marks = {}, {}, {}
@@ -858,7 +854,7 @@ def ring_run(a, rank, local_rank, world, ctx):
             # of all the files in flight (one stream taking every free page would feed the files one after the other)
             # (a file that is ALONE gets a whole round's worth per turn: with 16 pages per turn one 64 GiB file went through
             # 253 small rounds and ~100 ms of per-round latency — and never qualified for the ring's lone-stream cut-ahead)
-            q_turn = quota if (state["S"] > 1 or len(active) > 1) else 256 * unit
+            q_turn = quota if (state["S"] > 1 or len(active) > 1) else 256 * int(ring.page_bytes)
             for sid, st in active.items():
                 if st[1]:
                     want = min(st[1], q_turn)
@@ -1067,8 +1063,7 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
     per_step = max(1, int((128.0 if a.gib is None else a.gib) * GiB) // fbytes)
     arena = 0 if a.arena_gib is None else int(a.arena_gib * GiB)
     feeding = max(8, a.ring_streams * 8)
-    ring = pbs_plus_amd.PageRing(eng, arena_bytes=arena, max_streams=4096, sha_cus=a.ring_sha_cus, round_pages=a.ring_round_pages,
-                                 page_bytes=a.ring_page_tiles * 64 * 34 * 128)
+    ring = pbs_plus_amd.PageRing(eng, arena_bytes=arena, max_streams=4096, sha_cus=a.ring_sha_cus, round_pages=a.ring_round_pages)
     total_files = per_step * (a.steps + a.warmup)
     root = dup_roots(per_step * a.steps, a.seed + 4) if mode == "corpus_dup" else None
     edited = {"on": False}          # rechunk: False while the BASE snapshot is ingested, True for the edited corpus
@@ -1113,7 +1108,7 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
         seed, kind = spec(g)
         return O.fill(fbytes, seed, kind)
 
-    quota = 4 * (-(-int(cfg.MaxSize) // int(ring.page_bytes)) * int(ring.page_bytes))   # (4 pages of the rounds 3-5 geometry)
+    quota = 4 * int(ring.page_bytes)
     recs_of = {}
 
     def run(first, count, keep):

@@ -380,10 +380,10 @@ int pbsgpu_ring_park(pbsgpu_ring *ring);
 int pbsgpu_ring_get_stats(pbsgpu_ring *ring, pbsgpu_ring_stats *out);
 /* How the ring's service is laid out: CUs of the express service (0 = none) and the chunk size from which a chunk takes it. */
 int pbsgpu_ring_express(pbsgpu_ring *ring, uint32_t *express_cus, uint64_t *long_bytes);
-/* Which regime is the ring running in? Cumulative counters of the two SHA-256 services since pbsgpu_ring_create: every
- * service wave samples the shader clock and the 100 MHz wall clock once per 4096 block steps and, when it carried a block
- * in every step of the interval, adds the interval to these sums. ticks / steps x 10 = ns per block step of a chain UNDER
- * LOAD (an express step is two blocks of a chunk); cycles / ticks x 100 = the shader clock in MHz those chains ran at.
+/* Which regime is the ring running in? Cumulative counters of the two SHA-256 services since pbsgpu_ring_create: one
+ * wave of each service samples the shader clock and the 100 MHz wall clock once per 4096 block steps and, when it carried a
+ * block in every step of the interval, adds the interval to these sums. ticks / steps x 10 = ns per block step of a chain
+ * UNDER LOAD (an express step is two blocks of a chunk); cycles / ticks x 100 = the shader clock in MHz that chain ran at.
  * Read it twice and subtract to look at a phase (bench.py: feed phase and drain of the timed region -> `roofline`).
  * Safe while the service runs. */
 typedef struct pbsgpu_ring_probe {

@@ -215,24 +215,16 @@ struct alignas(64) RingCtl {   // device memory, one 64-byte line
                            // chunk only while every express pair is busy: waiting for one would cost more than it saves)
     uint32_t pad[7];
 };
-// Queue descriptor of one chunk: 64 bytes = 4 x uint4 (both queues):
-//   [0] {offset of the chunk's first byte in its first page, size (0 = void position), record cell, number of pages}
-//   [1..3] the physical pages the chunk has bytes in, in order (u32 each, kRingDescPages at most)
-// Since round 6 a page is SMALLER than the largest chunk (default 8 scan tiles = 2.125 MiB at avg 4 MiB): the service lane walks
-// the list, and gives a page back the moment its last block from that page is in registers — residency of a byte is the time
-// the hash needs to reach it, not the chain of the longest chunk on a 16 MiB page (rounds 3-5: page >= max chunk, two pieces).
-constexpr uint32_t kRingDescWords = 16;   // dwords per descriptor
-constexpr uint32_t kRingDescPages = 12;   // page ids a descriptor can carry: (max chunk - 1) / page + 2 <= 12
 struct RingSource {
     static constexpr bool kRing = true;
-    const uint4 *desc;         // ring of positions, 4 x uint4 each (see above)
+    const uint4 *desc;         // ring of positions, 2 x uint4 each: {p1.lo, p1.hi, len, len1} {p2v.lo, p2v.hi, cell, pages}
     uint32_t qmask;            // positions - 1 (power of two)
-    const uint8_t *arena;      // page p's body starts at arena + p * stride + 128
-    uint32_t stride, page_bytes;
-    // Which regime did a run land in? Every producer wave of a service samples clock64() (shader clock) and wall_clock64()
-    // (100 MHz) once per kRingProbeSteps block steps and, if it carried a block in EVERY step of the interval, adds
-    // {steps, shader cycles, wall ticks} to these device counters (3 x u64 per service: pair [0..2], express [3..5]):
-    // ns per block step of a chain under load and the shader clock it ran at, over all busy waves (pbsgpu_ring_probe).
+    // Which regime did a run land in? ONE producer wave of each service (workgroup 0, first producer) samples clock64() (the
+    // shader clock) and wall_clock64() (100 MHz) once per kRingProbeSteps block steps and, if it carried a block in EVERY step
+    // of the interval, adds {steps, shader cycles, wall ticks} to these device counters (3 x u64 per service: pair [0..2],
+    // express [3..5]): ns per block step of a chain under load and the shader clock it ran at (pbsgpu_ring_get_probe). One
+    // wave only: counting steps in EVERY producer wave cost the driver's line 1.2 % (profiles/r06_ab_walk_load_in_branch.log:
+    // the producer bounds the loaded chain, every instruction of its step shows); the others pay one scalar branch.
     unsigned long long *probe;
     // Chunks of at least `long_bytes` go through a second, smaller queue that idle lanes look at FIRST: a max-size chunk
     // hashes for ~0.45 s on one lane, so the later it starts the longer the ring's drain (bench: the last such chunk used
@@ -269,7 +261,7 @@ struct RingSource {
     uint32_t long_lo;
 };
 constexpr int kHbBeat = 0, kHbIntent = 16, kHbCommitted = 17, kHbClaim = 32, kHbRoundsEnq = 33;
-constexpr uint32_t kRingProbeSteps = 4096;  // block steps between two samples of a service wave (~7 ms)
+constexpr uint32_t kRingProbeSteps = 4096;  // block steps between two samples of a service's probe wave (~7 ms)
 
 
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)
@@ -312,7 +304,7 @@ struct RingSeg {
 };
 // Device-resident state of a stream slot.
 constexpr uint64_t kRingMaxStream = 1ull << kRingOffBits;  // logical coordinates are (stream slot << kRingOffBits) | offset
-constexpr uint32_t kRingPT = 4096;     // page-table window per stream (open chunk <= kRingDescPages pages + new pages of one round)
+constexpr uint32_t kRingPT = 512;      // page-table window per stream (open chunk <= 2 pages + new pages of one round)
 struct RingStreamState {
     uint64_t c;            // start of the open chunk (logical offset in the stream)
     uint64_t end;          // bytes received so far

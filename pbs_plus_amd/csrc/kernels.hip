@@ -1571,25 +1571,12 @@ struct SegmentSource {
 //   * the consumer writes the digest straight into the host-visible record cell and raises the cell's flag.
 // (RingCtl / RingSource: kernels.h)
 
-// A service lane gives a page back: the lane that brings its reference count to zero reports it to the host through the
-// FIFO in mapped pinned memory (release order: every load this lane issued from the page has completed).
-__device__ __forceinline__ void ring_release_page(const RingSource &src, const uint32_t pi) {
-    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == 1u) {
-        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
-        __hip_atomic_store(&src.free_fifo[fs & src.free_mask], ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-// the services' regime probe (RingSource::probe): called once per block step by a producer wave, wave-uniform
+// the services' regime probe (RingSource::probe): called once per block step by the service's probe wave, wave-uniform
 struct RingProbe {
     uint32_t n = 0, idle = 0;
     unsigned long long c0 = 0, w0 = 0;
 };
 __device__ __forceinline__ void ring_probe_step(const RingSource &src, RingProbe &pb, const bool busy, const int slot, const int lane) {
-#ifdef PBS_NO_PROBE
-    return;
-#endif
     pb.idle |= busy ? 0u : 1u;
     if (++pb.n < kRingProbeSteps) return;
     const unsigned long long c = clock64(), w = wall_clock64();
@@ -1603,45 +1590,6 @@ __device__ __forceinline__ void ring_probe_step(const RingSource &src, RingProbe
     pb.c0 = c;
     pb.w0 = w;
 }
-// A lane's walk over the pages of its chunk (RingSource only; plain words, not a struct: the producers keep them in VGPRs).
-// `base` is virtual: the byte at chunk offset `off` lives at base + off while off < wend. The chunk's page list travels in
-// REGISTERS (wcur + a shift register of the up to 11 pages behind it, filled from the descriptor when the lane takes the
-// chunk): a crossing is a handful of moves. A first version fetched the next page id from the descriptor AT the crossing —
-// a load inside a branch in front of the block loads, and the waitcnt bookkeeping then waited for EVERY outstanding load in
-// every step: the loaded chain went from 1.87 to 2.02 us per block, the driver's line from 620 to 589 GiB/s on the same box
-// (profiles/r06_ab_walk_load_in_branch.log). No load may sit behind a branch on the producer's path.
-#ifndef PBS_WALK_N
-#define PBS_WALK_N 11
-#endif
-#define PBS_RING_WALK_STATE                                                                                        \
-    [[maybe_unused]] uint32_t wq[PBS_WALK_N];        /* the chunk's pages behind the current one, next first */    \
-    [[maybe_unused]] uint32_t wend = 0;              /* chunk offset at which the current page ends */             \
-    [[maybe_unused]] uint32_t wcur = 0xffffffffu;    /* current physical page */                                   \
-    [[maybe_unused]] uint32_t wleft = 0;             /* pages behind the current one */                            \
-    _Pragma("unroll") for (int wi_ = 0; wi_ < PBS_WALK_N; ++wi_) wq[wi_] = 0xffffffffu;
-// take a chunk: e0..e3 = its descriptor (already loaded), tk = this lane takes it
-#define PBS_RING_WALK_TAKE(tk, e0, e1, e2, e3)                                                                               \
-    base = (tk) ? src.arena + (uint64_t)(e1).x * src.stride + 128u + (e0).x : base;                                         \
-    len = (tk) ? (uint64_t)(e0).y : len;                                                                                     \
-    dst = (tk) ? src.cells + (uint64_t)(e0).z * 64u + 8u : dst;                                                              \
-    wend = (tk) ? src.page_bytes - (e0).x : wend;                                                                            \
-    wcur = (tk) ? (e1).x : wcur;                                                                                             \
-    wleft = (tk) ? (e0).w - 1u : wleft;                                                                                      \
-    {                                                                                                                        \
-        const uint32_t ids_[11] = {(e1).y, (e1).z, (e1).w, (e2).x, (e2).y, (e2).z, (e2).w, (e3).x, (e3).y, (e3).z, (e3).w};   \
-        _Pragma("unroll") for (int wi_ = 0; wi_ < PBS_WALK_N; ++wi_) wq[wi_] = (tk) ? ids_[wi_] : wq[wi_];                   \
-    }
-// the block at chunk offset `off` starts behind the current page (and the chunk still has bytes there): on to the next page;
-// `rel` = the page left (given back when this block is CONSUMED)
-#define PBS_RING_WALK_CROSS(off, rel)                                                                \
-    if ((uint32_t)(off) >= wend && (off) < len) {                                                    \
-        rel = wcur;                                                                                  \
-        wcur = wq[0];                                                                                \
-        _Pragma("unroll") for (int wi_ = 0; wi_ + 1 < PBS_WALK_N; ++wi_) wq[wi_] = wq[wi_ + 1];      \
-        --wleft;                                                                                     \
-        base = src.arena + (uint64_t)wcur * src.stride + 128u - wend;                                \
-        wend += src.page_bytes;                                                                      \
-    }
 
 // Each lane streams one byte range through SHA-256. Per loop trip every busy lane consumes
 // one 64-byte block: the raw dwords of the NEXT block are requested before the current
@@ -1811,22 +1759,23 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         uint64_t len = 0, blk = 0, nblk = 0;  // blk = next block to fetch
         uint8_t *dst = nullptr;
         bool have = false, exhausted = false;
-        // ring service only: the lane's walk over the pages of its chunk, the lane's claimed queue position
-        PBS_RING_WALK_STATE
-        [[maybe_unused]] uint32_t claim = 0;
+        // ring service only: second piece of a chunk that crosses into another physical page (virtual base: the byte at
+        // chunk offset `off >= len1` lives at base2 + off), the chunk's page references, the lane's claimed queue position
+        [[maybe_unused]] const uint8_t *base2 = nullptr;
+        [[maybe_unused]] uint32_t len1 = 0, pages = 0xffffffffu, claim = 0;
         [[maybe_unused]] uint32_t claimed = 0;  // (a word, not a bool: two bool flags set in sibling branches get their stores
                                                 // merged through a selected pointer by the optimiser, which puts both in scratch)
         [[maybe_unused]] unsigned long long idle_since = 0;
         [[maybe_unused]] uint32_t hb_seen = 0;
         // FIFO of raw blocks in flight: a block is requested D iterations before it is expanded, so
         // HBM/TLB latency of the lane-private streams stays off the serial chain
+        // (round 6: D = 4 in the ring's service — is it memory latency that makes the producer the slower half under load, 1.92-1.95
+        // against 1.81-1.82 us per step? No: 604-612 GiB/s against 618-619 on the same box, profiles/r06_ab_restored_services_and_fifo_depth.log)
         constexpr int D = 2;  // even (buffer parity is derived from the slot index)
         uint32_t R[D][17];
         uint32_t selv[D], cflag[D];
         uint8_t *dstv[D];
-        // ring service: pages this slot's block lets go of when it is CONSUMED (every earlier load has completed by then):
-        // relv = the page the lane left with this block, pagesv / extrav = the chunk's last page(s) behind its last block
-        [[maybe_unused]] uint32_t pagesv[D], relv[D], extrav[D];
+        [[maybe_unused]] uint32_t pagesv[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
 #pragma unroll
@@ -1834,7 +1783,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             selv[s] = 0x00010203u;
             cflag[s] = 0;
             dstv[s] = nullptr;
-            pagesv[s] = relv[s] = extrav[s] = 0xffffffffu;
+            pagesv[s] = 0xffffffffu;
         }
 
         // Dense form: a wave RESERVES kReserve extra queue positions with every atomic and serves its lanes from that
@@ -1885,17 +1834,19 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                             __atomic_thread_fence(__ATOMIC_ACQUIRE);
                             const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
                             const bool tk = elig && rank < cnt;
-                            uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
-                            const uint4 *dl = src.ldesc + (uint64_t)((got0 + rank) & src.lmask) * (kRingDescWords / 4u);
+                            uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
                             if (tk) {
-                                e0 = dl[0];
-                                e1 = dl[1];
-                                e2 = dl[2];
-                                e3 = dl[3];
+                                e0 = src.ldesc[2u * ((got0 + rank) & src.lmask)];
+                                e1 = src.ldesc[2u * ((got0 + rank) & src.lmask) + 1u];
                             }
-                            PBS_RING_WALK_TAKE(tk, e0, e1, e2, e3)
+                            base = tk ? reinterpret_cast<const uint8_t *>(((uint64_t)e0.y << 32) | e0.x) : base;
+                            base2 = tk ? reinterpret_cast<const uint8_t *>(((uint64_t)e1.y << 32) | e1.x) : base2;
+                            len = tk ? (uint64_t)e0.z : len;
+                            len1 = tk ? e0.w : len1;
+                            dst = tk ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
+                            pages = tk ? e1.w : pages;
                             blk = tk ? 0ull : blk;
-                            nblk = tk ? ((uint64_t)e0.y + 8u) / 64u + 1u : nblk;
+                            nblk = tk ? ((uint64_t)e0.z + 8u) / 64u + 1u : nblk;
                             have = have | tk;
                             need = need && !tk;
                         }
@@ -1931,22 +1882,24 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 const uint32_t tail = (uint32_t)ts, stop = (uint32_t)(ts >> 32);
                 const bool ready = need && claimed != 0u && (int32_t)(tail - claim) > 0;
                 if (__ballot(ready)) __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, d2 = d0, d3 = d0;
-                const uint4 *dm = src.desc + (uint64_t)(claim & src.qmask) * (kRingDescWords / 4u);
+                uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
                 if (ready) {
-                    d0 = dm[0];
-                    d1 = dm[1];
-                    d2 = dm[2];
-                    d3 = dm[3];
+                    d0 = src.desc[2u * (claim & src.qmask)];
+                    d1 = src.desc[2u * (claim & src.qmask) + 1u];
                 }
                 // size 0 = a void position (the open chunk of a round): the lane takes another one next time.
                 // (selects and or-updates, no conditional stores: two flags set in sibling branches get their stores merged
                 // through a selected pointer by the optimiser, which moves both flags into scratch memory)
-                const bool got = ready && d0.y != 0u;
+                const bool got = ready && d0.z != 0u;
                 claimed = ready ? 0u : claimed;
-                PBS_RING_WALK_TAKE(got, d0, d1, d2, d3)
+                base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)d0.y << 32) | d0.x) : base;
+                base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)d1.y << 32) | d1.x) : base2;
+                len = got ? (uint64_t)d0.z : len;
+                len1 = got ? d0.w : len1;
+                dst = got ? src.cells + (uint64_t)d1.z * 64u + 8u : dst;
+                pages = got ? d1.w : pages;
                 blk = got ? 0ull : blk;
-                nblk = got ? ((uint64_t)d0.y + 8u) / 64u + 1u : nblk;
+                nblk = got ? ((uint64_t)d0.z + 8u) / 64u + 1u : nblk;
                 have = have | got;
                 // stop: nothing will ever be published at this position. (stop is raised behind the last publish of BOTH queues;
                 // the long queue is looked at again after the fence, so a lane never leaves while long chunks are unclaimed)
@@ -2007,16 +1960,8 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
             uint32_t c = 0;
             if (have) {
                 const uint64_t off = blk * 64;
-                [[maybe_unused]] uint32_t rel = 0xffffffffu, extra = 0xffffffffu;
-                if constexpr (Source::kRing) {
-                    // the block starts behind the current page (and the chunk still has bytes there): on to the chunk's next
-                    // page; the page left is given back when THIS block is consumed. (A block that starts in front of the
-                    // boundary reads on into the page's tail pad, which mirrors the next page's first 128 bytes.)
-                    PBS_RING_WALK_CROSS(off, rel)
-                    // the chunk's last block: a last page that holds fewer than 64 bytes of the chunk is never entered
-                    extra = (blk + 1 == nblk && wleft != 0u) ? wq[0] : extra;
-                }
                 const uint8_t *bb = base;
+                if constexpr (Source::kRing) bb = (off < len1) ? base : base2;  // which physical page holds this block
                 if (off + 64 <= len) {  // pure data block: 4-byte aligned vector loads + funnel selector
                     const uint8_t *p = bb + off;
                     const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
@@ -2034,11 +1979,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
                 dstv[s] = dst;
-                if constexpr (Source::kRing) {
-                    pagesv[s] = wcur;
-                    relv[s] = rel;
-                    extrav[s] = extra;
-                }
+                if constexpr (Source::kRing) pagesv[s] = pages;
                 if (++blk == nblk) have = false;
             }
             cflag[s] = c;
@@ -2049,6 +1990,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         bool running = true;
         [[maybe_unused]] bool wg_busy = false;  // some pair of this workgroup had a block in the previous step
         [[maybe_unused]] RingProbe probe;
+        [[maybe_unused]] const bool probe_on = blockIdx.x == 0 && wave == 2;
         while (running) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -2061,16 +2003,27 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     const uint32_t c = cflag[s];
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
-                        // Progressive release (round 6): the block that took the lane into a NEW page is being expanded — every
-                        // load from the page it left has completed (loads return in order), so that page's reference goes
-                        // now; behind the chunk's LAST block the page it ends in (and a last page the lane never had to
-                        // enter). Whoever brings a page to zero hands it back to the host, which may refill it at once. A
-                        // page's residency is the time the hash needs to pass it, not the chain of the longest chunk on it.
-                        if (c & 1u) {
-                            if (relv[s] != 0xffffffffu) ring_release_page(src, relv[s]);
-                            if (c & 2u) {
-                                ring_release_page(src, pagesv[s]);
-                                if (extrav[s] != 0xffffffffu) ring_release_page(src, extrav[s]);
+                        // The chunk's LAST block has arrived in registers: nothing of the chunk will be read from HBM
+                        // again. Drop its page references (release: all earlier loads of this lane have completed);
+                        // whoever brings a page to zero hands it back to the host, which may refill it at once.
+                        // (Round 4 tried letting go of a two-page chunk's FIRST page as soon as its last block there was
+                        // in: no gain — a max-size chunk lives almost entirely in ONE 16.2 MiB page, which it holds for
+                        // its whole 0.46 s either way; configs[2] through the ring 412 vs 422 GiB/s. Removed again.)
+                        if (c & 2u) {
+                            const uint32_t pg = pagesv[s];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
+                                if (pi != 0xffffu) {
+                                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
+                                                                                __HIP_MEMORY_SCOPE_AGENT);
+                                    if (old == 1u) {
+                                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
+                                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask],
+                                                           ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                }
                             }
                         }
                     }
@@ -2141,7 +2094,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                             idle_since = 0;
                         }
                         if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
-                        ring_probe_step(src, probe, any_cur, 0, lane);
+                        if (probe_on) ring_probe_step(src, probe, any_cur, 0, lane);
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
@@ -2335,18 +2288,15 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
         uint64_t len = 0, blk = 0, nblk = 0;  // blk = the lane's next block (A: even blocks, B: odd blocks)
         uint8_t *dst = nullptr;
         bool have = false, exhausted = false;
-        PBS_RING_WALK_STATE
+        [[maybe_unused]] const uint8_t *base2 = nullptr;
+        [[maybe_unused]] uint32_t len1 = 0, pages = 0xffffffffu;
         [[maybe_unused]] unsigned long long idle_since = 0;
         [[maybe_unused]] uint32_t poll_ctr = 0;
         constexpr int D = 2;
         uint32_t R[D][17];
         uint32_t selv[D], cflag[D];
         uint8_t *dstv[D];
-        // ring service: pages given back when this slot's block is consumed — by the pair's A lane only (both lanes walk the
-        // chunk's pages for their own blocks; A's blocks are the even ones, so when A has left a page every block of the chunk
-        // in it — B's are one behind — has been loaded): relv = the page A left with this block; pagesv / extrav = the page(s)
-        // the chunk ends in, behind A's last block (B's last block, if it comes later, is consumed in the same step)
-        [[maybe_unused]] uint32_t pagesv[D], relv[D], extrav[D];
+        [[maybe_unused]] uint32_t pagesv[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
 #pragma unroll
@@ -2354,7 +2304,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
             selv[s] = 0x00010203u;
             cflag[s] = 0;
             dstv[s] = nullptr;
-            pagesv[s] = relv[s] = extrav[s] = 0xffffffffu;
+            pagesv[s] = 0xffffffffu;
         }
         // `need`: this A lane's PAIR has issued every block of its chunk and wants the next one (B lanes never ask)
         auto acquire = [&](bool need) {
@@ -2378,15 +2328,17 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         __atomic_thread_fence(__ATOMIC_ACQUIRE);
                         const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
                         got = need && rank < cnt;
-                        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0, e2 = e0, e3 = e0;
-                        const uint4 *dl = src.ldesc + (uint64_t)((got0 + rank) & src.lmask) * (kRingDescWords / 4u);
+                        uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
                         if (got) {
-                            e0 = dl[0];
-                            e1 = dl[1];
-                            e2 = dl[2];
-                            e3 = dl[3];
+                            e0 = src.ldesc[2u * ((got0 + rank) & src.lmask)];
+                            e1 = src.ldesc[2u * ((got0 + rank) & src.lmask) + 1u];
                         }
-                        PBS_RING_WALK_TAKE(got, e0, e1, e2, e3)
+                        base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e0.y << 32) | e0.x) : base;
+                        base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e1.y << 32) | e1.x) : base2;
+                        len = got ? (uint64_t)e0.z : len;
+                        len1 = got ? e0.w : len1;
+                        dst = got ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
+                        pages = got ? e1.w : pages;
                         if (lane == leader) atomicAdd(&src.ctl->xp_busy, cnt);  // (given back when the chunk's last block is in)
                     }
                 } else {
@@ -2428,17 +2380,14 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     len = ln;
                     dst = reinterpret_cast<uint8_t *>(ds);
                 }
-                if constexpr (Source::kRing) {  // the B lane walks the same page list for its own (odd) blocks
-                    const uint32_t we = (uint32_t)__shfl((int)wend, srcl, 64);
-                    const uint32_t wc = (uint32_t)__shfl((int)wcur, srcl, 64);
-                    const uint32_t wl = (uint32_t)__shfl((int)wleft, srcl, 64);
-                    wend = pgot ? we : wend;
-                    wcur = pgot ? wc : wcur;
-                    wleft = pgot ? wl : wleft;
-#pragma unroll
-                    for (int j = 0; j < PBS_WALK_N; ++j) {
-                        const uint32_t v = (uint32_t)__shfl((int)wq[j], srcl, 64);
-                        wq[j] = pgot ? v : wq[j];
+                if constexpr (Source::kRing) {
+                    const uint64_t b2 = (uint64_t)__shfl((unsigned long long)reinterpret_cast<uintptr_t>(base2), srcl, 64);
+                    const uint32_t l1 = (uint32_t)__shfl((int)len1, srcl, 64);
+                    const uint32_t pg = (uint32_t)__shfl((int)pages, srcl, 64);
+                    if (pgot) {
+                        base2 = reinterpret_cast<const uint8_t *>(b2);
+                        len1 = l1;
+                        pages = pg;
                     }
                 }
                 if (pgot) {
@@ -2455,15 +2404,8 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
             uint32_t c = 0;
             if (have) {
                 const uint64_t off = blk * 64;
-                [[maybe_unused]] uint32_t rel = 0xffffffffu, extra = 0xffffffffu, fin = 0xffffffffu;
-                if constexpr (Source::kRing) {
-                    PBS_RING_WALK_CROSS(off, rel)  // on to the chunk's next page (see the pair form)
-                    const bool a_last = !roleB && blk + 2 >= nblk;  // A's last block: the chunk ends in this step
-                    fin = a_last ? wcur : fin;
-                    extra = (a_last && wleft != 0u) ? wq[0] : extra;
-                    rel = roleB ? 0xffffffffu : rel;
-                }
                 const uint8_t *bb = base;
+                if constexpr (Source::kRing) bb = (off < len1) ? base : base2;
                 if (off + 64 <= len) {
                     const uint8_t *p = bb + off;
                     const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
@@ -2481,11 +2423,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                 }
                 c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
                 dstv[s] = dst;
-                if constexpr (Source::kRing) {
-                    pagesv[s] = fin;
-                    relv[s] = rel;
-                    extrav[s] = extra;
-                }
+                if constexpr (Source::kRing) pagesv[s] = pages;
                 blk += 2;
                 if (blk >= nblk) have = false;
             }
@@ -2499,6 +2437,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
         bool running = true;
         [[maybe_unused]] bool wg_busy = false;
         [[maybe_unused]] RingProbe probe;
+        [[maybe_unused]] const bool probe_on = blockIdx.x == 0 && wave == 2;
         while (running) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -2511,16 +2450,27 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
                         // the chunk's LAST block is in registers (the partner's blocks of this step and all earlier ones
-                        // too: same load instructions, same wait): the pair is free for the service's accounting
+                        // too: same load instructions, same wait): the pair is free for the service's accounting, and the
+                        // chunk's page references are dropped, as the pair form does
                         {
                             const unsigned long long mdone = __ballot((c & 2u) != 0u);
                             if (mdone && lane == (__ffsll((long long)mdone) - 1)) atomicSub(&src.ctl->xp_busy, (uint32_t)__popcll(mdone));
                         }
-                        if (c & 1u) {  // progressive release, by the A lane (see pagesv above)
-                            if (relv[s] != 0xffffffffu) ring_release_page(src, relv[s]);
-                            if (pagesv[s] != 0xffffffffu) {
-                                ring_release_page(src, pagesv[s]);
-                                if (extrav[s] != 0xffffffffu) ring_release_page(src, extrav[s]);
+                        if (c & 2u) {
+                            const uint32_t pg = pagesv[s];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
+                                if (pi != 0xffffu) {
+                                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE,
+                                                                                __HIP_MEMORY_SCOPE_AGENT);
+                                    if (old == 1u) {
+                                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
+                                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask],
+                                                           ((unsigned long long)(fs + 1u) << 32) | pi, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                                    }
+                                }
                             }
                         }
                     }
@@ -2548,7 +2498,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                         live = any_cur || !wave_done;
                         if (!any_cur && !wave_done && !wg_busy) __builtin_amdgcn_s_sleep(48);  // (never while the sibling pair works)
                         if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
-                        ring_probe_step(src, probe, any_cur, 3, lane);  // (a step of this form = TWO blocks per chunk)
+                        if (probe_on) ring_probe_step(src, probe, any_cur, 3, lane);  // (a step of this form = TWO blocks per chunk)
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();

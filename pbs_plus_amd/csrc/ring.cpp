@@ -534,9 +534,6 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.desc = desc.as<uint4>();
     q.qmask = qslots - 1;
     q.probe = probe.as<unsigned long long>();
-    q.arena = arena.as<uint8_t>();
-    q.stride = (uint32_t)stride;
-    q.page_bytes = (uint32_t)page_bytes;
     q.ldesc = ldesc.as<uint4>();
     q.lmask = lslots - 1;
     q.long_bytes = long_bytes;
@@ -684,14 +681,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
     if (hold_engine_ref) engine_ref(e);
     r->eng = e;
     int st = [&]() -> int {
-        // page geometry: a whole number of scan tiles (every tile of a full page takes the scan's check-free path), and large
-        // enough for a chunk's page list to fit its queue descriptor: (max - 1) / page + 2 <= kRingDescPages. Since round 6 a
-        // page may be SMALLER than the largest chunk: the service lane walks the chunk's pages and gives each back when the
-        // hash has passed it (progressive release). The DEFAULT stays the largest chunk rounded up to tiles (61 tiles = 16.2
-        // MiB at avg 4 MiB): measured on one box, driver's command, 61 / 16 / 8 tiles per page: 595-600 / 592 / 584-586 GiB/s,
-        // configs[2] through the ring 500-502 vs 497-499, configs[3] 541 vs 541 (profiles/r06_ab_page_geometry.log) — halving
-        // and quartering the residency of a byte moves nothing, because the arena does not bind: the services' CU-time does
-        // (DESIGN.md 5.5), and eight times the pages per round cost the cut side and the host a little.
+        // page geometry: a whole number of scan tiles, >= the largest chunk (so a chunk touches at most two pages)
         const uint32_t big = 64u * 34u * 128u, small = 64u * 4u * 128u;
         uint64_t page = o.page_bytes;
         if (page == 0) {
@@ -702,7 +692,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (page % big == 0) r->tile_bytes = big;
         else if (page % small == 0) r->tile_bytes = small;
         else return PBSGPU_E_INVALID;
-        if (((uint64_t)e->cfg.max - 1) / page + 2 > pbsk::kRingDescPages || page >= (1ull << 31)) return PBSGPU_E_INVALID;
+        if (page < e->cfg.max || page >= (1ull << 31)) return PBSGPU_E_INVALID;
         r->page_bytes = page;
         r->tpp = (uint32_t)(page / r->tile_bytes);
         r->stride = page + 256;
@@ -712,7 +702,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
             HIPCHK(hipMemGetInfo(&fr, &tot));
             arena_bytes = fr > (12ull << 30) ? fr - (8ull << 30) : fr / 2;
         }
-        r->npages = (uint32_t)std::min<uint64_t>(arena_bytes / r->stride, 1u << 30);
+        r->npages = (uint32_t)std::min<uint64_t>(arena_bytes / r->stride, 65534);  // 16-bit page ids in the queue descriptors
         {   // the chunk FIFO and the record cells are sized for every chunk the arena can hold (arena / min chunk size):
             // with small average chunk sizes that bound, not HBM, limits the arena (4 M resident chunks = 128 MB of
             // descriptors + 1 GB of pinned record cells)
@@ -750,11 +740,9 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->split_auto = xp > 0 && !o.sha_cus && !o.express_cus && !getenv("PBSGPU_RING_SHA_CUS") && !getenv("PBSGPU_RING_XP_CUS") &&
                         r->svc_cus >= 96;
         if (const char *v = getenv("PBSGPU_RING_SPLIT_AUTO")) r->split_auto = r->split_auto && atoi(v) != 0;
-        // a round takes up to ~4.3 GB of new pages (256 pages of the old 16.2 MiB geometry), whatever the page size
-        r->round_pages = o.round_pages ? o.round_pages
-                                       : (uint32_t)std::max<uint64_t>(16, (256ull * 61ull * big + r->page_bytes - 1) / r->page_bytes);
+        r->round_pages = o.round_pages ? o.round_pages : 256;
         if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
-        r->round_pages = std::min(std::min<uint32_t>(r->round_pages, kPagesPerStreamRound), r->npages);
+        r->round_pages = std::min(r->round_pages, r->npages);
         r->min_round_pages = std::max(1u, r->round_pages / 4);
         if (const char *v = getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = (uint32_t)std::max(1, atoi(v));
         // ~30 ms of the service's throughput (4.3 GiB/s per CU measured) is plenty to ride out the gaps between rounds
@@ -790,7 +778,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         CHK(r->probe.ensure(64));
         CHK(r->streams.ensure((size_t)r->max_streams * sizeof(pbsk::RingStreamState)));
         CHK(r->pending.ensure((size_t)r->npages * 4 + 64));
-        CHK(r->desc.ensure((size_t)r->qslots * pbsk::kRingDescWords * 4));
+        CHK(r->desc.ensure((size_t)r->qslots * 32));
         // optional long-chunk queue (PBSGPU_RING_LONG_BYTES, e.g. half the maximum chunk size = 8 % of the chunks, 30 % of the
         // bytes of random data): idle lanes look at it first
         // (OFF by default: measured +0.8 % on the bench line for +40 ms of single-file latency — the drain is not made of
@@ -800,7 +788,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (const char *v = getenv("PBSGPU_RING_LONG_BYTES")) r->long_bytes = (uint32_t)std::max(0L, atol(v));
         if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);
-        CHK(r->ldesc.ensure((size_t)r->lslots * pbsk::kRingDescWords * 4));
+        CHK(r->ldesc.ensure((size_t)r->lslots * 32));
         CHK(r->scalars.ensure(pbsk::kRsCount * 4 + 64));
         CHK(r->tile_cnt.ensure((size_t)ntiles * 4 + 16));
         CHK(r->tile_off.ensure((size_t)ntiles * 4 + 16));

@@ -12,8 +12,9 @@
 namespace pbse {
 
 constexpr uint32_t kRingInputs = 16;            // rounds whose host-written tables may be in flight
-constexpr uint32_t kPagesPerStreamRound = pbsk::kRingPT - 32;  // a stream's new pages of ONE round + its open chunk's pages
-                                                                // (<= kRingDescPages) must fit the stream's page-table window
+constexpr uint32_t kPagesPerStreamRound = 256;  // < kRingPT - 2 (open chunk). It was 48 until a lone 64 GiB file turned out to
+                                                // go through 83 small rounds, none of them large enough for the cut-ahead at
+                                                // full chip width (ring_enqueue_round): a whole default round per stream now
 
 struct PageReq {                          // a committed page waiting for its round
     uint32_t phys = 0;

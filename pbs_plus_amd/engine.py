@@ -635,8 +635,7 @@ class PageRing:
                     break
                 j = todo.pop(0)
                 active[sid] = [j, int(jobs[j][2]), False]
-            # pages are dealt out evenly among the open streams (16 x the largest chunk, rounded up to pages)
-            quota = 16 * (-(-int(self._eng.config.MaxSize) // self.page_bytes) * self.page_bytes)
+            quota = 16 * self.page_bytes            # pages are dealt out evenly among the open streams
             for sid, a in active.items():
                 j, left, sent_final = a
                 if not sent_final:

@@ -68,14 +68,6 @@ SMALL = dict(page_bytes=65536, max_streams=8, sha_cus=4, round_pages=6)
      [(31, 0, (1 << 20) + 5), (32, 1, 300 * 1024), (33, 3, 700 * 1024 + 3), (34, 0, 64), (35, 0, 65), (36, 4, 131072)], 2),
     ("avg 64 KiB", 65536, dict(arena_bytes=96 * (262144 + 256), page_bytes=262144, max_streams=8, sha_cus=16, round_pages=16),
      [(41 + i, i % 5, (8 << 20) + 4099 * i) for i in range(6)], None),
-    # pages SMALLER than the largest chunk (round 6): 32 KiB pages under a 256 KiB maximum — a chunk walks over up to 9 pages
-    # and gives each back as the hash passes it; zero runs (kind 1: nothing but max-size chunks) through the express service too
-    ("avg 64 KiB, 32 KiB pages", 65536, dict(arena_bytes=700 * (32768 + 256), page_bytes=32768, max_streams=8, sha_cus=16,
-                                             round_pages=96, express_cus=2),
-     [(141 + i, i % 5, (6 << 20) + 4099 * i) for i in range(6)], None),
-    ("avg 64 KiB, 64 KiB pages, few of them", 65536, dict(arena_bytes=40 * (65536 + 256), page_bytes=65536, max_streams=4,
-                                                          sha_cus=4, round_pages=12),
-     [(151 + i, (i * 3) % 5, (3 << 20) + 777 * i) for i in range(4)], 2),
 ])
 def test_ring_streams_match_the_oracle(gpu_lib, O, name, avg, opt, jobs, conc):
     from pbs_plus_amd import PageRing
@@ -95,17 +87,14 @@ def test_ring_streams_match_the_oracle(gpu_lib, O, name, avg, opt, jobs, conc):
     eng.close()
 
 
-@pytest.mark.parametrize("tiles", [61, 8])
-def test_ring_production_chunker_three_streams(gpu_lib, O, tiles):
-    """avg 4 MiB (buzhash.NewConfig(4 << 20), commit_orchestrate.go:144): default page size (61 scan tiles, 16.2 MiB) and, since
-    round 6, pages of 8 tiles = 2.125 MiB (a max-size chunk walks over 8-9 pages and gives each back as the hash passes it),
+def test_ring_production_chunker_three_streams(gpu_lib, O):
+    """avg 4 MiB (buzhash.NewConfig(4 << 20), commit_orchestrate.go:144): default page size (61 scan tiles, 16.2 MiB),
     random / 30 % zero extents / all-zero streams of 0.5-1.5 GiB through 3 GiB of pages — the arena turns over"""
     from pbs_plus_amd import PageRing
 
     avg = 4 << 20
     eng = _engine(avg)
-    ring = PageRing(eng, arena_bytes=3 * GiB, max_streams=4, sha_cus=64, round_pages=64 * 61 // tiles,
-                    page_bytes=tiles * 64 * 34 * 128 if tiles != 61 else 0, express_cus=8 if tiles != 61 else 0)
+    ring = PageRing(eng, arena_bytes=3 * GiB, max_streams=4, sha_cus=64, round_pages=64)
     jobs = [(51, 0, 3 * GiB // 2 + 56), (52, 3, 3 * GiB // 2), (53, 1, GiB // 2 + 4096), (54, 4, GiB + 24)]
     got = ring.ingest_synthetic(jobs, timeout_s=120.0)
     ring.quiesce()
@@ -113,7 +102,7 @@ def test_ring_production_chunker_three_streams(gpu_lib, O, tiles):
     want = _oracle_records(O, avg, jobs)
     for i, (g, w) in enumerate(zip(got, want)):
         _assert_same(g, w, (i, jobs[i]))
-    assert st["page_bytes"] == tiles * 64 * 34 * 128 and st["pages_free"] == st["pages_total"]
+    assert st["page_bytes"] == 61 * 64 * 34 * 128 and st["pages_free"] == st["pages_total"]
     assert st["pages_enqueued"] > st["pages_total"]          # the arena turned over
     assert (got[2]["size"][:-1] == 16 << 20).all()           # a zero run is cut at max size only
     ring.close()
