@@ -47,9 +47,19 @@ type (
 	}
 	FileHash    struct{ Index, Size, XXH3 uint64 }
 	RingOptions struct {
-		ArenaBytes, PageBytes          uint64
-		MaxStreams, ShaCUs, RoundPages uint32
-		ExpressCUs                     uint32
+		ArenaBytes, PageBytes                                                            uint64
+		MaxStreams, ShaCUs, RoundPages                                                   uint32
+		ExpressCUs                                                                       uint32
+		MinRoundPages, MaxInflight, LongBytes, LongLoBytes, LongSpill, PollEvery, Flags uint32
+		BacklogMiB, LoneDeferMs, IdleTimeoutS, AutoparkMs                                float64
+	}
+	EngineOptions struct {
+		Inflight, ShaForm, ShaSlackPct, ShaDensePct                      uint32
+		ResolveParMin                                                    uint64
+		ShaManyFilesPerCore                                              uint32
+		StreamShaCUs, StreamExpressCUs, StreamRingSlots, StreamCtxPool   uint32
+		StreamRingGiB                                                    float64
+		StreamPageBytes                                                  uint64
 	}
 	RingStats struct {
 		PageBytes, BytesEnqueued, Chunks uint64
@@ -65,6 +75,9 @@ type (
 func NewConfig(int) (Config, error)               { return Config{}, ErrNotBuilt }
 func (c Config) WithTable([256]uint32) Config     { return c }
 func NewEngine(int, Config, int) (*Engine, error) { return nil, ErrNotBuilt }
+func NewEngineOpt(int, Config, EngineOptions) (*Engine, error) { return nil, ErrNotBuilt }
+
+const RingOff = ^uint32(0)
 func ParseDynamicIndex([]byte) ([]ChunkInfo, int64, [32]byte, error) {
 	return nil, 0, [32]byte{}, ErrNotBuilt
 }

@@ -82,8 +82,35 @@ type ChunkInfo struct {
 type Engine struct{ h *C.pbsgpu_engine }
 
 func NewEngine(device int, cfg Config, inflight int) (*Engine, error) {
+	return NewEngineOpt(device, cfg, EngineOptions{Inflight: uint32(inflight)})
+}
+
+// EngineOptions mirrors pbsgpu_engine_options (ABI v5): every tuning value an engine has, per engine — two engines of one
+// process may differ (rounds 1-5 read them from process-wide PBSGPU_* environment variables). Zero values = the defaults.
+type EngineOptions struct {
+	Inflight            uint32  // batches in flight at once (1..16; 0 = 2)
+	ShaForm             uint32  // batch-path hash kernel: 0 wave pairs, 1 single-wave lanes, 2 express (tests, A/B)
+	ShaSlackPct         uint32  // percent + 1 (0 = default)
+	ShaDensePct         uint32  // 0 = default 150; ^uint32(0) = never
+	ResolveParMin       uint64  // 0 = default 64 MiB; ^uint64(0) = always the serial walk
+	ShaManyFilesPerCore uint32  // HashFiles policy: files in flight per host core from which the GPU wins (0 = 55)
+	StreamShaCUs        uint32  // the engine's own ring behind Stream: CUs of its pair service (0 = 32)
+	StreamExpressCUs    uint32  // ... of its express service (0 = 8; ^uint32(0) = none)
+	StreamRingSlots     uint32  // ring streams open at once (0 = 256)
+	StreamCtxPool       uint32  // closed stream contexts kept for re-use (0 = 8; ^uint32(0) = none)
+	StreamRingGiB       float64 // its arena (0 = 48)
+	StreamPageBytes     uint64  // its page size (0 = default)
+}
+
+func NewEngineOpt(device int, cfg Config, o EngineOptions) (*Engine, error) {
 	e := &Engine{}
-	if err := check(C.pbsgpu_engine_create(C.int(device), &cfg.c, C.uint32_t(inflight), &e.h), "engine_create"); err != nil {
+	co := C.pbsgpu_engine_options{inflight: C.uint32_t(o.Inflight), sha_form: C.uint32_t(o.ShaForm),
+		sha_slack_pct: C.uint32_t(o.ShaSlackPct), sha_dense_pct: C.uint32_t(o.ShaDensePct),
+		resolve_par_min: C.uint64_t(o.ResolveParMin), sha_many_files_per_core: C.uint32_t(o.ShaManyFilesPerCore),
+		stream_sha_cus: C.uint32_t(o.StreamShaCUs), stream_express_cus: C.uint32_t(o.StreamExpressCUs),
+		stream_ring_slots: C.uint32_t(o.StreamRingSlots), stream_ctx_pool: C.uint32_t(o.StreamCtxPool),
+		stream_ring_gib: C.double(o.StreamRingGiB), stream_page_bytes: C.uint64_t(o.StreamPageBytes)}
+	if err := check(C.pbsgpu_engine_create_opt(C.int(device), &cfg.c, &co, &e.h), "engine_create"); err != nil {
 		return nil, err
 	}
 	runtime.SetFinalizer(e, func(e *Engine) { e.Close() })
@@ -648,13 +675,23 @@ type RingOptions struct {
 	// ExpressCUs run the two-lanes-per-chunk SHA-256 form on the long chunks (>= 5/8 of the maximum size): the chain of a
 	// chunk ~1.4x faster at ~0.65 of the throughput per CU. For rings whose latency matters more than their CU-time.
 	ExpressCUs uint32
+	// ABI v5: what used to be PBSGPU_RING_* environment variables (pbsgpu.h); zero = default, RingOff = "none"
+	MinRoundPages, MaxInflight, LongBytes, LongLoBytes, LongSpill, PollEvery, Flags uint32
+	BacklogMiB, LoneDeferMs, IdleTimeoutS, AutoparkMs                                float64
 }
+
+// RingOff expresses "none" for RingOptions fields whose zero value means "default" (PBSGPU_RING_OFF).
+const RingOff = ^uint32(0)
 
 func (e *Engine) NewRing(o RingOptions) (*Ring, error) {
 	defer runtime.KeepAlive(e)
 	co := C.pbsgpu_ring_options{arena_bytes: C.uint64_t(o.ArenaBytes), page_bytes: C.uint64_t(o.PageBytes),
 		max_streams: C.uint32_t(o.MaxStreams), sha_cus: C.uint32_t(o.ShaCUs), round_pages: C.uint32_t(o.RoundPages),
-		express_cus: C.uint32_t(o.ExpressCUs)}
+		express_cus: C.uint32_t(o.ExpressCUs), min_round_pages: C.uint32_t(o.MinRoundPages),
+		max_inflight: C.uint32_t(o.MaxInflight), long_bytes: C.uint32_t(o.LongBytes), long_lo_bytes: C.uint32_t(o.LongLoBytes),
+		long_spill: C.uint32_t(o.LongSpill), poll_every: C.uint32_t(o.PollEvery), flags: C.uint32_t(o.Flags),
+		backlog_mib: C.double(o.BacklogMiB), lone_defer_ms: C.double(o.LoneDeferMs), idle_timeout_s: C.double(o.IdleTimeoutS),
+		autopark_ms: C.double(o.AutoparkMs)}
 	r := &Ring{eng: e}
 	if err := check(C.pbsgpu_ring_create(e.h, &co, &r.h), "ring_create"); err != nil {
 		return nil, err

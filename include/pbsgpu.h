@@ -113,6 +113,33 @@ typedef struct pbsgpu_engine pbsgpu_engine;
 /* `device` = HIP ordinal; `inflight` = number of batches that may be in
  * flight at once (1..16; 0 -> default 2). */
 int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight, pbsgpu_engine **out);
+/* ... with every tuning value an engine has (ABI v5). Until v4 these were process-wide PBSGPU_* environment variables,
+ * read once — invisible to a host that runs two engines with different needs. 0 / 0.0 = the default everywhere. The
+ * variables named in the comments still work as DEBUG overrides of whatever the caller passed (one table in engine.cpp). */
+typedef struct pbsgpu_engine_options {
+    uint32_t inflight;               /* batches in flight at once (1..16; 0 = 2) */
+    uint32_t sha_form;               /* batch-path hash kernel: 0 = wave pairs (default), 1 = single-wave lanes, 2 = express
+                                      * (two lanes per chunk). Parity tests and A/B runs; PBSGPU_SHA_MODE=lane|pair|xpair */
+    uint32_t sha_slack_pct;          /* workgroup budget of a batch's hash launch over total work / longest chain, in percent
+                                      * + 1 (0 = default 25 %; 1 = none); PBSGPU_SHA_SLACK_PCT */
+    uint32_t sha_dense_pct;          /* work per pair lane, in percent of the longest chain, from which a batch's hash launch
+                                      * takes the dense form (0 = default 150; 0xffffffff = never); PBSGPU_SHA_DENSE_PCT */
+    uint64_t resolve_par_min;        /* smallest single stream whose cut chain is resolved by pointer doubling (0 = default
+                                      * 64 MiB; UINT64_MAX = always the serial walk); PBSGPU_RESOLVE_PAR_MIN / _SERIAL */
+    uint32_t sha_many_files_per_core;/* pbsgpu_sha256_many_pays: files in flight per host core from which a GPU batch wins
+                                      * (0 = default 55); PBSGPU_SHA_MANY_FILES_PER_CORE */
+    /* the engine's own page ring behind pbsgpu_stream_* (created by the first stream) */
+    uint32_t stream_sha_cus;         /* CUs of its pair service (0 = default 32); PBSGPU_STREAM_SHA_CUS */
+    uint32_t stream_express_cus;     /* ... of its express service (0 = default 8; 0xffffffff = none); PBSGPU_STREAM_XP_CUS */
+    uint32_t stream_ring_slots;      /* ring streams (sections of all payload streams) open at once (0 = 256); PBSGPU_STREAM_RING_SLOTS */
+    uint32_t stream_ctx_pool;        /* closed stream contexts kept for re-use (0 = default 8; 0xffffffff = none); PBSGPU_STREAM_CTX_POOL */
+    uint32_t reserved0;
+    double stream_ring_gib;          /* its arena (0 = default 48 GiB); PBSGPU_STREAM_RING_GIB */
+    uint64_t stream_page_bytes;      /* its page size (0 = default); PBSGPU_STREAM_PAGE_BYTES */
+    uint64_t reserved[4];
+} pbsgpu_engine_options;
+int pbsgpu_engine_create_opt(int device, const pbsgpu_config *cfg, const pbsgpu_engine_options *opt /* NULL = defaults */,
+                             pbsgpu_engine **out);
 void pbsgpu_engine_destroy(pbsgpu_engine *eng);
 int pbsgpu_engine_config(const pbsgpu_engine *eng, pbsgpu_config *out);
 /* Release what the engine only holds for re-use: the page ring of its payload streams (arena of PBSGPU_STREAM_RING_GIB,
@@ -317,7 +344,30 @@ typedef struct pbsgpu_ring_options {
                             * service share when sha_cus is 0 too (measured: throughput unchanged, a lone 64 GiB file 15 %
                             * sooner, the drain of a burst 0.08 s shorter), none when sha_cus is given. A value given here
                             * comes ON TOP of a given sha_cus. PBSGPU_RING_XP_CUS overrides (0 = off). (`reserved` before.) */
+    /* ---- ABI v5: what used to be PBSGPU_RING_* environment variables (still honoured as debug overrides: one table in
+     * ring.cpp). 0 / 0.0 = the default; PBSGPU_RING_OFF where "none" must be expressible. ---- */
+    uint32_t min_round_pages;  /* a round is launched as soon as this many pages wait (0 = round_pages / 4) */
+    uint32_t max_inflight;     /* rounds in flight (0 = 3) */
+    uint32_t long_bytes;       /* chunk size from which a chunk takes the express service (0 = 13/16 of the maximum) */
+    uint32_t long_lo_bytes;    /* ... while the express pairs are mostly idle (0 = 11/16 of the maximum on bulk rings; OFF = never) */
+    uint32_t long_spill;       /* long chunks waiting beyond which the pair lanes help (0 = default rule) */
+    uint32_t poll_every;       /* block steps between two looks at the queue of a service wave that carries work (0 = 8..64 by chunker) */
+    uint32_t flags;            /* PBSGPU_RING_F_* */
+    uint32_t reserved0;
+    double backlog_mib;        /* bytes waiting in front of the service beyond which no page is handed out (0 = 128 MiB per
+                                * service CU; < 0 = no limit) */
+    double lone_defer_ms;      /* how long the first rounds of bulk streams on an idle ring are cut ahead of the service (0 = 25; < 0 = never) */
+    double idle_timeout_s;     /* the service stops on its own after this long without work or a call (0 = 20 s) */
+    double autopark_ms;        /* > 0: the ring parks its service when nothing has been anywhere in it for this long */
+    uint64_t reserved[4];
 } pbsgpu_ring_options;
+#define PBSGPU_RING_OFF 0xffffffffu
+#define PBSGPU_RING_F_NO_OVERLAP 1u      /* scan of round n + 1 NOT beside the control kernel of round n (one scan set) */
+#define PBSGPU_RING_F_NO_STAGE 2u        /* the round's kernels read its tables from mapped host memory (rounds 3-4) */
+#define PBSGPU_RING_F_NO_CUT_PRIO 4u     /* refill and scan streams at normal priority */
+#define PBSGPU_RING_F_NO_SPLIT_AUTO 8u   /* the pair / express CU split does not follow the data */
+#define PBSGPU_RING_F_DEFER_SERVICE 16u  /* profiling: rounds only fill the queue, quiesce runs the services alone */
+#define PBSGPU_RING_F_FILL_SERIAL 32u    /* experiments: the synthetic refill in stream order behind the previous scan */
 typedef struct pbsgpu_ring_stats {
     uint64_t page_bytes, bytes_enqueued, chunks, candidates, pages_enqueued, pages_recycled, service_bytes_last;
     uint32_t pages_total, pages_free, sha_cus, rounds, rounds_done, rounds_in_flight, streams_opened, service_launches;

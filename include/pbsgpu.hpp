@@ -186,6 +186,18 @@ class Engine {
         r.value = std::shared_ptr<Engine>(new Engine(h));
         return r;
     }
+    // ... with every per-engine tuning value (pbsgpu_engine_options, ABI v5; zero fields = the defaults)
+    static Result<std::shared_ptr<Engine>> New(int device, const buzhash::Config &cfg, const pbsgpu_engine_options &opt) {
+        Result<std::shared_ptr<Engine>> r;
+        pbsgpu_engine *h = nullptr;
+        const int st = pbsgpu_engine_create_opt(device, &cfg.c, &opt, &h);
+        if (st != PBSGPU_OK) {
+            r.err = errorf("engine create", st);
+            return r;
+        }
+        r.value = std::shared_ptr<Engine>(new Engine(h));
+        return r;
+    }
     ~Engine() { pbsgpu_engine_destroy(h_); }
     pbsgpu_engine *handle() const { return h_; }
 

@@ -83,9 +83,27 @@ class FileHash(C.Structure):
     _fields_ = [("index", C.c_uint64), ("size", C.c_uint64), ("xxh3", C.c_uint64)]
 
 
+RING_OFF = 0xFFFFFFFF
+RING_F_NO_OVERLAP, RING_F_NO_STAGE, RING_F_NO_CUT_PRIO, RING_F_NO_SPLIT_AUTO, RING_F_DEFER_SERVICE, RING_F_FILL_SERIAL = 1, 2, 4, 8, 16, 32
+
+
 class RingOptions(C.Structure):
+    """pbsgpu_ring_options (ABI v5): positional use keeps working for the first six fields; the rest by keyword."""
     _fields_ = [("arena_bytes", C.c_uint64), ("page_bytes", C.c_uint64), ("max_streams", C.c_uint32),
-                ("sha_cus", C.c_uint32), ("round_pages", C.c_uint32), ("express_cus", C.c_uint32)]
+                ("sha_cus", C.c_uint32), ("round_pages", C.c_uint32), ("express_cus", C.c_uint32),
+                ("min_round_pages", C.c_uint32), ("max_inflight", C.c_uint32), ("long_bytes", C.c_uint32),
+                ("long_lo_bytes", C.c_uint32), ("long_spill", C.c_uint32), ("poll_every", C.c_uint32), ("flags", C.c_uint32),
+                ("reserved0", C.c_uint32), ("backlog_mib", C.c_double), ("lone_defer_ms", C.c_double),
+                ("idle_timeout_s", C.c_double), ("autopark_ms", C.c_double), ("reserved", C.c_uint64 * 4)]
+
+
+class EngineOptions(C.Structure):
+    """pbsgpu_engine_options (ABI v5)"""
+    _fields_ = [("inflight", C.c_uint32), ("sha_form", C.c_uint32), ("sha_slack_pct", C.c_uint32), ("sha_dense_pct", C.c_uint32),
+                ("resolve_par_min", C.c_uint64), ("sha_many_files_per_core", C.c_uint32), ("stream_sha_cus", C.c_uint32),
+                ("stream_express_cus", C.c_uint32), ("stream_ring_slots", C.c_uint32), ("stream_ctx_pool", C.c_uint32),
+                ("reserved0", C.c_uint32), ("stream_ring_gib", C.c_double), ("stream_page_bytes", C.c_uint64),
+                ("reserved", C.c_uint64 * 4)]
 
 
 class RingStats(C.Structure):
@@ -125,6 +143,7 @@ SYMBOLS = {
     "pbsgpu_config_init": (C.c_int, [C.c_uint64, _P, C.POINTER(Config)]),
     "pbsgpu_default_table": (C.POINTER(C.c_uint32), []),
     "pbsgpu_engine_create": (C.c_int, [C.c_int, C.POINTER(Config), C.c_uint32, C.POINTER(_P)]),
+    "pbsgpu_engine_create_opt": (C.c_int, [C.c_int, C.POINTER(Config), C.POINTER(EngineOptions), C.POINTER(_P)]),
     "pbsgpu_engine_destroy": (None, [_P]),
     "pbsgpu_engine_config": (C.c_int, [_P, C.POINTER(Config)]),
     "pbsgpu_engine_trim": (C.c_int, [_P, _U64P]),

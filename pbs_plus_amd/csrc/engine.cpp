@@ -99,7 +99,7 @@ void dev_free(void *p) {
         hipDeviceptr_t base = nullptr;
         if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) {
             (void)hipGetLastError();
-            size = 256u << 20;  // unknown: count it as a large block rather than as nothing (the cap errs on the early side)
+            size = 64u << 20;  // unknown: count it as a sizeable block rather than as nothing (the cap errs on the early side)
         }
         // the cap: PBSGPU_GRAVEYARD_MIB (debug override, read once) or an eighth of the memory of the device the POINTER
         // belongs to — not of whatever device the calling thread has current
@@ -349,12 +349,9 @@ static int enqueue_cut(pbsgpu_engine *e, Slot &s, uint32_t cap) {
     }
     // one long stream, no suggested boundaries: follow the cut chain by pointer doubling (one workgroup, ~20 rounds)
     // instead of walking it chunk by chunk on one wave (4.6 ms per 64 GiB, 11 ms next to SHA waves)
-    static const bool par_off = getenv("PBSGPU_RESOLVE_SERIAL") != nullptr;
     constexpr uint32_t kParNodes = 1u << 18, kParLevels = 19;
-    static const uint64_t par_min = []() -> uint64_t {  // PBSGPU_RESOLVE_PAR_MIN: smallest stream that takes the parallel path
-        const char *v = getenv("PBSGPU_RESOLVE_PAR_MIN");
-        return v ? strtoull(v, nullptr, 10) : (64ull << 20);
-    }();
+    const uint64_t par_min = e->opt.resolve_par_min;  // smallest stream that takes the parallel path (~0: never)
+    const bool par_off = par_min == ~0ull;
     // expected candidates = 3 per (mask + 1) bytes; twice that is the node budget (dense / crafted inputs fall back)
     const uint64_t expect = (uint64_t)(3.0 * (double)s.nbytes / ((double)e->cfg.mask + 1.0)) + 64;
     uint32_t big_nodes = 0, big_levels = 0;
@@ -414,9 +411,9 @@ static int enqueue_hash(pbsgpu_engine *e, Slot &s) {
     // form of the hash kernel: issue-bound (dense) or chain-bound (sparse), from what the host knows at submit time —
     // the bytes of the batch and the longest chain the chunker can produce
     const uint64_t longest = std::min<uint64_t>(e->cfg.max, std::max<uint64_t>(s.nbytes, 1)) / 64 + 1;
-    const bool dense = pbsk::sha256_dense_pays(s.nbytes / 64, longest, e->num_cus);
+    const bool dense = pbsk::sha256_dense_pays(s.nbytes / 64, longest, e->num_cus, e->opt.sha_dense_pct);
     HIPCHK(pbsk::launch_sha256_records(s.recs.as<pbsgpu_record>(), sc + SC_NREC, sc + SC_QUEUE, s.order.as<uint4>(),
-                                       sc + SC_WGLIMIT, e->num_cus, dense, s.stream));
+                                       sc + SC_WGLIMIT, e->num_cus, dense, (int)e->opt.sha_form, s.stream));
     HIPCHK(hipEventRecord(s.ev[EV_SHA1], s.stream));
     return PBSGPU_OK;
 }
@@ -667,9 +664,58 @@ int pbsgpu_device_count(void) {
     return n;
 }
 
+// DEBUG overrides of pbsgpu_engine_options by environment (the variable names of rounds 1-5): ONE table, one getenv
+static void engine_env_overrides(pbsgpu_engine_options &o) {
+    enum Kind { U32, U32_ZERO_OFF, U64, F64, SHA_MODE, RESOLVE_SERIAL };
+    struct Entry {
+        const char *name;
+        Kind kind;
+        void *field;
+    };
+    const Entry table[] = {
+        {"PBSGPU_SHA_MODE", SHA_MODE, &o.sha_form},
+        {"PBSGPU_SHA_SLACK_PCT", U32, &o.sha_slack_pct},  // (value + 1, see below)
+        {"PBSGPU_SHA_DENSE_PCT", U32_ZERO_OFF, &o.sha_dense_pct},
+        {"PBSGPU_RESOLVE_PAR_MIN", U64, &o.resolve_par_min},
+        {"PBSGPU_RESOLVE_SERIAL", RESOLVE_SERIAL, &o.resolve_par_min},
+        {"PBSGPU_SHA_MANY_FILES_PER_CORE", U32, &o.sha_many_files_per_core},
+        {"PBSGPU_STREAM_SHA_CUS", U32, &o.stream_sha_cus},
+        {"PBSGPU_STREAM_XP_CUS", U32_ZERO_OFF, &o.stream_express_cus},
+        {"PBSGPU_STREAM_RING_SLOTS", U32, &o.stream_ring_slots},
+        {"PBSGPU_STREAM_CTX_POOL", U32_ZERO_OFF, &o.stream_ctx_pool},
+        {"PBSGPU_STREAM_RING_GIB", F64, &o.stream_ring_gib},
+        {"PBSGPU_STREAM_PAGE_BYTES", U64, &o.stream_page_bytes},
+    };
+    for (const Entry &e : table) {
+        const char *v = getenv(e.name);
+        if (!v || !*v) continue;
+        switch (e.kind) {
+        case U32:
+            *static_cast<uint32_t *>(e.field) = (uint32_t)std::max(0L, atol(v)) + (e.field == &o.sha_slack_pct ? 1u : 0u);
+            break;
+        case U32_ZERO_OFF: *static_cast<uint32_t *>(e.field) = atol(v) <= 0 ? 0xffffffffu : (uint32_t)atol(v); break;
+        case U64: *static_cast<uint64_t *>(e.field) = strtoull(v, nullptr, 10); break;
+        case F64: *static_cast<double *>(e.field) = std::max(0.0, atof(v)); break;
+        case SHA_MODE: *static_cast<uint32_t *>(e.field) = v[0] == 'l' ? 1u : v[0] == 'x' ? 2u : 0u; break;
+        case RESOLVE_SERIAL: *static_cast<uint64_t *>(e.field) = ~0ull; break;
+        }
+    }
+}
+
 int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight, pbsgpu_engine **out) {
+    pbsgpu_engine_options o{};
+    o.inflight = inflight;
+    return pbsgpu_engine_create_opt(device, cfg, &o, out);
+}
+
+int pbsgpu_engine_create_opt(int device, const pbsgpu_config *cfg, const pbsgpu_engine_options *opt, pbsgpu_engine **out) {
     if (!cfg || !out) return PBSGPU_E_INVALID;
     *out = nullptr;
+    pbsgpu_engine_options o{};
+    if (opt) o = *opt;
+    engine_env_overrides(o);
+    uint32_t inflight = o.inflight;
+    if (o.sha_form > 2) return PBSGPU_E_INVALID;
     // the candidate/resolve split needs: window 64, mask = 2^k - 1, min >= window, max > min
     if (cfg->window != pbsk::kWindow) return PBSGPU_E_INVALID;
     const uint64_t m1 = (uint64_t)cfg->mask + 1;
@@ -714,10 +760,19 @@ int pbsgpu_engine_create(int device, const pbsgpu_config *cfg, uint32_t inflight
         if (hipMalloc(reinterpret_cast<void **>(&e->d_table_rot), sizeof(rot)) != hipSuccess) { st = PBSGPU_E_NOMEM; break; }
         if (hipMemcpy(e->d_table_rot, rot, sizeof(rot), hipMemcpyHostToDevice) != hipSuccess) { st = PBSGPU_E_HIP; break; }
         e->sha_slack_pct = inflight > 4 ? 0u : 25u;
-        if (const char *sl = getenv("PBSGPU_SHA_SLACK_PCT")) {  // experiments
-            const int v = atoi(sl);
-            if (v >= 0 && v <= 400) e->sha_slack_pct = (uint32_t)v;
-        }
+        if (o.sha_slack_pct) e->sha_slack_pct = std::min(o.sha_slack_pct - 1u, 400u);
+        // every default resolved once: the rest of the library reads e->opt
+        if (o.sha_dense_pct == 0) o.sha_dense_pct = 150;
+        if (o.sha_dense_pct == 0xffffffffu) o.sha_dense_pct = 0;
+        if (o.resolve_par_min == 0) o.resolve_par_min = 64ull << 20;
+        if (o.sha_many_files_per_core == 0) o.sha_many_files_per_core = 55;
+        if (o.stream_ring_slots == 0) o.stream_ring_slots = 256;
+        o.stream_ring_slots = std::max(4u, std::min(o.stream_ring_slots, 4096u));
+        if (o.stream_ctx_pool == 0) o.stream_ctx_pool = 8;
+        if (o.stream_ctx_pool == 0xffffffffu) o.stream_ctx_pool = 0;
+        if (o.stream_ring_gib <= 0) o.stream_ring_gib = 48.0;
+        o.inflight = inflight;
+        e->opt = o;
         for (uint32_t i = 0; i < inflight && st == PBSGPU_OK; ++i) {
             e->slots.emplace_back(new (std::nothrow) Slot());
             st = e->slots.back() ? e->slots.back()->init() : PBSGPU_E_NOMEM;
@@ -788,10 +843,7 @@ int pbsgpu_engine_trim(pbsgpu_engine *e, uint64_t *freed_bytes) {
 // be ~50x slower than the code it replaces, so bindings ask first.
 int pbsgpu_sha256_many_pays(const pbsgpu_engine *e, uint32_t nfiles, uint32_t host_cores, int *pays) {
     if (!e || !pays) return PBSGPU_E_INVALID;
-    static const uint32_t per_core = []() -> uint32_t {
-        const char *v = getenv("PBSGPU_SHA_MANY_FILES_PER_CORE");
-        return (uint32_t)std::max(1, v ? atoi(v) : 55);
-    }();
+    const uint32_t per_core = std::max(1u, e->opt.sha_many_files_per_core);
     if (host_cores == 0) host_cores = 1;
     *pays = (uint64_t)nfiles > (uint64_t)per_core * host_cores ? 1 : 0;
     return PBSGPU_OK;
@@ -1035,7 +1087,8 @@ static int sha256_many(pbsgpu_engine *e, const void *ptr, bool host, uint64_t nb
     }
     HIPCHK(pbsk::launch_sha256_segments(d, s->segs.as<pbsgpu_segment>(), nseg, s->recs.as<uint8_t>(),
                                         s->scalars.as<uint32_t>() + SC_QUEUE, e->num_cus,
-                                        pbsk::sha256_dense_pays(total_blocks, longest, e->num_cus), s->stream));
+                                        pbsk::sha256_dense_pays(total_blocks, longest, e->num_cus, e->opt.sha_dense_pct),
+                                        (int)e->opt.sha_form, s->stream));
     return fetch_result(s, digests, s->recs.p, (size_t)nseg * 32);
 }
 

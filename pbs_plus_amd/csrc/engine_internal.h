@@ -203,6 +203,7 @@ struct pbsgpu_engine {
     // SHA workgroup budget slack (k_order): 25 % keeps one batch's makespan at its longest chunk; with more
     // than 4 batches in flight the chip is oversubscribed anyway and 0 % (fewest CUs per batch) carries more
     uint32_t sha_slack_pct = 25;
+    pbsgpu_engine_options opt{};  // as given to pbsgpu_engine_create_opt, defaults resolved (engine.cpp: resolve_engine_options)
     pbsgpu_config cfg{};
     uint32_t bits = 0;     // mask == 2^bits - 1
     uint32_t thr = 0;      // break_min << (32 - bits)

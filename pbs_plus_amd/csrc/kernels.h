@@ -10,11 +10,7 @@
 namespace pbsk {
 
 // ---- Buzhash candidate scan geometry -------------------------------------------------
-// One wave owns one "wave tile" of 64 lanes x STRIP bytes; STRIP/16 is odd so the
-// per-lane ds_read_b128 of the LDS-staged tile is bank-conflict free.
-constexpr int kScanStrip = 240;                   // bytes per lane
-constexpr int kScanWaves = 8;                     // waves per workgroup (2 per SIMD)
-constexpr int kScanTile = 64 * kScanStrip;        // 15360 bytes per wave tile
+// One wave owns one "wave tile" of 64 lanes x (LINES x 128) bytes (k_scan3: LINES = 34 -> 278 528 B, 4 -> 32 768 B).
 constexpr int kWindow = 64;
 
 struct ScanParams {
@@ -27,7 +23,7 @@ struct ScanParams {
     uint32_t thr;             // break_min << (32 - bits)
     uint32_t cap;             // slots per tile
     uint32_t *tile_cnt;       // [ntiles] true count (may exceed cap)
-    uint32_t *tile_slots;     // [ntiles * cap] end offset within tile (1..kScanTile), a-coords
+    uint32_t *tile_slots;     // [ntiles * cap] end offset within tile (1..tile_bytes), a-coords
     unsigned long long *tile_queue;  // device counter, zero at launch: next tile to hand out
     uint32_t tiles_per_wave;         // k_scan3: 0 = persistent workgroups, else a wave retires after this many tiles
     uint32_t shared_chip;            // other batches of the engine are in flight (their SHA chains are running)
@@ -143,8 +139,9 @@ hipError_t launch_resolve_single(const uint64_t *cands, const uint32_t *ncand, c
 
 // SHA-256 of every record's chunk: one lane per chunk, lanes pull records from a shared queue.
 // `queue` is a device uint32 that must be zero at launch.
+// (`form`: pbsgpu_engine_options::sha_form — 0 wave pairs, 1 single-wave lanes, 2 express)
 hipError_t launch_sha256_records(pbsgpu_record *recs, const uint32_t *nrec, uint32_t *queue, const uint4 *qdesc,
-                                 const uint32_t *wg_limit, int num_cus, bool dense, hipStream_t st);
+                                 const uint32_t *wg_limit, int num_cus, bool dense, int form, hipStream_t st);
 // longest-first queue order (counting sort by size class) + workgroup budget for the SHA kernel:
 // lanes = (1 + slack_pct/100) x total blocks / longest chunk's blocks
 // (writes the queue as 16-byte descriptors {address lo, hi, size, record index}: kQueueDescBytes per record)
@@ -154,10 +151,10 @@ hipError_t launch_order(const uint8_t *data, const pbsgpu_segment *segs, const p
                         hipStream_t st);
 // true when a hash launch of `total_blocks` 64-byte blocks whose longest item has `longest_blocks` is bound by issue
 // slots rather than by that longest chain (the device-side twin of this test lives in k_order)
-bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus);
+bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus, uint32_t dense_pct);
 // SHA-256 of whole segments (verification path): digests[32*i] for segs[i]
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg,
-                                  uint8_t *digests, uint32_t *queue, int num_cus, bool dense, hipStream_t st);
+                                  uint8_t *digests, uint32_t *queue, int num_cus, bool dense, int form, hipStream_t st);
 
 // XXH3-64 (seed 0) of whole segments: out[i] for segs[i]; `queue` zero at launch
 // XXH3-64 (seed 0), two phases (kernels.hip): every 1 KiB block of every input is summed by some wave of the grid

@@ -26,349 +26,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// PBSGPU_SCAN_MODE selects the scan kernel for A/B measurements: default = cooperative loads (k_scan3);
-// "stream" = per-lane register streaming (k_scan2); "lds" = LDS-tiled (k_scan)
-static int scan_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("PBSGPU_SCAN_MODE");
-        mode = (e && e[0] == 'l') ? 0 : (e && e[0] == 's') ? 1 : 2;  // lds | stream | (default) coop
-    }
-    return mode;
-}
-
 // =====================================================================================
 // (1) Buzhash candidate scan
 // =====================================================================================
-// h(i) = XOR_{k=0..63} rotl(T[b[i-k]], k mod 32). With the running prefix
-// P(i) = rotl(P(i-1),1) ^ T[b[i]] this is h(i) = P(i) ^ P(i-64) (64 = 0 mod 32), so a
-// lane that keeps the last 64 prefixes in registers needs ONE table lookup per byte.
-// The table is pre-rotated by r = 32-bits on the host: rotation commutes with the
-// recurrence, and (h & mask) >= break_min becomes the single unsigned compare
-// rotl(h,r) >= break_min << r, so no AND is needed per byte.
-// LDS: the 256-entry table replicated 32x ([entry][lane&31]) so every lane of a
-// ds_read_b32 group hits its own bank regardless of the data byte.
-template <int S, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_scan(ScanParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int REGION = kWindow + 64 * S;  // bytes staged per wave (halo + tile), multiple of 16
-    static_assert(S % 16 == 0 && ((S / 16) & 1) == 1, "strip must be an odd number of 16-byte slots");
-    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);  // [256][32]
-    uint8_t *regions = smem + 256 * 32 * 4;
-    uint32_t *counters = reinterpret_cast<uint32_t *>(regions + WAVES * REGION);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 256 * 32; i += WAVES * 64) tab[i] = p.table_rot[i >> 5];
-    __syncthreads();
-
-    uint8_t *reg = regions + wave * REGION;
-    uint32_t *wcnt = counters + wave;
-    const uint32_t *tl = tab + (lane & 31);
-    const uint64_t A = p.nbytes + p.lead;  // extent in aligned ("a") coordinates
-    const uint32_t thr = p.thr;
-
-    // Tiles are handed out dynamically (a wave grabs kGrab consecutive tiles per atomic): when other
-    // batches' kernels occupy part of the chip, the workgroups that ARE resident drain all tiles and
-    // late workgroups find none, so the kernel's duration tracks the CUs it actually got.
-    constexpr uint32_t kGrab = 8;
-    uint64_t t = 0, t_end = 0;
-    for (;;) {
-        if (t == t_end) {
-            unsigned long long g = 0;
-            if (lane == 0) g = atomicAdd(p.tile_queue, (unsigned long long)kGrab);
-            t = __shfl(g, 0, 64);
-            if (t >= p.ntiles) break;
-            t_end = min(t + kGrab, p.ntiles);
-        }
-        const uint64_t wbase = t * (uint64_t)(64 * S);
-        if (lane == 0) *wcnt = 0;
-        // stage [wbase-64, wbase+64*S): coalesced 16-byte pieces, zero outside the buffer
-        constexpr int PIECES = REGION / 16;
-#pragma unroll 4
-        for (int j0 = 0; j0 < PIECES; j0 += 64) {
-            const int j = j0 + lane;
-            if (j < PIECES) {
-                const int64_t a = (int64_t)wbase - kWindow + (int64_t)j * 16;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (a >= 0 && (uint64_t)a < A) v = *reinterpret_cast<const uint4 *>(p.data_al + a);
-                *reinterpret_cast<uint4 *>(reg + j * 16) = v;
-            }
-        }
-        wave_sync();
-
-        const uint8_t *sp = reg + lane * S;
-        uint32_t ring[64];
-        uint32_t P = 0;
-        // warm-up: the 64 bytes before the strip (previous lane's tail / halo)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sp + 16 * g);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                P = __builtin_rotateleft32(P, 1) ^ tl[b * 32];
-                ring[g * 16 + k] = P;
-            }
-        }
-        // one 16-byte group: 16 lookups, 16 window hashes, one rare-path test
-        auto group16 = [&](const int gq /*group index within a 64-byte round: static*/, const uint32_t goff) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(sp + kWindow + goff);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            uint32_t h[16];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                P = __builtin_rotateleft32(P, 1) ^ tl[b * 32];
-                const int ri = gq * 16 + k;
-                h[k] = P ^ ring[ri];
-                ring[ri] = P;
-                acc = max(acc, h[k]);
-            }
-            if (acc >= thr) {  // rare: at least one of these 16 positions is a candidate
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (h[k] >= thr) {
-                        const uint32_t off = (uint32_t)(lane * S) + goff + (uint32_t)k + 1u;  // exclusive end in tile
-                        const uint64_t ea = wbase + off;
-                        if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
-                            const uint32_t slot = atomicAdd(wcnt, 1u);
-                            if (slot < p.cap) p.tile_slots[t * p.cap + slot] = off;
-                        }
-                    }
-                }
-            }
-        };
-        constexpr int ROUNDS = S / 64, REM = (S % 64) / 16;
-#pragma unroll 1
-        for (int r = 0; r < ROUNDS; ++r) {  // runtime loop keeps the ring indices static and the live set small
-            const uint32_t roff = (uint32_t)r * 64u;
-            group16(0, roff);
-            group16(1, roff + 16u);
-            group16(2, roff + 32u);
-            group16(3, roff + 48u);
-        }
-#pragma unroll
-        for (int g = 0; g < REM; ++g) group16(g, (uint32_t)(ROUNDS * 64 + g * 16));
-        wave_sync();
-        if (lane == 0) p.tile_cnt[t] = *wcnt;
-        wave_sync();
-        ++t;
-    }
-}
-
+// h(i) = XOR_{k=0..63} rotl(T[b[i-k]], k mod 32): a pure function of the last 64 bytes, so every position is tested
+// independently. The table is pre-rotated by r = 32-bits on the host: rotation commutes with the recurrence, and
+// (h & mask) >= break_min becomes the single unsigned compare rotl(h,r) >= break_min << r, so no AND is needed per byte.
+// (Rounds 1-5 kept two earlier kernels selectable for A/B runs — an LDS-tiled one, 2.28 TB/s, and a per-lane register
+// streaming one, 4.36 TB/s: docs/NOTES.md. Gone with round 6: k_scan3 below is the scan.)
 // -------------------------------------------------------------------------------------
-// Candidate scan, register-streaming form (default). Measured on gfx950: a SIMD issues one
-// wave64 integer VALU op per ~4.2 cycles whatever its occupancy (39 T lane-ops/s chip-wide), so
-// the scan is HBM-bound only below ~5 VALU ops per byte. This form gets there by
-//  * no LDS tile: every lane streams its own long strip (LINES x 128 B) straight from HBM in
-//    full 128-byte lines (8 back-to-back dwordx4 loads -> the line is consumed while still in
-//    L1), next line prefetched into a second register set (ping-pong);
-//  * warm-up (64 B) amortised over LINES*128 bytes: 1.5 % at LINES = 34 (vs 27 % for 240-byte strips);
-//  * table replicated 64x ([entry][lane], 64 KiB, table at LDS offset 0): the lookup address
-//    (byte << 8) | (lane << 2) is ONE v_perm_b32, and every lane owns its bank;
-//  * per byte: v_perm, ds_read_b32, v_alignbit, v_xor (prefix), v_xor (window hash), 1/2 v_max3.
-// Lane strips are 4352 B apart (34 lines: even for the ping-pong, not a power of two).
-#ifndef PBS_SCAN_THREADS
-#define PBS_SCAN_THREADS 512
-#endif
-#ifndef PBS_SCAN_WPS
-#define PBS_SCAN_WPS 2
-#endif
-#ifndef PBS_SCAN_NBUF
-#define PBS_SCAN_NBUF 2
-#endif
-template <int LINES, int NBUF>
-__global__ __launch_bounds__(PBS_SCAN_THREADS, PBS_SCAN_WPS) void k_scan2(ScanParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    static_assert(NBUF >= 1 && NBUF <= 3, "1 (no register prefetch), 2 or 3 rotating line buffers");
-    static_assert(LINES % NBUF == 0, "strip must be a whole number of buffer rotations");
-    constexpr uint32_t SL = LINES * 128;          // strip bytes per lane
-    constexpr uint64_t TILE = 64ull * SL;         // bytes per wave tile
-    // static => the compiler knows the table's LDS address and folds it into the ds_read
-    __shared__ __attribute__((aligned(1024))) uint32_t tab[256 * 64];  // [entry][lane]
-    uint32_t *counters = reinterpret_cast<uint32_t *>(smem);           // dynamic part: counters (+ residency pad)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 256 * 64; i += PBS_SCAN_THREADS) tab[i] = p.table_rot[i >> 6];
-    __syncthreads();
-
-    uint32_t *wcnt = counters + wave;
-    const uint64_t A = p.nbytes + p.lead;
-    const uint32_t thr = p.thr;
-    const uint32_t lane4 = (uint32_t)lane << 2;
-    const uint8_t *lds0 = reinterpret_cast<const uint8_t *>(tab);
-
-    // table lookup of byte k (0..3) of dword w: address = (byte << 8) | lane*4
-#define PBS_LOOKUP(w, k) \
-    (*reinterpret_cast<const uint32_t *>(lds0 + __builtin_amdgcn_perm((w), lane4, 0x0c0c0400u | ((uint32_t)(k) << 8))))
-
-    for (;;) {
-        unsigned long long g0 = 0;
-        if (lane == 0) g0 = atomicAdd(p.tile_queue, 1ull);
-        const uint64_t t = __shfl(g0, 0, 64);
-        if (t >= p.ntiles) break;
-        const uint64_t t_idx = t;
-        const uint64_t wbase = t * TILE;
-        const uint64_t sbase = wbase + (uint64_t)lane * SL;  // a-coordinate of this lane's strip
-        if (lane == 0) *wcnt = 0;
-        wave_sync();
-
-        auto load16 = [&](uint64_t a) -> uint4 {  // 16 bytes at a-coordinate a (zero outside the buffer)
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (a < A) v = *reinterpret_cast<const uint4 *>(p.data_al + a);
-            return v;
-        };
-
-        uint32_t ring[64];
-        uint32_t P = 0;
-        {   // warm-up: the 64 bytes before the strip
-            uint4 wv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) wv[g] = (sbase >= 64) ? load16(sbase - 64 + 16 * g) : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint32_t w[4] = {wv[g].x, wv[g].y, wv[g].z, wv[g].w};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    P = __builtin_rotateleft32(P, 1) ^ PBS_LOOKUP(w[k >> 2], k & 3);
-                    ring[g * 16 + k] = P;
-                }
-            }
-        }
-
-        // 128 bytes = 16 batches of 8 table lookups, software-pipelined: the lookups of batch j+1 are issued
-        // before batch j is consumed and ONE s_waitcnt lgkmcnt(8) covers a whole batch (the compiler's default is a
-        // counted wait in front of every single use: ~1 extra issue slot per byte)
-        auto process_line = [&](const uint4 (&X)[8], const uint32_t line) {
-            uint32_t tv[2][8];
-            auto issue = [&](const int batch, uint32_t (&dst)[8]) {
-                const uint4 &v = X[batch >> 1];
-                const uint32_t w0 = (batch & 1) ? v.z : v.x, w1 = (batch & 1) ? v.w : v.y;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dst[k] = PBS_LOOKUP(w0, k);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dst[4 + k] = PBS_LOOKUP(w1, k);
-            };
-            issue(0, tv[0]);
-            uint32_t h[16];
-            uint32_t acc = 0;
-#pragma unroll
-            for (int batch = 0; batch < 16; ++batch) {
-                if (batch < 15) {
-                    issue(batch + 1, tv[(batch + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);   // keep "issue next, wait once, consume" as written
-                    __builtin_amdgcn_s_waitcnt(0xC87F);  // lgkmcnt(8): everything but the 8 newest lookups has landed
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const uint32_t(&t)[8] = tv[batch & 1];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int pos = batch * 8 + k;       // byte within the line
-                    const int hk = pos & 15;
-                    const uint32_t rp = __builtin_rotateleft32(P, 1);
-                    const int ri = pos & 63;
-                    h[hk] = __builtin_amdgcn_bitop3_b32(rp, t[k], ring[ri], 0x96);  // P_new ^ P_old(-64)
-                    P = rp ^ t[k];
-                    ring[ri] = P;
-                    acc = max(acc, h[hk]);
-                }
-                if (batch & 1) {  // end of a 16-byte group
-                    if (acc >= thr) {  // rare
-                        const int g = batch >> 1;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            if (h[k] >= thr) {
-                                const uint64_t ea = sbase + (uint64_t)line * 128u + (uint32_t)(g * 16 + k + 1);
-                                if (ea >= (uint64_t)p.lead + kWindow && ea <= A) {
-                                    const uint32_t slot = atomicAdd(wcnt, 1u);
-                                    if (slot < p.cap) p.tile_slots[t_idx * p.cap + slot] = (uint32_t)(ea - wbase);
-                                }
-                            }
-                        }
-                    }
-                    acc = 0;
-                }
-            }
-        };
-        // interior tiles (every lane's strip fully inside the buffer) load without per-piece bounds tests:
-        // the predicate is wave-uniform, so it costs one scalar branch per line instead of 8 exec-mask dances
-        const bool interior = __all(sbase + SL <= A);
-        auto load_line = [&](uint4 (&X)[8], const uint32_t line) {
-            const uint64_t a = sbase + (uint64_t)line * 128u;
-            if (interior) {
-                const uint4 *q = reinterpret_cast<const uint4 *>(p.data_al + a);
-#pragma unroll
-                for (int g = 0; g < 8; ++g) X[g] = q[g];
-            } else {
-#pragma unroll
-                for (int g = 0; g < 8; ++g) X[g] = load16(a + 16 * g);
-            }
-        };
-
-        if (sbase < A) {
-            if constexpr (NBUF == 1) {  // no register prefetch: latency is hidden by the other waves on the SIMD
-                uint4 L0[8];
-#pragma unroll 1
-                for (uint32_t line = 0; line < (uint32_t)LINES; ++line) {
-                    load_line(L0, line);
-                    process_line(L0, line);
-                }
-            } else if constexpr (NBUF == 2) {
-                uint4 L0[8], L1[8];
-                load_line(L0, 0);
-#pragma unroll 1
-                for (uint32_t line = 0; line < (uint32_t)LINES; line += 2) {
-                    load_line(L1, line + 1);
-                    process_line(L0, line);
-                    if (line + 2 < (uint32_t)LINES) load_line(L0, line + 2);
-                    process_line(L1, line + 1);
-                }
-            } else {  // two lines in flight ahead of the one being hashed
-                uint4 L0[8], L1[8], L2[8];
-                load_line(L0, 0);
-                load_line(L1, 1);
-#pragma unroll 1
-                for (uint32_t line = 0; line < (uint32_t)LINES; line += 3) {
-                    load_line(L2, line + 2);
-                    process_line(L0, line);
-                    if (line + 3 < (uint32_t)LINES) load_line(L0, line + 3);
-                    process_line(L1, line + 1);
-                    if (line + 4 < (uint32_t)LINES) load_line(L1, line + 4);
-                    process_line(L2, line + 2);
-                }
-            }
-        }
-        wave_sync();
-        if (lane == 0) p.tile_cnt[t] = *wcnt;
-        wave_sync();
-    }
-#undef PBS_LOOKUP
-}
-
-template <int LINES, int NBUF>
-static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st) {
-    // counters + pad (64 KiB table is static): keeps SHA workgroups off this CU; 15 KiB lets two 384-thread
-    // workgroups share a CU
-    constexpr size_t lds = 64 + ((PBS_SCAN_THREADS == 384) ? (15u << 10) : (16u << 10));
-    {   // per launch, not once per process: the attribute is per device
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan2<LINES, NBUF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    constexpr unsigned wpb = PBS_SCAN_THREADS / 64;
-    uint64_t blocks = (p.ntiles + wpb - 1) / wpb;
-    const uint64_t maxb = (uint64_t)num_cus * ((PBS_SCAN_THREADS == 384) ? 2 : 1);
-    if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL((k_scan2<LINES, NBUF>), dim3((unsigned)blocks), dim3(PBS_SCAN_THREADS), lds, st, p);
-    return hipGetLastError();
-}
-
-// -------------------------------------------------------------------------------------
-// Candidate scan, cooperative-load form. k_scan2's per-lane streaming is bound by the texture addresser
+// Candidate scan, cooperative-load form. Per-lane streaming of whole lines is bound by the texture addresser
 // (64 distinct 128-byte lines per load instruction: 4.14 TB/s for pure loads, profiles/
 // r01_ubench_load_pattern_ceiling.log), so here the four lanes of a quad fetch 64 CONTIGUOUS bytes of one
 // strip per instruction (16 lines per instruction; 6.0 TB/s ceiling) and a small per-wave LDS stage
@@ -377,7 +44,7 @@ static hipError_t launch_scan2(const ScanParams &p, int num_cus, hipStream_t st)
 // conflict-free). A half-line is exactly one revolution of the 64-entry window ring, so ring indices
 // stay static. D half-lines per wave are kept in flight (D x 4 KiB: memory-level parallelism). The hash
 // runs in rolling form over two alternating rings of table values (see scan3_tile); pre-rotated 64x
-// replicated table, batched lookups and slot lists as in k_scan2.
+// replicated table (every lane of a ds_read_b32 hits its own bank whatever the data byte), batched lookups, per-tile slot lists.
 // Index algebra restated on CPU: tests/helpers.py::scan_coop_model.
 #define PBS_LOOKUP3(w, k) \
     (*reinterpret_cast<const uint32_t *>(lds0 + __builtin_amdgcn_perm((w), lane4, 0x0c0c0400u | ((uint32_t)(k) << 8))))
@@ -566,35 +233,6 @@ __global__ __launch_bounds__(512, 2) void k_scan3(ScanParams p) {
 }
 #undef PBS_LOOKUP3
 
-// PBSGPU_SCAN_CU_RESERVE: CUs the cooperative scan leaves free (default 16 of 256)
-static int scan_cu_reserve(int num_cus) {
-    static const int v = []() {
-        const char *e = getenv("PBSGPU_SCAN_CU_RESERVE");
-        return e ? atoi(e) : -1;
-    }();
-    if (v >= 0) return std::min(v, num_cus - 1);
-    return num_cus >= 64 ? 16 : 0;
-}
-
-// PBSGPU_SCAN_CUS_SHARED: CUs the scan may take while OTHER batches are hashing (0 = no extra limit). A scan at full
-// tilt pulls the chip clock down and with it every running SHA chain (+21-40 % chain time on 240 CUs, +3.5 % on 64,
-// scripts/r2_probe_clock.py); the SHA chains are the critical path of every pass in flight, the scan is not.
-static int scan_cus_shared() {
-    static const int v = []() {
-        const char *e = getenv("PBSGPU_SCAN_CUS_SHARED");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
-}
-
-static uint32_t scan_tiles_per_wave() {
-    static const int v = []() {
-        const char *e = getenv("PBSGPU_SCAN_TILES_PER_WAVE");
-        return e ? atoi(e) : 0;
-    }();
-    return v > 0 ? (uint32_t)v : 0u;
-}
-
 template <int LINES, int D>
 static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st) {
     constexpr size_t lds = 64 + 8 * 64 * 80;  // counters + 8 per-wave stages (40 KiB: also keeps SHA workgroups off this CU)
@@ -605,84 +243,31 @@ static hipError_t launch_scan3(const ScanParams &p, int num_cus, hipStream_t st)
     // A scan workgroup fills its CU completely (244 VGPRs x 2 waves per SIMD, 104 KiB LDS). With PERSISTENT workgroups
     // (one per CU draining the tile queue) no other kernel can place a single wave anywhere for the 15-25 ms of a 64 GiB
     // scan — measured with 4 batches in flight: the small resolve-chain kernels of the OTHER batches took 11 ms instead
-    // of 0.4-4.9 and their SHA launches started ~24 ms late. Two remedies, both switchable: a few CUs never taken
-    // (PBSGPU_SCAN_CU_RESERVE, default 16), and workgroups that retire after a few tiles so that the dispatcher
-    // interleaves everyone else (PBSGPU_SCAN_TILES_PER_WAVE, default 0 = persistent: measured with 4 batches in flight
-    // the resolve chains drop from 13 to 9 ms but the scans stretch from 25 to 40 ms, no net gain — what stretches the
-    // SHA launches under overlap is not placement but the chip clock under the scan's power draw).
-    ScanParams q = p;
-    q.tiles_per_wave = scan_tiles_per_wave();
-    if (q.tiles_per_wave) {
-        blocks = (p.ntiles + 8ull * q.tiles_per_wave - 1) / (8ull * q.tiles_per_wave);
-    } else {
-        uint64_t usable = (uint64_t)std::max(1, num_cus - scan_cu_reserve(num_cus));
-        if (p.shared_chip && scan_cus_shared() > 0) usable = std::min<uint64_t>(usable, (uint64_t)scan_cus_shared());
-        if (blocks > usable) blocks = usable;
-    }
+    // of 0.4-4.9 and their SHA launches started ~24 ms late. Hence a few CUs are never taken (16 of 256). (Workgroups that
+    // retire after a few tiles so that the dispatcher interleaves everyone else were measured too: the resolve chains drop
+    // from 13 to 9 ms but the scans stretch from 25 to 40 ms, no net gain — ScanParams::tiles_per_wave stays 0.)
+    const uint64_t usable = (uint64_t)std::max(1, num_cus - (num_cus >= 64 ? 16 : 0));
+    if (blocks > usable) blocks = usable;
     if (p.max_blocks && blocks > p.max_blocks) blocks = p.max_blocks;
-    hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, q);
+    hipLaunchKernelGGL((k_scan3<LINES, D>), dim3((unsigned)blocks), dim3(512), lds, st, p);
     return hipGetLastError();
 }
 
-// PBSGPU_SCAN_DEPTH (coop mode): half-lines in flight per wave, 4 (default) | 2 (even: the two rings alternate)
-static int scan_depth() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("PBSGPU_SCAN_DEPTH");
-        v = e ? atoi(e) : 4;
-        if (v != 2 && v != 4) v = 4;
-    }
-    return v;
-}
-
+// half-lines in flight per wave: 4 (at 2 the kernel measured 4.66 instead of 4.90 TB/s, at 1 it is latency-bound: 3.96)
 template <int LINES>
 static hipError_t launch_scan3_any(const ScanParams &p, int num_cus, hipStream_t st) {
-    switch (scan_depth()) {
-    case 2: return launch_scan3<LINES, 2>(p, num_cus, st);
-    default: return launch_scan3<LINES, 4>(p, num_cus, st);
-    }
-}
-
-// PBSGPU_SCAN_VARIANT (experiments): 0 = 34 lines/2 buffers, 1 = 36/3, 2 = 66/2, 3 = 72/3
-static int scan_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("PBSGPU_SCAN_VARIANT");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 3) v = 0;
-    }
-    return v;
+    return launch_scan3<LINES, 4>(p, num_cus, st);
 }
 
 uint32_t scan_tile_bytes(uint64_t nbytes) {
-    if (scan_mode() == 0) return kScanTile;
-    if (nbytes < (48ull << 20)) return 64u * 4u * 128u;
-    constexpr uint32_t lines[4] = {34, 36, 66, 72};
-    return 64u * lines[scan_variant()] * 128u;
+    return nbytes < (48ull << 20) ? 64u * 4u * 128u : 64u * 34u * 128u;  // (small batches: small tiles, so that the chip fills)
 }
 
 hipError_t launch_scan(const ScanParams &p, int num_cus, hipStream_t st) {
     if (p.ntiles == 0) return hipSuccess;
-    if (p.tile_bytes == 64u * 34u * 128u) {
-        if (scan_mode() == 2) return launch_scan3_any<34>(p, num_cus, st);
-        return (PBS_SCAN_NBUF == 1) ? launch_scan2<34, 1>(p, num_cus, st) : launch_scan2<34, 2>(p, num_cus, st);
-    }
-    if (p.tile_bytes == 64u * 36u * 128u) return launch_scan2<36, 3>(p, num_cus, st);
-    if (p.tile_bytes == 64u * 66u * 128u) return launch_scan2<66, 2>(p, num_cus, st);
-    if (p.tile_bytes == 64u * 72u * 128u) return launch_scan2<72, 3>(p, num_cus, st);
-    if (p.tile_bytes == 64u * 4u * 128u)
-        return (scan_mode() == 2) ? launch_scan3_any<4>(p, num_cus, st) : launch_scan2<4, 2>(p, num_cus, st);
-    constexpr int S = kScanStrip, W = kScanWaves;
-    constexpr size_t lds = 256 * 32 * 4 + (size_t)W * (kWindow + 64 * S) + W * 4 + 32;
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<S, W>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    uint64_t blocks = (p.ntiles + W - 1) / W;
-    if (blocks > (uint64_t)num_cus) blocks = (uint64_t)num_cus;  // persistent: one workgroup per CU
-    hipLaunchKernelGGL((k_scan<S, W>), dim3((unsigned)blocks), dim3(W * 64), lds, st, p);
-    return hipGetLastError();
+    if (p.tile_bytes == 64u * 34u * 128u) return launch_scan3_any<34>(p, num_cus, st);
+    if (p.tile_bytes == 64u * 4u * 128u) return launch_scan3_any<4>(p, num_cus, st);
+    return hipErrorInvalidValue;
 }
 
 // =====================================================================================
@@ -2647,23 +2232,12 @@ __global__ __launch_bounds__(1024) void k_order(const uint8_t *data, const pbsgp
     }
 }
 
-// PBSGPU_SHA_DENSE_PCT: work per pair-mode lane, in percent of the longest chain, from which the SHA kernel runs its
-// dense (4 pairs per CU) form; 0 = never
-static uint32_t sha_dense_pct() {
-    static long pct = -1;
-    if (pct < 0) {
-        const char *e = getenv("PBSGPU_SHA_DENSE_PCT");
-        pct = e ? atol(e) : 150;
-        if (pct < 0) pct = 0;
-    }
-    return (uint32_t)pct;
-}
-
-bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus) {
-    const uint32_t pct = sha_dense_pct();
-    if (!pct) return false;
+// dense_pct: work per pair-mode lane, in percent of the longest chain, from which the SHA kernel runs its dense (4 pairs
+// per CU) form; 0 = never (pbsgpu_engine_options::sha_dense_pct, default 150)
+bool sha256_dense_pays(uint64_t total_blocks, uint64_t longest_blocks, int num_cus, uint32_t dense_pct) {
+    if (!dense_pct) return false;
     if (longest_blocks < 1) longest_blocks = 1;
-    return total_blocks * 100ull > (uint64_t)pct * longest_blocks * 128ull * (uint64_t)num_cus;
+    return total_blocks * 100ull > (uint64_t)dense_pct * longest_blocks * 128ull * (uint64_t)num_cus;
 }
 
 hipError_t launch_order(const uint8_t *data, const pbsgpu_segment *segs, const pbsgpu_record *recs, const uint32_t *nrec,
@@ -2679,14 +2253,8 @@ hipError_t launch_order(const uint8_t *data, const pbsgpu_segment *segs, const p
 // Dynamic-LDS padding: a wave already saturates its SIMD's integer issue rate (one wave64 VALU op
 // per ~4 cycles), so a co-resident wave halves the speed of the serial chain. Requesting LDS the
 // kernel never touches caps residency at one wave per SIMD (2 pairs / 4 single waves per CU).
-static size_t sha_lds_pad(size_t dflt) {
-    static long pad = -2;
-    if (pad == -2) {
-        const char *e = getenv("PBSGPU_SHA_LDS_PAD");
-        pad = e ? atol(e) : -1;
-    }
-    return pad >= 0 ? (size_t)pad : dflt;
-}
+constexpr size_t kPairLdsPad = 16u << 10;  // ~69 KB static + 16 KB > 80 KB -> exactly one pair workgroup per CU
+constexpr size_t kLaneLdsPad = 36u << 10;  // four single-wave workgroups per CU
 
 template <typename K>
 static hipError_t allow_lds(K kernel, size_t bytes) {
@@ -2694,21 +2262,12 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
                                (int)bytes);
 }
 
-// PBSGPU_SHA_MODE=lane selects the single-wave kernel, =xpair the express form (two lanes per chunk) for EVERY chunk of
-// the batch path (A/B measurements, and the parity tests of those kernels); default = wave pairs
-static int sha_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("PBSGPU_SHA_MODE");
-        mode = (e && e[0] == 'l') ? 0 : (e && e[0] == 'x') ? 2 : 1;
-    }
-    return mode;
-}
-
+// `form` (pbsgpu_engine_options::sha_form): 0 = wave pairs (default), 1 = the single-wave kernel, 2 = the express form (two
+// lanes per chunk) for EVERY chunk of the batch path — A/B measurements and the parity tests of those kernels
 // host-decided form (descriptor jobs, whole-segment hashing): exactly one launch
 template <typename Source>
-static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source src, uint32_t nitems, uint32_t *queue) {
-    if (sha_mode() == 2) {  // (131 KB static LDS: one workgroup per CU without padding)
+static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source src, uint32_t nitems, uint32_t *queue, int form) {
+    if (form == 2) {  // (131 KB static LDS: one workgroup per CU without padding)
         hipLaunchKernelGGL((k_sha256_xpair<Source>), dim3(grid * (dense ? 4u : 2u)), dim3(256), 0, st, src, (const uint32_t *)nullptr,
                            nitems, queue, (const uint32_t *)nullptr);
         return hipGetLastError();
@@ -2717,7 +2276,7 @@ static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source 
         hipLaunchKernelGGL((k_sha256_pair<Source, true>), dim3(grid), dim3(512), 0, st, src, (const uint32_t *)nullptr,
                            nitems, queue, (const uint32_t *)nullptr);
     } else {
-        const size_t pad = sha_lds_pad(16u << 10);  // ~69 KB static + 16 KB > 80 KB -> exactly one workgroup per CU
+        const size_t pad = kPairLdsPad;
         hipError_t e = allow_lds(&k_sha256_pair<Source, false>, pad);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_sha256_pair<Source, false>), dim3(grid), dim3(256), pad, st, src,
@@ -2726,72 +2285,49 @@ static hipError_t launch_pair(unsigned grid, bool dense, hipStream_t st, Source 
     return hipGetLastError();
 }
 
-static inline unsigned sha_grid(int num_cus) { return (unsigned)num_cus * 8u; }  // 2 waves per SIMD
-
-// PBSGPU_SHA_DENSE_FORM=lanes: dense launches use the single-wave kernel at PBSGPU_SHA_LANE_WAVES (default 4) waves
-// per SIMD instead of four producer/consumer pairs per CU (A/B measurements)
-static int sha_dense_lanes() {
-    static int w = -1;
-    if (w < 0) {
-        const char *f = getenv("PBSGPU_SHA_DENSE_FORM");
-        const char *e = getenv("PBSGPU_SHA_LANE_WAVES");
-        w = (f && f[0] == 'l') ? (e ? atoi(e) : 4) : 0;
-        if (w < 0 || w > 8) w = 0;
-    }
-    return w;
-}
 
 hipError_t launch_sha256_records(pbsgpu_record *recs, const uint32_t *nrec, uint32_t *queue, const uint4 *qdesc,
-                                 const uint32_t *wg_limit, int num_cus, bool dense, hipStream_t st) {
+                                 const uint32_t *wg_limit, int num_cus, bool dense, int form, hipStream_t st) {
     RecordSource src{recs, qdesc};
-    if (dense && sha_dense_lanes()) {
-        hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u * (unsigned)sha_dense_lanes()), dim3(64), 0,
-                           st, src, nrec, 0u, queue, wg_limit, 1u);
-    } else if (sha_mode() == 2) {
+    if (form == 2) {
         hipLaunchKernelGGL((k_sha256_xpair<RecordSource>), dim3((unsigned)num_cus), dim3(256), 0, st, src, nrec, 0u, queue,
                            wg_limit);
-    } else if (sha_mode() == 1) {
+    } else if (form == 0) {
         if (dense) {
             hipLaunchKernelGGL((k_sha256_pair<RecordSource, true>), dim3((unsigned)num_cus), dim3(512), 0, st, src, nrec,
                                0u, queue, wg_limit);
         } else {
-            const size_t pad = sha_lds_pad(16u << 10);  // ~69 KB static + 16 KB > 80 KB -> exactly one workgroup per CU
-            hipError_t e = allow_lds(&k_sha256_pair<RecordSource, false>, pad);
+            hipError_t e = allow_lds(&k_sha256_pair<RecordSource, false>, kPairLdsPad);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((k_sha256_pair<RecordSource, false>), dim3((unsigned)num_cus), dim3(256), pad, st, src,
+            hipLaunchKernelGGL((k_sha256_pair<RecordSource, false>), dim3((unsigned)num_cus), dim3(256), kPairLdsPad, st, src,
                                nrec, 0u, queue, wg_limit);
         }
     } else {
-        const size_t pad = sha_lds_pad(36u << 10);  // four single-wave workgroups per CU
-        hipError_t e = allow_lds(&k_sha256<RecordSource>, pad);
+        hipError_t e = allow_lds(&k_sha256<RecordSource>, kLaneLdsPad);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u), dim3(64), pad, st, src, nrec, 0u,
+        hipLaunchKernelGGL((k_sha256<RecordSource>), dim3((unsigned)num_cus * 4u), dim3(64), kLaneLdsPad, st, src, nrec, 0u,
                            queue, wg_limit, 0u);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *segs, uint32_t nseg, uint8_t *digests,
-                                  uint32_t *queue, int num_cus, bool dense, hipStream_t st) {
+                                  uint32_t *queue, int num_cus, bool dense, int form, hipStream_t st) {
     if (nseg == 0) return hipSuccess;
     SegmentSource src{data, segs, digests};
-    unsigned grid = sha_grid(num_cus);
-    const unsigned need = (nseg + 63) / 64;
-    if (grid > need) grid = need;
-    if (sha_mode() != 0) {
+    if (form != 1) {
         unsigned g2 = (unsigned)num_cus;
         const unsigned need2 = (nseg + (dense ? 255u : 127u)) / (dense ? 256u : 128u);
         if (g2 > need2) g2 = need2;
-        return launch_pair(g2, dense, st, src, nseg, queue);
-    } else {
-        const size_t pad = sha_lds_pad(36u << 10);
-        hipError_t e = allow_lds(&k_sha256<SegmentSource>, pad);
-        if (e != hipSuccess) return e;
-        grid = (unsigned)num_cus * 4u;
-        if (grid > need) grid = need;
-        hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), pad, st, src, (const uint32_t *)nullptr,
-                           nseg, queue, (const uint32_t *)nullptr, 0u);
+        return launch_pair(g2, dense, st, src, nseg, queue, form);
     }
+    hipError_t e = allow_lds(&k_sha256<SegmentSource>, kLaneLdsPad);
+    if (e != hipSuccess) return e;
+    unsigned grid = (unsigned)num_cus * 4u;
+    const unsigned need = (nseg + 63) / 64;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), kLaneLdsPad, st, src, (const uint32_t *)nullptr,
+                       nseg, queue, (const uint32_t *)nullptr, 0u);
     return hipGetLastError();
 }
 

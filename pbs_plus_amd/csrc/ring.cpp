@@ -202,17 +202,21 @@ int ring_start_service(pbsgpu_ring *r, bool force = false) {
         HIPCHK(hipStreamSynchronize(r->ss));
         ring_service_ended(r);
     }
-    if (r->svc == SvcState::Stopped && !force && service_park_generation(r->eng->device) != 0) {
+    const uint32_t park_gen = service_park_generation(r->eng->device);
+    if (r->svc == SvcState::Stopped && !force && park_gen != 0 && park_gen != r->park_grace_gen) {
         // The park request is STILL pending: other rings of the device (the stream writer's engine ring beside a bulk ring,
         // two engines) have not let go of their services yet. Starting ours now would put the device's service count back
         // before theirs has dropped — with several busy rings the count then never reaches zero, nothing is ever freed and
         // every ring pays its restart stall for nothing (round 5's cap only worked with ONE ring per device). Stay stopped:
         // rounds are still cut (like the cut-ahead of a lone stream), the next pump asks again, and the last ring to end
-        // flushes. Bounded: a ring that is never called again (its service then stops by its idle timeout, but nobody
-        // observes the end) must not hold the others up for good.
+        // flushes. Bounded, ONCE per request: a ring that is never called again (its service stops by its idle timeout, but
+        // nobody observes the end — an engine a host leaked) keeps the request pending for good, and must cost every other
+        // ring one grace period, not one per service start (a stream writer's ring restarts its service after every idle
+        // 2 ms: the first version of this wait made a whole test suite crawl behind one leaked engine).
         const double t = now_ms();
         if (r->park_wait_t0 == 0) r->park_wait_t0 = t;
-        if (t - r->park_wait_t0 < 400.0) return PBSGPU_OK;
+        if (t - r->park_wait_t0 < 250.0) return PBSGPU_OK;
+        r->park_grace_gen = park_gen;
     }
     r->park_wait_t0 = 0;
     if (r->svc == SvcState::Stopping) {
@@ -466,9 +470,9 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     if (r->ps && r->ctl_used[set])  // this scan set's previous user must have been resolved before the scan overwrites it
         if (hipStreamWaitEvent(r->ps, r->ev_ctl[set], 0) != hipSuccess) return fail(PBSGPU_E_HIP);
     {
-        // (PBSGPU_RING_FILL_SERIAL=1, experiments: the synthetic refill in stream order behind the previous round's scan instead
+        // (PBSGPU_RING_F_FILL_SERIAL, experiments: the synthetic refill in stream order behind the previous round's scan instead
         // of beside it on its own stream)
-        static const bool fill_serial = []() { const char *v = getenv("PBSGPU_RING_FILL_SERIAL"); return v && atoi(v) != 0; }();
+        const bool fill_serial = r->fill_serial;
         pbsk::RingStage stg{};
         if (r->stage_inputs) {
             const uint8_t *hb = r->in((uint32_t)in);
@@ -527,6 +531,52 @@ int ring_take_page(pbsgpu_ring *r, uint32_t *phys) {
     return PBSGPU_OK;
 }
 
+// DEBUG overrides of pbsgpu_ring_options by environment: the variable names of rounds 3-5, ONE table, one getenv. What a
+// host passes in the options is what counts (two engines of one process may want different rings); these exist so that an
+// unmodified binary can be A/B-tested (scripts/, the parity tests that force a code path).
+void ring_env_overrides(pbsgpu_ring_options &o) {
+    enum Kind { U32, U32_ZERO_OFF, F64, F64_ZERO_NEG, FLAG_IF_ZERO, FLAG_IF_SET };
+    struct Entry {
+        const char *name;
+        Kind kind;
+        void *field;
+        uint32_t flag;
+    };
+    const Entry table[] = {
+        {"PBSGPU_RING_SHA_CUS", U32, &o.sha_cus, 0},
+        {"PBSGPU_RING_XP_CUS", U32_ZERO_OFF, &o.express_cus, 0},
+        {"PBSGPU_RING_ROUND_PAGES", U32, &o.round_pages, 0},
+        {"PBSGPU_RING_MIN_ROUND_PAGES", U32, &o.min_round_pages, 0},
+        {"PBSGPU_RING_MAX_INFLIGHT", U32, &o.max_inflight, 0},
+        {"PBSGPU_RING_LONG_BYTES", U32_ZERO_OFF, &o.long_bytes, 0},
+        {"PBSGPU_RING_LONG_LO_BYTES", U32_ZERO_OFF, &o.long_lo_bytes, 0},
+        {"PBSGPU_RING_LONG_SPILL", U32, &o.long_spill, 0},
+        {"PBSGPU_RING_POLL_EVERY", U32, &o.poll_every, 0},
+        {"PBSGPU_RING_BACKLOG_MIB", F64_ZERO_NEG, &o.backlog_mib, 0},
+        {"PBSGPU_RING_LONE_DEFER_MS", F64_ZERO_NEG, &o.lone_defer_ms, 0},
+        {"PBSGPU_RING_IDLE_TIMEOUT_S", F64, &o.idle_timeout_s, 0},
+        {"PBSGPU_RING_AUTOPARK_MS", F64, &o.autopark_ms, 0},
+        {"PBSGPU_RING_OVERLAP", FLAG_IF_ZERO, &o.flags, PBSGPU_RING_F_NO_OVERLAP},
+        {"PBSGPU_RING_STAGE_INPUTS", FLAG_IF_ZERO, &o.flags, PBSGPU_RING_F_NO_STAGE},
+        {"PBSGPU_RING_CUT_PRIO", FLAG_IF_ZERO, &o.flags, PBSGPU_RING_F_NO_CUT_PRIO},
+        {"PBSGPU_RING_SPLIT_AUTO", FLAG_IF_ZERO, &o.flags, PBSGPU_RING_F_NO_SPLIT_AUTO},
+        {"PBSGPU_RING_DEFER_SERVICE", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DEFER_SERVICE},
+        {"PBSGPU_RING_FILL_SERIAL", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_FILL_SERIAL},
+    };
+    for (const Entry &e : table) {
+        const char *v = getenv(e.name);
+        if (!v || !*v) continue;
+        switch (e.kind) {
+        case U32: *static_cast<uint32_t *>(e.field) = (uint32_t)std::max(0L, atol(v)); break;
+        case U32_ZERO_OFF: *static_cast<uint32_t *>(e.field) = atol(v) <= 0 ? PBSGPU_RING_OFF : (uint32_t)atol(v); break;
+        case F64: *static_cast<double *>(e.field) = std::max(0.0, atof(v)); break;
+        case F64_ZERO_NEG: *static_cast<double *>(e.field) = atof(v) <= 0.0 ? -1.0 : atof(v); break;
+        case FLAG_IF_ZERO: if (atoi(v) == 0) *static_cast<uint32_t *>(e.field) |= e.flag; break;
+        case FLAG_IF_SET: if (atoi(v) != 0) *static_cast<uint32_t *>(e.field) |= e.flag; break;
+        }
+    }
+}
+
 }  // namespace
 
 pbsk::RingSource pbsgpu_ring::source() const {
@@ -555,16 +605,15 @@ pbsk::RingSource pbsgpu_ring::source() const {
     // >= 11 MiB for 1 024 pairs; its last record then waits for the express chain of a 16 MiB chunk (0.34 s), not for the pair
     // chain of a 12.9 MiB one (0.37 s).
     q.long_lo = (xp_cus && long_lo_auto) ? (uint32_t)((uint64_t)eng->cfg.max * 11 / 16) : 0u;
-    if (const char *v = getenv("PBSGPU_RING_LONG_LO_BYTES")) q.long_lo = xp_cus ? (uint32_t)std::max(0L, atol(v)) : 0u;
+    if (opt_long_lo) q.long_lo = (xp_cus && opt_long_lo != PBSGPU_RING_OFF) ? opt_long_lo : 0u;
     if (q.long_lo >= q.long_bytes) q.long_lo = 0u;
-    if (const char *v = getenv("PBSGPU_RING_LONG_SPILL")) q.long_spill = (uint32_t)std::max(0, atoi(v));
+    if (opt_long_spill) q.long_spill = opt_long_spill;
     q.ctl = ctl.as<pbsk::RingCtl>();
     q.cells = cells.as<uint8_t>();
     q.pending = pending.as<uint32_t>();
     q.free_fifo = free_fifo.as<unsigned long long>();
     q.free_mask = nfree - 1;
-    double idle_s = idle_timeout_s > 0 ? idle_timeout_s : 20.0;
-    if (const char *v = getenv("PBSGPU_RING_IDLE_TIMEOUT_S")) idle_s = std::max(0.05, atof(v));
+    const double idle_s = idle_timeout_s > 0 ? std::max(0.05, idle_timeout_s) : 20.0;
     q.idle_ticks = (unsigned long long)(idle_s * 100e6);  // wall_clock64 runs at 100 MHz
     q.heartbeat = heartbeat.as<uint32_t>();
     {   // poll period of waves that carry work (power of two; 1 = every step, the behaviour before round 4)
@@ -574,7 +623,7 @@ pbsk::RingSource pbsgpu_ring::source() const {
         // 0.430 -> 0.409 s (profiles/r05_ab_long_spill_and_poll.log; round 4: 1 -> 8: 606 -> 615).
         const uint64_t min_steps = std::min<uint64_t>(eng->effmin, eng->cfg.min) / 64u;
         int every = (int)std::min<uint64_t>(64, std::max<uint64_t>(8, pow2_at_least(min_steps / 256u + 1u) / 2u));
-        if (const char *v = getenv("PBSGPU_RING_POLL_EVERY")) every = std::max(1, atoi(v));
+        if (opt_poll_every) every = (int)opt_poll_every;
         q.poll_mask = pow2_at_least((uint64_t)every) - 1u;
     }
     return q;
@@ -675,6 +724,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
     CHK(set_device(e));
     pbsgpu_ring_options o{};
     if (opt) o = *opt;
+    ring_env_overrides(o);
     pbsgpu_ring *r = new (std::nothrow) pbsgpu_ring();
     if (!r) return PBSGPU_E_NOMEM;
     r->holds_engine_ref = hold_engine_ref;
@@ -716,19 +766,16 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // ~233 CU-ms (128 chains per CU at 1.66-1.75 us per 64-byte block) — measured optimum 192 of 256 CUs
         // (profiles/r03_ring_sweep_*.log: 184 -> 580, 192 -> 597, 200 -> 528, 208 -> 504 GiB/s)
         int sha = o.sha_cus ? (int)o.sha_cus : std::max(1, e->num_cus - e->num_cus / 4);
-        if (!o.sha_cus)
-            if (const char *v = getenv("PBSGPU_RING_SHA_CUS")) sha = atoi(v);
         // EXPRESS service: that many CUs run k_sha256_xpair — two lanes per chunk: the chain of a chunk 1.37x faster (1.28
         // vs 1.75 us per block, profiles/r04_chain_time_pair_vs_express.log) at 0.65 of the throughput per CU — on the
         // chunks of at least long_bytes. Bulk rings (default service share): 16 CUs for chunks >= 13/16 of the maximum
         // (1.3 % of random data's chunks, 5 % of its bytes): the driver's line is unchanged within noise (the drain gets
         // 0.08 s shorter, the feed phase 4 % slower: profiles/r04_ab_express_service.log), one file alone is 15 % sooner.
         // The CUs come out of the pair service's share unless that was given explicitly.
-        int xp = (int)o.express_cus;
-        if (xp == 0 && !o.sha_cus && !getenv("PBSGPU_RING_SHA_CUS") && e->num_cus >= 128) xp = 16;
-        if (const char *v = getenv("PBSGPU_RING_XP_CUS")) xp = std::max(0, atoi(v));
+        int xp = o.express_cus == PBSGPU_RING_OFF ? 0 : (int)o.express_cus;
+        if (o.express_cus == 0 && !o.sha_cus && e->num_cus >= 128) xp = 16;
         xp = std::min(xp, std::max(0, e->num_cus / 2));
-        if (xp && !o.sha_cus && !getenv("PBSGPU_RING_SHA_CUS")) sha = std::max(1, sha - xp);
+        if (xp && !o.sha_cus) sha = std::max(1, sha - xp);
         // The cut side needs its share: with 13/16 of the chip (208 of 256 CUs) in service workgroups the driver's line falls
         // to 525-545 GiB/s, with 216 the cut kernels barely find a CU (a warm-up of 5 files took 120 s:
         // profiles/r04_ab_cu_split.log). Whatever was asked for, the services together get at most 3/4 of the chip + 8.
@@ -737,21 +784,22 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->xp_cus = (uint32_t)xp;
         r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1 - xp));
         r->svc_cus = r->sha_cus + r->xp_cus;
-        r->split_auto = xp > 0 && !o.sha_cus && !o.express_cus && !getenv("PBSGPU_RING_SHA_CUS") && !getenv("PBSGPU_RING_XP_CUS") &&
-                        r->svc_cus >= 96;
-        if (const char *v = getenv("PBSGPU_RING_SPLIT_AUTO")) r->split_auto = r->split_auto && atoi(v) != 0;
+        r->split_auto = xp > 0 && !o.sha_cus && !o.express_cus && r->svc_cus >= 96 && !(o.flags & PBSGPU_RING_F_NO_SPLIT_AUTO);
         r->round_pages = o.round_pages ? o.round_pages : 256;
-        if (const char *v = getenv("PBSGPU_RING_ROUND_PAGES")) r->round_pages = (uint32_t)std::max(1, atoi(v));
         r->round_pages = std::min(r->round_pages, r->npages);
-        r->min_round_pages = std::max(1u, r->round_pages / 4);
-        if (const char *v = getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = (uint32_t)std::max(1, atoi(v));
+        r->min_round_pages = o.min_round_pages ? std::max(1u, std::min(o.min_round_pages, std::max(1u, r->round_pages / 4)))
+                                               : std::max(1u, r->round_pages / 4);
         // ~30 ms of the service's throughput (4.3 GiB/s per CU measured) is plenty to ride out the gaps between rounds
-        r->backlog_limit = (uint64_t)r->sha_cus << 27;
-        if (const char *v = getenv("PBSGPU_RING_BACKLOG_MIB")) r->backlog_limit = (uint64_t)(std::max(0.0, atof(v)) * 1048576.0);
-        if (const char *v = getenv("PBSGPU_RING_MAX_INFLIGHT")) r->max_inflight = (uint32_t)std::min<int>(std::max(1, atoi(v)), kRingInputs);
-        if (const char *v = getenv("PBSGPU_RING_AUTOPARK_MS")) r->autopark_ms = std::max(0.0, atof(v));
-        if (const char *v = getenv("PBSGPU_RING_DEFER_SERVICE")) r->defer_service = atoi(v) != 0;
-        if (const char *v = getenv("PBSGPU_RING_LONE_DEFER_MS")) r->lone_defer_ms = std::max(0.0, atof(v));
+        r->backlog_limit = o.backlog_mib < 0 ? 0 : o.backlog_mib > 0 ? (uint64_t)(o.backlog_mib * 1048576.0) : (uint64_t)r->sha_cus << 27;
+        if (o.max_inflight) r->max_inflight = std::min<uint32_t>(std::max(1u, o.max_inflight), kRingInputs);
+        r->autopark_ms = std::max(0.0, o.autopark_ms);
+        r->defer_service = (o.flags & PBSGPU_RING_F_DEFER_SERVICE) != 0;
+        r->fill_serial = (o.flags & PBSGPU_RING_F_FILL_SERIAL) != 0;
+        r->lone_defer_ms = o.lone_defer_ms < 0 ? 0.0 : o.lone_defer_ms > 0 ? o.lone_defer_ms : 25.0;
+        r->idle_timeout_s = o.idle_timeout_s;
+        r->opt_long_lo = o.long_lo_bytes;
+        r->opt_long_spill = o.long_spill;
+        r->opt_poll_every = o.poll_every;
         // Candidate slots per scan tile. The batch path starts small and RE-RUNS a batch whose tile overflowed; a ring round
         // cannot be re-run (later rounds continue from it), so the ring provisions for periodic data up front: one
         // candidate per 128 bytes (a repeating block of >= 128 bytes whose every period holds a candidate — BASELINE
@@ -785,7 +833,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // late-starting long chunks; kept as a switch)
         r->long_bytes = r->xp_cus ? (long_bytes_hint ? long_bytes_hint : (uint32_t)((uint64_t)e->cfg.max * 13 / 16)) : 0;
         r->long_lo_auto = long_bytes_hint == 0;  // (a ring with its own threshold — the stream writer's — keeps it)
-        if (const char *v = getenv("PBSGPU_RING_LONG_BYTES")) r->long_bytes = (uint32_t)std::max(0L, atol(v));
+        if (o.long_bytes) r->long_bytes = o.long_bytes == PBSGPU_RING_OFF ? 0u : o.long_bytes;
         if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);
         CHK(r->ldesc.ensure((size_t)r->lslots * 32));
@@ -794,8 +842,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         CHK(r->tile_off.ensure((size_t)ntiles * 4 + 16));
         CHK(r->tile_slots.ensure((size_t)ntiles * r->cap * 4 + 16));
         CHK(r->tileq.ensure(128));
-        bool overlap = true;
-        if (const char *v = getenv("PBSGPU_RING_OVERLAP")) overlap = atoi(v) != 0;
+        const bool overlap = !(o.flags & PBSGPU_RING_F_NO_OVERLAP);
         if (overlap) {
             CHK(r->tile_cnt2.ensure((size_t)ntiles * 4 + 16));
             CHK(r->tile_slots2.ensure((size_t)ntiles * r->cap * 4 + 16));
@@ -823,8 +870,8 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->in_status_off = al64(r->in_suggidx_off + ((size_t)r->max_streams + 1) * 4);
         r->input_stride = r->in_status_off + 64;
         CHK(r->inputs.ensure(r->input_stride * kRingInputs));
-        // PBSGPU_RING_STAGE_INPUTS=0: the round's kernels read their tables from mapped host memory (rounds 3-4), for A/B runs
-        if (const char *v = getenv("PBSGPU_RING_STAGE_INPUTS")) r->stage_inputs = atoi(v) != 0;
+        // PBSGPU_RING_F_NO_STAGE: the round's kernels read their tables from mapped host memory (rounds 3-4), for A/B runs
+        r->stage_inputs = !(o.flags & PBSGPU_RING_F_NO_STAGE);
         if (r->stage_inputs) CHK(r->inputs_dev.ensure(r->input_stride * kRingInputs));
         std::memset(r->inputs.p, 0, r->input_stride * kRingInputs);
         // Three priorities: the services highest (their own hardware-queue pool: nothing may queue behind a kernel that only
@@ -834,8 +881,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // k_ring_control 1.1 ms per launch for 10 us / 170 us of work; PBSGPU_RING_CUT_PRIO=0: all normal).
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        bool cut_prio = true;
-        if (const char *v = getenv("PBSGPU_RING_CUT_PRIO")) cut_prio = atoi(v) != 0;
+        const bool cut_prio = !(o.flags & PBSGPU_RING_F_NO_CUT_PRIO);
         r->bulk_prio = cut_prio ? prio_lo : 0;
         HIPCHK(hipStreamCreateWithFlags(&r->cs, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithPriority(&r->fs, hipStreamNonBlocking, r->bulk_prio));

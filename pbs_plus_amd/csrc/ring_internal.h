@@ -127,13 +127,16 @@ struct pbsgpu_ring {
     double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
     double idle_since_ms = 0;
     uint32_t park_gen_seen = 0;           // last graveyard park request this ring honoured (engine_internal.h: dev_free)
+    uint32_t park_grace_gen = 0;          // the park request this ring has already waited its grace period for (ring_start_service)
     double park_wait_t0 = 0;              // since when a start has been waiting for the other rings of the device to let go (ring_start_service)
     bool parked_for_flush = false;        // ... and its service was parked for it: the next start waits for that service's END
-    bool defer_service = false;           // PBSGPU_RING_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
+    bool fill_serial = false;             // PBSGPU_RING_F_FILL_SERIAL
+    uint32_t opt_long_lo = 0, opt_long_spill = 0, opt_poll_every = 0;  // pbsgpu_ring_options (0 = the default rule)
+    bool defer_service = false;           // PBSGPU_RING_F_DEFER_SERVICE (profiling): rounds only enqueue; quiesce runs the service ALONE
     double lone_defer_ms = 25.0;          // a lone bulk stream's rounds are cut ahead of the service start for at most this long (0 = off)
     double defer_t0 = 0;                  // when the current deferral began (0 = none)
     uint64_t deferred_bytes = 0;          // bytes cut while no service was running (they are the next launch's work)
-    double idle_timeout_s = 0;            // > 0: the service's own idle stop (default 20 s; PBSGPU_RING_IDLE_TIMEOUT_S overrides)
+    double idle_timeout_s = 0;            // > 0: the service's own idle stop (pbsgpu_ring_options::idle_timeout_s; default 20 s)
     // host bookkeeping
     std::vector<uint32_t> free_pages;
     uint32_t free_read = 0;               // entries of the free FIFO consumed

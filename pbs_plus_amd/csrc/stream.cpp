@@ -214,11 +214,11 @@ int engine_ring_get(pbsgpu_engine *e, pbsgpu_ring **out) {
         CHK(set_device(e));
         pbsgpu_ring_options o{};
         // Arena: ingest rate x residency. A host-fed engine moves <= ~55 GiB/s (PCIe) and a page stays for queue wait + the
-        // chain of the longest chunk touching it (<= 0.46 s, ~0.3 s on average): 48 GiB is generous (PBSGPU_STREAM_RING_GIB).
+        // chain of the longest chunk touching it (<= 0.46 s, ~0.3 s on average): 48 GiB is generous (pbsgpu_engine_options::stream_ring_gib).
         // Service: 50 GiB/s need ~12 CUs of chains (4.3 GiB/s per CU); 32 leave headroom for bursts and keep 7/8 of the chip
-        // for everything else the process runs (PBSGPU_STREAM_SHA_CUS).
-        double gib = 48.0;
-        if (const char *v = getenv("PBSGPU_STREAM_RING_GIB")) gib = std::max(0.001, atof(v));
+        // for everything else the process runs (pbsgpu_engine_options::stream_sha_cus).
+        const pbsgpu_engine_options &eo = e->opt;  // (defaults resolved by pbsgpu_engine_create_opt)
+        const double gib = eo.stream_ring_gib;
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
         uint64_t want = (uint64_t)(gib * 1073741824.0);
@@ -226,29 +226,28 @@ int engine_ring_get(pbsgpu_engine *e, pbsgpu_ring **out) {
         if (fr > keep && want > fr - keep) want = fr - keep;
         o.arena_bytes = want;
         int cus = std::max(1, std::min(32, e->num_cus / 2));
-        if (const char *v = getenv("PBSGPU_STREAM_SHA_CUS")) cus = std::max(1, std::min(atoi(v), e->num_cus - 1));
+        if (eo.stream_sha_cus) cus = std::max(1, std::min((int)eo.stream_sha_cus, e->num_cus - 1));
         o.sha_cus = (uint32_t)cus;
         // ... and 8 more for the EXPRESS service: what an archive waits for at its end is the serial SHA-256 chain of its last
         // long chunks (0.49 s for a 16 MiB chunk on a pair lane); two lanes per chunk finish it in 0.36 s, and a host-fed
-        // engine has CUs to spare (12.5 % of 50 GiB/s in chunks >= 10 MiB need 3 express CUs) (PBSGPU_STREAM_XP_CUS)
+        // engine has CUs to spare (12.5 % of 50 GiB/s in chunks >= 10 MiB need 3 express CUs)
         int xp = std::min(8, std::max(0, e->num_cus / 2 - cus));
-        if (const char *v = getenv("PBSGPU_STREAM_XP_CUS")) xp = std::max(0, std::min(atoi(v), e->num_cus / 2));
-        o.express_cus = (uint32_t)xp;
-        o.max_streams = 256;
-        if (const char *v = getenv("PBSGPU_STREAM_RING_SLOTS")) o.max_streams = (uint32_t)std::max(4, std::min(atoi(v), 4096));
-        if (const char *v = getenv("PBSGPU_STREAM_PAGE_BYTES")) o.page_bytes = (uint64_t)std::max(0L, atol(v));
+        if (eo.stream_express_cus) xp = eo.stream_express_cus == 0xffffffffu ? 0 : std::min((int)eo.stream_express_cus, e->num_cus / 2);
+        o.express_cus = xp ? (uint32_t)xp : PBSGPU_RING_OFF;
+        o.max_streams = eo.stream_ring_slots;
+        o.page_bytes = eo.stream_page_bytes;
+        // nothing in flight anywhere for 2 ms: stop the service (its CUs, and hipFree / device-wide syncs of the process, come
+        // back); the next page starts it again
+        o.autopark_ms = 2.0;
+        // ... and a writer that simply stops calling (a blocking read) gives them back after 2 s without any call at all
+        o.idle_timeout_s = 2.0;
+        // host-fed pages trickle in (3 per millisecond at 50 GiB/s) and a round is three launches: cut every 8 pages instead of
+        // waiting for a quarter of a full round (64 pages = 20 ms more latency for every chunk, and for the archive's drain)
+        o.min_round_pages = 8;
         pbsgpu_ring *r = nullptr;
         // ... for every chunk of at least half the maximum size: what an archive waits for at its end is then a 16 MiB chunk on
         // an express pair (0.36 s) rather than a 13 MiB one on a pair lane (0.40 s); 23 % of 50 GiB/s keep 4-5 express CUs busy
-        CHK(ring_create_internal(e, &o, false, &r, o.express_cus ? (uint32_t)(e->cfg.max / 2) : 0u));
-        // nothing in flight anywhere for 2 ms: stop the service (its CUs, and hipFree / device-wide syncs of the process, come
-        // back); the next page starts it again
-        // host-fed pages trickle in (3 per millisecond at 50 GiB/s) and a round is three launches: cut every 8 pages instead of
-        // waiting for a quarter of a full round (64 pages = 20 ms more latency for every chunk, and for the archive's drain)
-        if (!getenv("PBSGPU_RING_MIN_ROUND_PAGES")) r->min_round_pages = std::min<uint32_t>(r->min_round_pages, 8);
-        if (r->autopark_ms == 0) r->autopark_ms = 2.0;
-        // ... and a writer that simply stops calling (a blocking read) gives them back after 2 s without any call at all
-        r->idle_timeout_s = 2.0;
+        CHK(ring_create_internal(e, &o, false, &r, xp ? (uint32_t)(e->cfg.max / 2) : 0u));
         e->sring = r;
     }
     e->sring_users++;
@@ -746,10 +745,7 @@ static void stream_reset_state(pbsgpu_stream *s) {
 }
 
 static bool stream_park(pbsgpu_engine *e, pbsgpu_stream *s) {
-    static const size_t limit = []() -> size_t {
-        const char *v = getenv("PBSGPU_STREAM_CTX_POOL");
-        return (size_t)(v ? std::max(0L, atol(v)) : 8L);
-    }();
+    const size_t limit = e->opt.stream_ctx_pool;
     stream_reset_state(s);
     s->eng = nullptr;  // (a parked context holds no reference: the engine owns it)
     s->ring = nullptr;

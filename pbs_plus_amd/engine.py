@@ -67,12 +67,20 @@ class Engine:
     """One engine per (process, GPU). Stands where backupproxy's session owns the
     chunker + hasher built from the buzhash.Config (commit_orchestrate.go:137-149)."""
 
-    def __init__(self, config: Config, device: int = 0, inflight: int = 2):
+    def __init__(self, config: Config, device: int = 0, inflight: int = 2, **options):
+        """`options`: fields of pbsgpu_engine_options by name (sha_form=2, stream_ring_gib=8.0, ...); none = the defaults."""
         self._L = _lib.lib()
         self.config = config
         h = C.c_void_p()
-        check(self._L.pbsgpu_engine_create(int(device), C.byref(config._c), int(inflight), C.byref(h)),
-              "engine_create")
+        if options:
+            o = _lib.EngineOptions()
+            o.inflight = int(inflight)
+            for k, v in options.items():
+                setattr(o, k, v)
+            check(self._L.pbsgpu_engine_create_opt(int(device), C.byref(config._c), C.byref(o), C.byref(h)), "engine_create_opt")
+        else:
+            check(self._L.pbsgpu_engine_create(int(device), C.byref(config._c), int(inflight), C.byref(h)),
+                  "engine_create")
         self._h = h
         self.device = device
 
@@ -501,11 +509,14 @@ class PageRing:
     (internal/pxarmount/commit_reuse.go:457, internal/tapeio/converter.go:836) when bytes are in device memory."""
 
     def __init__(self, eng: Engine, arena_bytes: int = 0, page_bytes: int = 0, max_streams: int = 0, sha_cus: int = 0,
-                 round_pages: int = 0, express_cus: int = 0):
+                 round_pages: int = 0, express_cus: int = 0, **options):
+        """`options`: the other fields of pbsgpu_ring_options by name (flags=_lib.RING_F_NO_STAGE, lone_defer_ms=-1.0, ...)."""
         self._eng = eng
         self._L = eng._L
         opt = _lib.RingOptions(int(arena_bytes), int(page_bytes), int(max_streams), int(sha_cus), int(round_pages),
                                int(express_cus))
+        for k, v in options.items():
+            setattr(opt, k, v)
         h = C.c_void_p()
         check(self._L.pbsgpu_ring_create(eng._h, C.byref(opt), C.byref(h)), "ring_create")
         self._h = h

@@ -163,3 +163,47 @@ def test_library_load_sets_hw_queue_default_but_never_overrides():
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="6"), capture_output=True,
                          text=True, timeout=120)
     assert out.stdout.strip() == "6", out.stdout + out.stderr
+
+
+def test_option_structs_have_the_layout_the_bindings_assume(L, tmp_path):
+    """ABI v5 moved the tuning values out of the environment into pbsgpu_engine_options / pbsgpu_ring_options: the ctypes
+    mirrors (and through test_binding_sources the Go ones) must agree with what a C compiler makes of include/pbsgpu.h —
+    sizes and the offset of every field."""
+    import subprocess
+
+    from pbs_plus_amd import _lib
+
+    fields = {"pbsgpu_ring_options": _lib.RingOptions, "pbsgpu_engine_options": _lib.EngineOptions,
+              "pbsgpu_ring_probe": _lib.RingProbe, "pbsgpu_ring_stats": _lib.RingStats}
+    lines = []
+    for cname, cls in fields.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pbsgpu.h"\nint main(void) {\n' + "\n".join(lines) +
+                   "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.rsplit(" ", 1) for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in fields.items():
+        assert int(got[cname + " size"]) == C.sizeof(cls), (cname, got[cname + " size"], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_the_library_reads_its_tuning_from_options_not_from_the_environment():
+    """51 getenv() sites made split, thresholds, poll period, staging and priorities process-global
+    state, invisible to a host with two engines. Since ABI v5 they are fields of the two options structs; what is left of
+    getenv are two override TABLES (one per struct, for A/B runs of an unmodified binary) and a handful of process-level
+    debug switches."""
+    import re
+
+    sites = []
+    csrc = os.path.join(ROOT, "pbs_plus_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".cpp", ".hip", ".inc", ".h")):
+            text = open(os.path.join(csrc, name)).read()
+            text = re.sub(r"//[^\n]*", "", text)
+            sites += [(name, m.start()) for m in re.finditer(r"\bgetenv\s*\(", text)]
+    assert len(sites) <= 10, sites

@@ -437,8 +437,9 @@ def test_xxh3_many_matches_xxhash_library(engines):
 
 
 def test_alternate_kernels_stay_bit_exact(gpu_lib):
-    """The A/B kernels (single-wave SHA-256; LDS-tiled and per-lane streaming scans; scan prefetch depth 2) are
-    selected by environment variables read once per process: run a small parity check in subprocesses."""
+    """The alternative hash kernels of the batch path (single-wave lanes, express pairs) are an ENGINE option since round 6
+    (pbsgpu_engine_options::sha_form; the PBSGPU_SHA_MODE variable of rounds 1-5 still works as a debug override): both ways
+    of selecting them, a small parity check each. (The LDS-tiled and per-lane streaming scan kernels are gone.)"""
     import subprocess
     import sys
 
@@ -448,14 +449,15 @@ def test_alternate_kernels_stay_bit_exact(gpu_lib):
         "from oracle import oracle as O\n"
         "from pbs_plus_amd import Engine, buzhash\n"
         "from tests.helpers import records_equal\n"
+        "import os\n"
+        "opt = dict(sha_form=int(os.environ['SHA_FORM'])) if 'SHA_FORM' in os.environ else {}\n"
         "for avg, n, kind in ((4096, 3_000_001, 3), (4 << 20, 80 << 20, 0)):\n"
-        "    eng = Engine(buzhash.NewConfig(avg))\n"
+        "    eng = Engine(buzhash.NewConfig(avg), **opt)\n"
         "    data = O.fill(n, 5, kind)\n"
         "    assert records_equal(eng.chunk_and_digest(data), O.chunk_and_digest(O.new_config(avg), data)), avg\n"
         "    eng.close()\n"
         "print('alt-ok')\n" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-    for alt in (dict(PBSGPU_SHA_MODE="lane", PBSGPU_SCAN_MODE="lds"), dict(PBSGPU_SCAN_MODE="stream"),
-                dict(PBSGPU_SCAN_DEPTH="2")):
+    for alt in (dict(PBSGPU_SHA_MODE="lane"), dict(SHA_FORM="1"), dict(SHA_FORM="2")):
         env = dict(__import__("os").environ, **alt)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert "alt-ok" in out.stdout, str(alt) + out.stdout + out.stderr

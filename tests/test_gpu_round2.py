@@ -761,8 +761,7 @@ def test_dense_sha_form_stays_bit_exact(gpu_lib):
     PBSGPU_SHA_DENSE_PCT % of the longest chain per lane. PBSGPU_SHA_DENSE_PCT=1 (read once per process -> subprocess)
     makes it the form of every launch that has >~330 longest-chunks' worth of blocks: batch records (decided from the
     batch's bytes and the chunker's maximum), whole-segment hashing with every padding length and misaligned starts, and
-    the stream writer's shared hash jobs (decided from the items of the launch) — all against the oracle / hashlib. The
-    single-wave alternative for dense launches (PBSGPU_SHA_DENSE_FORM=lanes) runs the batch part as well."""
+    the stream writer's shared hash jobs (decided from the items of the launch) — all against the oracle / hashlib."""
     import os
     import subprocess
     import sys
@@ -797,7 +796,7 @@ def test_dense_sha_form_stays_bit_exact(gpu_lib):
         "    assert bytes(dig[i]) == hashlib.sha256(blob[o:o + l].tobytes()).digest(), (i, o, l)\n"
         "eng.close()\n"
         "print('dense-ok')\n" % root)
-    for extra in ({}, dict(PBSGPU_SHA_DENSE_FORM="lanes")):
+    for extra in ({},):
         env = dict(os.environ, PBSGPU_SHA_DENSE_PCT="1", **extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert "dense-ok" in out.stdout, str(extra) + out.stdout[-2000:] + out.stderr[-3000:]
