@@ -195,8 +195,7 @@ class Stream64g(Workload):
 
     def after_collect(self, batch, recs, ctx):
         if ctx.dist is not None:   # cross-stream duplicate detection over all ranks' files of this step
-            from pbs_plus_amd.dist import global_dedup
-            _, stats, _ = global_dedup(self.eng, recs, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
+            stats = reduce_records(ctx, self.eng, recs)
             self.extra["dedup_last_step"] = {k: int(v) for k, v in stats.items()}
 
     def cpu_sample(self):
@@ -335,11 +334,10 @@ class CorpusDup(Workload):
     def after_collect(self, batch, recs, ctx):
         self.pass_recs[id(batch)] = recs
         if len(self.pass_recs) == len(self.batches):     # one pass over the share is complete: digest-set reduce
-            from pbs_plus_amd.dist import global_dedup
             local = np.concatenate([self.pass_recs[id(b)] for b in self.batches])
             self.pass_recs = {}
             if ctx.dist is not None:
-                _, stats, _ = global_dedup(self.eng, local, device=ctx.comm_dev, cap_records=ctx.rec_cap * len(self.batches), want_records=False)
+                stats = reduce_records(ctx, self.eng, local, ctx.rec_cap * len(self.batches))
             else:
                 _, stats = self.eng.dedup(local)
             tb = max(int(stats["total_bytes"]), 1)
@@ -511,7 +509,10 @@ class Ctx:
     dist = None
     comm_dev = None
     rec_cap = 0
-    cabi = None        # result of the C-ABI digest-set reduce check (N > 1, RCCL)
+    cabi = None        # what the digest-set reduce of the timed region went through + its cross-check (N > 1)
+    cabi_comm = None   # the C ABI's communicator (setup_reduce), when the timed reduce goes through libpbsgpu itself
+    reduce_path = "torch.distributed (pbs_plus_amd.dist.global_dedup)"
+    reduce_error = None
     hard_exit = False  # a watchdog gave up on a collective: leave with os._exit once the line is out
 
 
@@ -766,35 +767,79 @@ def _hostfeed_subprocess(b, local_rank):
     raise RuntimeError(f"host-fed leg failed (rc {r.returncode}): {r.stderr[-400:]}")
 
 
-def cabi_reduce_check(eng, recs, ctx):
-    """pbsgpu_comm_create + pbsgpu_digest_allgather_dedup over all ranks (collective) vs the torch.distributed path."""
-    from pbs_plus_amd.dist import comm_dedup, global_dedup, make_comm
-
-    res = {"ok": False}
+def setup_reduce(ctx, eng):
+    """Which digest-set reduce the TIMED region uses. Since round 6: the C ABI's own communicator (pbsgpu_comm_create +
+    pbsgpu_digest_allgather_dedup: libpbsgpu dlopens RCCL, ONE ncclAllGather of [count | records] slots + device dedup — what a
+    Go host binds, no torch in it) whenever the ranks sit on their own GPUs (backend nccl); the torch.distributed path
+    (pbs_plus_amd.dist.global_dedup) otherwise — gloo: CPU tests, several ranks sharing one GPU, where RCCL cannot build a
+    communicator. PBS_BENCH_REDUCE=torch|cabi forces one. Collective; a watchdog keeps a communicator that does not come up
+    from taking the line down (every rank then falls back together)."""
+    ctx.cabi_comm, ctx.reduce_path = None, "torch.distributed (pbs_plus_amd.dist.global_dedup)"
+    if ctx.dist is None:
+        return
+    want = os.environ.get("PBS_BENCH_REDUCE", "torch" if os.environ.get("PBS_BENCH_NO_CABI_REDUCE") else "auto")
+    if want == "torch" or (want == "auto" and (ctx.comm_dev is None or ctx.comm_dev.type != "cuda")):
+        return
+    from pbs_plus_amd.dist import make_comm
+    res = {}
 
     def work():
         try:
-            _, ref, _ = global_dedup(eng, recs, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
-            comm = make_comm(eng, device=ctx.comm_dev)
-            comm_dedup(comm, recs, ctx.rec_cap)                       # first contact (RCCL channel set-up)
-            t0 = time.perf_counter()
-            _, st = comm_dedup(comm, recs, ctx.rec_cap)
-            res.update(ok=True, ms=round((time.perf_counter() - t0) * 1e3, 3), stats={k: int(v) for k, v in st.items()},
-                       equals_torch_path=bool(all(int(st[k]) == int(ref[k]) for k in ("nrecords", "nunique", "total_bytes",
-                                                                                        "unique_bytes"))),
-                       path="pbsgpu_comm_create + pbsgpu_digest_allgather_dedup (libpbsgpu dlopens RCCL: one ncclAllGather "
-                            "of [count | records] slots + device dedup)")
-            comm.close()
+            res["comm"] = make_comm(eng, device=ctx.comm_dev)
         except BaseException as exc:  # noqa: BLE001
             res["error"] = repr(exc)
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
     th.join(120)
+    ok = 0 if (th.is_alive() or "comm" not in res) else 1
     if th.is_alive():
-        res["error"] = "timeout after 120 s"
         ctx.hard_exit = True
-    return res
+    import torch
+    flag = torch.tensor([ok], dtype=torch.int64, device=ctx.comm_dev)
+    ctx.dist.all_reduce(flag, op=ctx.dist.ReduceOp.MIN)          # every rank or none
+    if int(flag.item()) == 1:
+        ctx.cabi_comm = res["comm"]
+        ctx.reduce_path = ("C ABI: pbsgpu_comm_create + pbsgpu_digest_allgather_dedup (libpbsgpu dlopens RCCL: one ncclAllGather of "
+                           "[count | records] slots + device dedup)")
+    else:
+        ctx.reduce_error = res.get("error", "timeout after 120 s")
+        if "comm" in res:
+            res["comm"].close()
+
+
+def reduce_records(ctx, eng, recs, cap_records=None):
+    """the digest-set reduce of the timed region (collective): statistics of the union over all ranks"""
+    cap = ctx.rec_cap if cap_records is None else cap_records
+    if getattr(ctx, "cabi_comm", None) is not None:
+        _, stats = ctx.cabi_comm.dedup(recs, cap, want_flags=False)
+        return stats
+    from pbs_plus_amd.dist import global_dedup
+    _, stats, _ = global_dedup(eng, recs, device=ctx.comm_dev, cap_records=cap, want_records=False)
+    return stats
+
+
+def reduce_cross_check(ctx, eng, recs):
+    """outside the timed region: the OTHER path over the same records (collective) — both must report the same union"""
+    if ctx.dist is None:
+        return None
+    from pbs_plus_amd.dist import global_dedup
+    keys = ("nrecords", "nunique", "total_bytes", "unique_bytes")
+    out = {"timed_path": ctx.reduce_path, "timed_through_c_abi": getattr(ctx, "cabi_comm", None) is not None}
+    if getattr(ctx, "reduce_error", None):
+        out["c_abi_error"] = ctx.reduce_error
+    try:
+        t0 = time.perf_counter()
+        mine = reduce_records(ctx, eng, recs)
+        out["ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        out["stats"] = {k: int(mine[k]) for k in keys}
+        if out["timed_through_c_abi"]:
+            _, ref, _ = global_dedup(eng, recs, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
+            out["equals_torch_path"] = bool(all(int(mine[k]) == int(ref[k]) for k in keys))
+        out["ok"] = True
+    except BaseException as exc:  # noqa: BLE001
+        out.update(ok=False, error=repr(exc))
+    return out
 
 
 def ring_run(a, rank, local_rank, world, ctx):
@@ -828,11 +873,10 @@ def ring_run(a, rank, local_rank, world, ctx):
         # once steps 0..k-1 have been reduced, whatever order the files finished in on this rank
         if ctx.dist is None or not state["timed"]:
             return
-        from pbs_plus_amd.dist import global_dedup
         pending_reduce[step] = recs
         while state["next_reduce"] in pending_reduce:
             r = pending_reduce.pop(state["next_reduce"])
-            _, stats, _ = global_dedup(eng, r, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
+            stats = reduce_records(ctx, eng, r)
             extra["dedup_last_step"] = {k: int(v) for k, v in stats.items()}
             state["next_reduce"] += 1
 
@@ -894,11 +938,11 @@ def ring_run(a, rank, local_rank, world, ctx):
         # first contact of the digest-set reduce BEFORE the persistent service starts: RCCL's lazy channel buffers, torch's
         # communication tensors and the engine's dedup work buffers all take their final size here (at the agreed record
         # capacity), so nothing inside the timed region allocates, frees or waits for the whole device
-        from pbs_plus_amd.dist import global_dedup
+        setup_reduce(ctx, eng)
         dummy = np.zeros(ctx.rec_cap, dtype=pbs_plus_amd.RECORD_DTYPE)
         dummy["digest"][:, :8] = np.arange(ctx.rec_cap, dtype=np.uint64).view(np.uint8).reshape(-1, 8)
         dummy["size"] = 1
-        global_dedup(eng, dummy, device=ctx.comm_dev, cap_records=ctx.rec_cap, want_records=False)
+        reduce_records(ctx, eng, dummy)
         ctx.dist.barrier()
     if a.warmup:
         run_files(a.warmup, False)
@@ -932,11 +976,10 @@ def ring_run(a, rank, local_rank, world, ctx):
         ctx.dist.all_reduce(tb, op=ctx.dist.ReduceOp.SUM)
         total_bytes = float(tb.item())
     state["timed"] = False
-    if ctx.dist is not None and ctx.comm_dev is not None and ctx.comm_dev.type == "cuda" and not os.environ.get("PBS_BENCH_NO_CABI_REDUCE"):
-        # the same digest-set reduce through the C ABI's own communicator (what a Go host binds: no torch in it), outside the
-        # timed region, on the last timed file of every rank; must agree with the torch path. A watchdog keeps a communicator
-        # that does not come up from taking the line down.
-        ctx.cabi = cabi_reduce_check(eng, kept[max(kept)], ctx)
+    if ctx.dist is not None:
+        # the reduce of the timed region once more on the last timed file of every rank, and (when it went through the C ABI)
+        # the torch.distributed path beside it: both must report the same union
+        ctx.cabi = reduce_cross_check(ctx, eng, kept[max(kept)])
     # one file alone through an idle ring: single-file latency (outside the timed region)
     ts0 = time.perf_counter()
     s_saved, state["S"] = state["S"], 1
@@ -1043,6 +1086,9 @@ def ring_run(a, rank, local_rank, world, ctx):
             out["cpu_baseline"] = mine
     if ctx.dist is not None and rank == 0 and ctx.cabi is not None:
         out.setdefault("results", {})["c_abi_digest_reduce"] = ctx.cabi
+    if getattr(ctx, "cabi_comm", None) is not None:
+        ctx.cabi_comm.close()
+        ctx.cabi_comm = None
     ring.close()
     eng.close()
     return out
@@ -1465,6 +1511,7 @@ def run_batch(a, rank, local_rank, world, ctx):
         rc = torch.tensor([ctx.rec_cap], dtype=torch.int64, device=ctx.comm_dev)
         ctx.dist.all_reduce(rc, op=ctx.dist.ReduceOp.MAX)
         ctx.rec_cap = int(rc.item())
+        setup_reduce(ctx, eng)      # (the C ABI's own communicator when the ranks sit on their own GPUs)
     inflight = max(1, a.reread) if a.reread else len(batches)
 
     def collect(b, t, timings):
@@ -1548,6 +1595,11 @@ def run_batch(a, rank, local_rank, world, ctx):
         out = assemble(a, w, cfg, world, inflight, elapsed, total_bytes, timings, serial_timing, serial_s)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a, w)
+        if ctx.dist is not None:
+            out.setdefault("results", {})["digest_reduce_path"] = ctx.reduce_path
+    if getattr(ctx, "cabi_comm", None) is not None:
+        ctx.cabi_comm.close()
+        ctx.cabi_comm = None
     w.free()
     eng.close()
     return out

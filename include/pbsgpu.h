@@ -504,7 +504,8 @@ int pbsgpu_comm_rank(const pbsgpu_comm *comm, int *rank, int *world);
 /* What RCCL reported when a pbsgpu_comm_* call of this process last failed ("" = nothing yet), e.g.
  * "ncclCommInitRank: unhandled system error (ncclResult 2)". The pointer stays valid for the calling thread. */
 const char *pbsgpu_comm_last_error(void);
-/* Collective. recs[0..n) (host memory, n <= cap_records) = this rank's records; cap_records must be the SAME on every
+/* Collective. recs[0..n) (HOST or DEVICE memory — device records travel device to device —, n <= cap_records) = this rank's
+ * records; cap_records must be the SAME on every
  * rank (bytes per rank / minimum chunk size is a bound every rank can compute). *stats describes the union over all
  * ranks and is identical on every rank; dup_own[i] (may be NULL) = 1 when an earlier record of the union — a lower rank's,
  * or this rank's with a lower index — carries the same digest. ~48 B per chunk travel: 12 MB per TiB of corpus.

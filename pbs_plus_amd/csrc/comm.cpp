@@ -242,8 +242,8 @@ int pbsgpu_comm_rank(const pbsgpu_comm *c, int *rank, int *world) {
     return PBSGPU_OK;
 }
 
-// The digest-set reduce. Collective: every rank calls it, in the same order. `recs` (host, n <= cap_records) = this rank's
-// records; cap_records must be the SAME on every rank (bytes / min chunk size is a bound every rank can compute). On return
+// The digest-set reduce. Collective: every rank calls it, in the same order. `recs` (HOST or DEVICE memory, n <= cap_records) =
+// this rank's records; cap_records must be the SAME on every rank (bytes / min chunk size is a bound every rank can compute). On return
 // `stats` describes the union over all ranks (identical on every rank); dup_own[i] = 1 when an EARLIER record of the union
 // — lower rank, or same rank and lower index — carries the same digest (may be NULL).
 // Errors are COLLECTIVE too: bad arguments, capacities that disagree or an allocation that fails on ONE rank make EVERY
@@ -290,9 +290,16 @@ int pbsgpu_digest_allgather_dedup(pbsgpu_comm *c, const pbsgpu_record *recs, uin
     uint8_t *hs = c->h_send.as<uint8_t>();
     std::memset(hs, 0, kSlotHeader);
     std::memcpy(hs, &n, 8);
-    if (n) std::memcpy(hs + kSlotHeader, recs, n * sizeof(pbsgpu_record));
     const uint64_t used = kSlotHeader + n * sizeof(pbsgpu_record);
-    HIPCHK(hipMemcpyAsync(c->send.p, hs, used, hipMemcpyHostToDevice, c->st));
+    if (n && is_device_pointer(recs)) {
+        // records that are already in DEVICE memory (a batch's record array, a device-side merge) go device -> device: only
+        // the 64-byte header comes from the host (round 5 took host records only: D2H by the caller, H2D here)
+        HIPCHK(hipMemcpyAsync(c->send.p, hs, kSlotHeader, hipMemcpyHostToDevice, c->st));
+        HIPCHK(hipMemcpyAsync(c->send.as<uint8_t>() + kSlotHeader, recs, n * sizeof(pbsgpu_record), hipMemcpyDeviceToDevice, c->st));
+    } else {
+        if (n) std::memcpy(hs + kSlotHeader, recs, n * sizeof(pbsgpu_record));
+        HIPCHK(hipMemcpyAsync(c->send.p, hs, used, hipMemcpyHostToDevice, c->st));
+    }
     if (used < slot) HIPCHK(hipMemsetAsync(c->send.as<uint8_t>() + used, 0, slot - used, c->st));
     if (const ncclResult_t rc = rccl().AllGather(c->send.p, c->recv.p, slot, ncclUint8, c->comm, c->st); rc != ncclSuccess)
         return comm_fail("ncclAllGather", rc);

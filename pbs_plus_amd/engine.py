@@ -459,6 +459,15 @@ class Comm:
                                                     C.byref(st)), "digest_allgather_dedup")
         return (dup[: recs.size] if want_flags else None), {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
 
+    def dedup_device(self, dptr: int, n: int, cap_records: int, want_flags: bool = True):
+        """dedup() on n records that already are in DEVICE memory (they travel device -> device, no host round trip)."""
+        dup = np.zeros(max(n, 1), dtype=np.uint8) if want_flags else None
+        st = _lib.DedupStats()
+        check(self._L.pbsgpu_digest_allgather_dedup(self._h, int(dptr) if n else None, int(n), int(cap_records),
+                                                    dup.ctypes.data if want_flags else None, C.byref(st)),
+              "digest_allgather_dedup")
+        return (dup[:n] if want_flags else None), {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.pbsgpu_comm_destroy(self._h)

@@ -404,11 +404,33 @@ def _patched_main(argv):
     torch.cuda.device_count = lambda: 1
     pbs_plus_amd.Engine = _FakeEngine
     pbs_plus_amd.PageRing = _FakeRing
+    if os.environ.get("PBS_BENCH_REDUCE") == "cabi":
+        # stand-in for pbs_plus_amd.Comm (pbsgpu_comm_create needs RCCL and one GPU per rank): the same collective contract —
+        # dedup(records, cap) on every rank, statistics of the union — over the process group that is already up
+        import pbs_plus_amd.dist as pdist
+
+        class _FakeComm:
+            def __init__(self, eng):
+                self.eng, self.calls = eng, 0
+
+            def dedup(self, recs, cap_records, want_flags=False):
+                import torch.distributed as dist
+                assert recs.size <= cap_records
+                parts = [None] * dist.get_world_size()
+                dist.all_gather_object(parts, recs)
+                self.calls += 1
+                dup, stats = self.eng.dedup(np.concatenate(parts))
+                return None, stats
+
+            def close(self):
+                assert self.calls >= 2          # first contact + at least one timed reduce went through here
+
+        pdist.make_comm = lambda eng, device=None, group=None: _FakeComm(eng)
     sys.argv = ["bench.py"] + list(argv)
     bench.main()
 
 
-def _two_ranks(args):
+def _two_ranks(args, extra_env=None):
     import socket
     import subprocess
 
@@ -421,7 +443,7 @@ def _two_ranks(args):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), PBS_BENCH_BACKEND="gloo")
+                   MASTER_PORT=str(port), PBS_BENCH_BACKEND="gloo", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
@@ -470,6 +492,27 @@ def test_bench_ring_two_ranks_gloo_reduces_in_step_order():
     assert "page ring" in d["config"]["path"] and "2 rank" in d["config"]["parallelism"]
     st = d["results"]["dedup_last_step"]
     assert st["nrecords"] > 0 and st["nunique"] == st["nrecords"]        # two different files: no shared chunks
+
+
+def test_bench_two_ranks_time_the_reduce_of_the_c_abi_communicator():
+    """Round 6: the digest-set reduce INSIDE the timed region of an N-rank line goes through the C ABI's own communicator
+    (pbsgpu_comm_create + pbsgpu_digest_allgather_dedup: what a Go host binds) whenever every rank has its own GPU; the
+    torch.distributed path is the cross-check outside the timed region (rounds 3-5: the other way round). World size 2 over
+    gloo with a stand-in communicator that keeps the collective contract: every timed reduce and the first contact go through
+    it, the line says so, and both paths report the same union."""
+    d = _two_ranks(["--gpus", "2", "--gib", str(12 / 1024), "--avg", "65536", "--steps", "4", "--warmup", "1",
+                    "--ring-streams", "2", "--no-cpu-baseline"], extra_env={"PBS_BENCH_REDUCE": "cabi"})
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    c = d["results"]["c_abi_digest_reduce"]
+    assert c["ok"] is True and c["timed_through_c_abi"] is True and c["equals_torch_path"] is True, c
+    assert "pbsgpu_digest_allgather_dedup" in c["timed_path"]
+    assert d["results"]["dedup_last_step"]["nrecords"] == c["stats"]["nrecords"] or d["results"]["dedup_last_step"]["nrecords"] > 0
+    # ... and the batch workloads take the same switch
+    d2 = _two_ranks(["--gpus", "2", "--workload", "corpus_dup", "--gib", str(64 / 1024), "--file-mib", "1", "--avg", "65536",
+                     "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], extra_env={"PBS_BENCH_REDUCE": "cabi"})
+    assert "pbsgpu_digest_allgather_dedup" in d2["results"]["digest_reduce_path"]
+    dd = d2["results"]["dedup"]
+    assert abs(dd["duplicate_bytes_frac"] - dd["expected_duplicate_frac"]) < 1e-9
 
 
 @pytest.mark.parametrize("mode", ["ring_manyfiles", "ring_corpus_dup", "ring_rechunk"])

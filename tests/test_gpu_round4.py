@@ -223,13 +223,19 @@ def test_comm_digest_set_reduce_behind_the_c_abi_one_rank(gpu_lib, O):
         assert np.array_equal(dup, want_dup) and stats == want_stats, (stats, want_stats)
     dup0, stats0 = comm.dedup(recs[:0], 16)
     assert dup0.size == 0 and stats0["nrecords"] == 0
+    # records that already are in DEVICE memory (round 6): no host round trip, same answer
+    dbuf = eng.alloc(recs.nbytes)
+    dbuf.upload(recs.view(np.uint8))
+    dupd, statsd = comm.dedup_device(dbuf.ptr, n, n + 5)
+    assert np.array_equal(dupd, want_dup) and statsd == want_stats, (statsd, want_stats)
+    dbuf.free()
     comm.close()
     eng.close()
 
 
 def test_bench_ring_forced_dist_runs_the_c_abi_reduce_beside_torch(gpu_lib):
-    """bench.py's multi-rank branch with ONE rank over RCCL (PBS_BENCH_FORCE_DIST): the line carries the result of the
-    digest-set reduce through libpbsgpu's own communicator, equal to the torch.distributed path's."""
+    """bench.py's multi-rank branch with ONE rank over RCCL (PBS_BENCH_FORCE_DIST): the digest-set reduce of the timed region
+    goes through libpbsgpu's own communicator, and equals the torch.distributed path's."""
     env = dict(os.environ, PBS_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
@@ -240,6 +246,8 @@ def test_bench_ring_forced_dist_runs_the_c_abi_reduce_beside_torch(gpu_lib):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     c = d["results"]["c_abi_digest_reduce"]
     assert c["ok"] is True and c["equals_torch_path"] is True and c["stats"]["nrecords"] > 0, c
+    # round 6: the reduce INSIDE the timed region is the C ABI's (libpbsgpu's own RCCL communicator), torch is the cross-check
+    assert c["timed_through_c_abi"] is True and "pbsgpu_digest_allgather_dedup" in c["timed_path"], c
 
 
 def test_ring_piece_table_producer_matches_the_host_rebuild(gpu_lib, O):
