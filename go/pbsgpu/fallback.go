@@ -10,6 +10,7 @@ package pbsgpu
 import (
 	"errors"
 	"io"
+	"unsafe"
 )
 
 // ErrNotBuilt is returned by every entry point in non-GPU builds.
@@ -125,6 +126,8 @@ func (c *Chunker) Close()                   {}
 func NewCommID() ([CommIDBytes]byte, error)                                      { return [CommIDBytes]byte{}, ErrNotBuilt }
 func (c *Comm) Dedup([]ChunkInfo, uint64) ([]bool, DedupStats, error)            { return nil, DedupStats{}, ErrNotBuilt }
 func (c *Comm) Close()                                                           {}
+func (c *Comm) SplitStream(unsafe.Pointer, uint64, uint64) ([]ChunkInfo, error)  { return nil, ErrNotBuilt }
+func SplitPlan(uint64, int, int, uint32) (uint64, uint64, uint64, uint64, error) { return 0, 0, 0, 0, ErrNotBuilt }
 func CommLastError() string                                                      { return "" }
 func (r *Ring) Open() (uint32, error)                                            { return 0, ErrNotBuilt }
 func (r *Ring) Reserve(uint32) (uintptr, uint64, error)                          { return 0, 0, ErrNotBuilt }

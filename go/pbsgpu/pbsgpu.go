@@ -925,6 +925,27 @@ func (c *Comm) Dedup(recs []ChunkInfo, capRecords uint64) ([]bool, DedupStats, e
 	return out, DedupStats{uint64(st.nrecords), uint64(st.nunique), uint64(st.total_bytes), uint64(st.unique_bytes)}, nil
 }
 
+// SplitPlan says which bytes of ONE stream of totalLen bytes rank `rank` of `world` owns, [ownStart, ownEnd), and which it
+// must hold in device memory, [lo, hi): 63 bytes of window halo to the left, one maximum chunk to the right (arithmetic only).
+func SplitPlan(totalLen uint64, world, rank int, maxChunk uint32) (ownStart, ownEnd, lo, hi uint64, err error) {
+	var a, b, l, h C.uint64_t
+	err = check(C.pbsgpu_split_plan(C.uint64_t(totalLen), C.int(world), C.int(rank), C.uint32_t(maxChunk), &a, &b, &l, &h), "split_plan")
+	return uint64(a), uint64(b), uint64(l), uint64(h), err
+}
+
+// SplitStream cuts and hashes ONE stream of totalLen bytes that is split over the ranks of the communicator (collective;
+// BASELINE configs[1] at N > 1 when the stream does not fit one GPU). local = DEVICE pointer to this rank's bytes [lo, hi) of
+// SplitPlan. Every rank gets the whole stream's records, in stream order.
+func (c *Comm) SplitStream(local unsafe.Pointer, totalLen uint64, capRecords uint64) ([]ChunkInfo, error) {
+	defer runtime.KeepAlive(c)
+	buf := make([]C.pbsgpu_record, capRecords+1)
+	var n C.uint64_t
+	if err := check(C.pbsgpu_comm_split_stream(c.h, local, C.uint64_t(totalLen), &buf[0], C.uint64_t(capRecords), &n), "comm_split_stream"); err != nil {
+		return nil, err
+	}
+	return fromRecords(buf, int(n)), nil
+}
+
 // CommLastError is what RCCL reported when a communicator call of this process last failed ("" = nothing yet): a
 // PBSGPU_E_HIP from NewComm / Dedup does not say whether the bootstrap found no network interface or the device faulted.
 func CommLastError() string { return C.GoString(C.pbsgpu_comm_last_error()) }

@@ -514,6 +514,17 @@ const char *pbsgpu_comm_last_error(void);
  * all-gathers before the large one, so no rank is left waiting inside it. (Only comm / stats NULL fail locally.) */
 int pbsgpu_digest_allgather_dedup(pbsgpu_comm *comm, const pbsgpu_record *recs, uint64_t n, uint64_t cap_records,
                                   uint8_t *dup_own /* n, may be NULL */, pbsgpu_dedup_stats *stats);
+/* One stream split over the ranks (BASELINE.json configs[1] at N > 1 when the stream is larger than one GPU's memory;
+ * rounds 2-5 had this in Python only). pbsgpu_split_plan is arithmetic: rank `rank` of `world` OWNS [*own_start, *own_end)
+ * and must HOLD [*lo, *hi) in device memory — 63 bytes of window halo to the left, one maximum chunk to the right.
+ * pbsgpu_comm_split_stream is collective: `local` = device pointer to this rank's bytes [lo, hi); every rank scans its own
+ * bytes, the candidate END offsets and later the digests are all-gathered (two small exchanges, errors collective as
+ * above), the cut chain is resolved identically everywhere, each rank hashes the chunks that START in its range.
+ * out[0 .. *nrecords) = the WHOLE stream's records in stream order, identical on every rank. */
+int pbsgpu_split_plan(uint64_t total_len, int world, int rank, uint32_t max_chunk, uint64_t *own_start, uint64_t *own_end,
+                      uint64_t *lo, uint64_t *hi);
+int pbsgpu_comm_split_stream(pbsgpu_comm *comm, const void *local, uint64_t total_len, pbsgpu_record *out, uint64_t cap,
+                             uint64_t *nrecords);
 
 /* ---- dynamic index (.didx) encoding ------------------------------------------
  * On-disk form of the record list: datastore.NewDynamicIndexWriter(ctime)

@@ -212,6 +212,8 @@ SYMBOLS = {
     "pbsgpu_comm_rank": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pbsgpu_comm_last_error": (C.c_char_p, []),
     "pbsgpu_digest_allgather_dedup": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(DedupStats)]),
+    "pbsgpu_split_plan": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_uint32] + [C.POINTER(C.c_uint64)] * 4),
+    "pbsgpu_comm_split_stream": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pbsgpu_didx_size": (C.c_int, [C.c_uint64, _U64P]),
     "pbsgpu_didx_encode": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_int64, _P, C.c_uint64]),
     "pbsgpu_didx_decode": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _U64P, C.POINTER(C.c_int64), _P]),

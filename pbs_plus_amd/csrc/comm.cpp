@@ -326,4 +326,134 @@ int pbsgpu_digest_allgather_dedup(pbsgpu_comm *c, const pbsgpu_record *recs, uin
     return PBSGPU_OK;
 }
 
+// ---- one stream split over the ranks (second row) ------------------------------------------------------
+// Rank r OWNS [r * S, min((r + 1) * S, T)) of the stream (S = T / world rounded up to 8 bytes) and must HOLD [lo, hi): 63
+// bytes of window halo to the left (for the candidates it reports), one maximum chunk to the right (every chunk that STARTS
+// in its range is then local).
+int pbsgpu_split_plan(uint64_t total_len, int world, int rank, uint32_t max_chunk, uint64_t *own_start, uint64_t *own_end,
+                      uint64_t *lo, uint64_t *hi) {
+    if (world < 1 || rank < 0 || rank >= world || !own_start || !own_end || !lo || !hi) return PBSGPU_E_INVALID;
+    uint64_t S = (total_len + (uint64_t)world - 1) / (uint64_t)world;
+    S = (S + 7) & ~7ull;
+    const uint64_t a = std::min((uint64_t)rank * S, total_len), b = std::min(((uint64_t)rank + 1) * S, total_len);
+    *own_start = a;
+    *own_end = b;
+    *lo = a > 63 ? a - 63 : 0;
+    *hi = std::min(total_len, b + (uint64_t)max_chunk);
+    return PBSGPU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// all-gather of one variable-length byte string per rank (host memory in, host memory out): sizes travel in an agreement
+// step (a rank that failed before says so there, and every rank returns its error together), payloads padded to the largest
+int comm_allgather_var(pbsgpu_comm *c, int status, const void *mine, uint64_t nbytes, std::vector<std::vector<uint8_t>> &parts) {
+    CHK(comm_agree(c, status, status == PBSGPU_OK ? nbytes : 0, 0));
+    if (const int v = comm_verdict(c); v != PBSGPU_OK) return v;
+    const CommHeader *hh = c->h_hdr.as<CommHeader>() + 1;
+    uint64_t mx = 0;
+    std::vector<uint64_t> cnt((size_t)c->world);
+    for (int r = 0; r < c->world; ++r) {
+        cnt[(size_t)r] = hh[r].n;
+        mx = std::max(mx, hh[r].n);
+    }
+    parts.assign((size_t)c->world, {});
+    if (mx == 0) return PBSGPU_OK;
+    const uint64_t slot = (mx + 63) & ~63ull;
+    int st = c->send.ensure(slot);
+    if (st == PBSGPU_OK) st = c->recv.ensure(slot * (uint64_t)c->world);
+    if (st == PBSGPU_OK) st = c->h_send.ensure(slot * (uint64_t)c->world);
+    CHK(comm_agree(c, st, nbytes, 0));
+    if (const int v = comm_verdict(c); v != PBSGPU_OK) return v;
+    if (nbytes) HIPCHK(hipMemcpyAsync(c->send.p, mine, nbytes, hipMemcpyHostToDevice, c->st));
+    if (nbytes < slot) HIPCHK(hipMemsetAsync(c->send.as<uint8_t>() + nbytes, 0, slot - nbytes, c->st));
+    if (const ncclResult_t rc = rccl().AllGather(c->send.p, c->recv.p, slot, ncclUint8, c->comm, c->st); rc != ncclSuccess)
+        return comm_fail("ncclAllGather (split stream)", rc);
+    HIPCHK(hipMemcpyAsync(c->h_send.p, c->recv.p, slot * (uint64_t)c->world, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (int r = 0; r < c->world; ++r) {
+        const uint8_t *p = c->h_send.as<uint8_t>() + (uint64_t)r * slot;
+        parts[(size_t)r].assign(p, p + cnt[(size_t)r]);
+    }
+    return PBSGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// Cut + hash ONE stream of `total_len` bytes that is split over the ranks of `comm` (collective; BASELINE.json configs[1]
+// at N > 1 when the stream does not fit one GPU). `local` = DEVICE pointer to this rank's bytes [lo, hi) of pbsgpu_split_plan.
+// Data path: every rank scans its own bytes. Two exchange steps: the candidate END offsets that fall into the ranks' OWN
+// ranges (a few per MiB), then the digests. The cut chain is resolved identically on every rank from the gathered list (the
+// resolve kernel alone), each rank hashes the chunks that START in its range; out[0 .. *nrecords) = the WHOLE stream's
+// records in stream order, identical on every rank (segment 0). (rounds 2-5: pbs_plus_amd/dist.py over torch.distributed.)
+int pbsgpu_comm_split_stream(pbsgpu_comm *c, const void *local, uint64_t total_len, pbsgpu_record *out, uint64_t cap,
+                             uint64_t *nrecords) {
+    if (!c || !nrecords) return PBSGPU_E_INVALID;
+    pbsgpu_engine *e = c->eng;
+    std::lock_guard<std::mutex> lk(c->mu);
+    CHK(set_device(e));
+    uint64_t own_a = 0, own_b = 0, lo = 0, hi = 0;
+    CHK(pbsgpu_split_plan(total_len, c->world, c->rank, e->cfg.max, &own_a, &own_b, &lo, &hi));
+    // ---- candidates of the own range, in stream coordinates ----
+    int mine = PBSGPU_OK;
+    std::vector<uint64_t> ends;
+    if ((!local && hi > lo) || (!out && cap)) mine = PBSGPU_E_INVALID;
+    if (mine == PBSGPU_OK && hi > lo) {
+        uint64_t n = 0;
+        ends.resize((size_t)((hi - lo) / std::max<uint64_t>(e->cfg.avg / 4, 64) + 1024));
+        mine = pbsgpu_candidates_device(e, local, hi - lo, ends.data(), ends.size(), &n);
+        if (mine == PBSGPU_E_CAPACITY) {
+            ends.resize((size_t)n);
+            mine = pbsgpu_candidates_device(e, local, hi - lo, ends.data(), ends.size(), &n);
+        }
+        if (mine == PBSGPU_OK) {
+            ends.resize((size_t)n);
+            size_t k = 0;
+            for (uint64_t x : ends) {
+                const uint64_t s = x + lo;
+                if (s > own_a && s <= own_b) ends[k++] = s;  // every candidate is reported by exactly one rank
+            }
+            ends.resize(k);
+        }
+    }
+    std::vector<std::vector<uint8_t>> parts;
+    CHK(comm_allgather_var(c, mine, ends.data(), ends.size() * 8, parts));
+    std::vector<uint64_t> all;
+    for (auto &p : parts) {
+        const size_t at = all.size();
+        all.resize(at + p.size() / 8);
+        std::memcpy(all.data() + at, p.data(), p.size() / 8 * 8);
+    }
+    // ---- the cut chain, identically on every rank ----
+    std::vector<pbsgpu_record> recs((size_t)(total_len / std::min<uint32_t>(e->effmin, e->cfg.min) + 2));
+    uint64_t nrec = 0;
+    mine = pbsgpu_resolve_candidates(e, all.data(), all.size(), total_len, recs.data(), recs.size(), &nrec);
+    // ---- digests of the chunks that START in the own range ----
+    std::vector<pbsgpu_segment> segs;
+    std::vector<uint8_t> digs;
+    if (mine == PBSGPU_OK) {
+        for (uint64_t i = 0; i < nrec; ++i) {
+            const uint64_t start = recs[i].end - recs[i].size;
+            if (start >= own_a && start < own_b) segs.push_back(pbsgpu_segment{start - lo, recs[i].size});
+        }
+        digs.resize(segs.size() * 32);
+        if (!segs.empty() && segs.size() < (1ull << 32))
+            mine = pbsgpu_sha256_many_device(e, local, hi - lo, segs.data(), (uint32_t)segs.size(), digs.data());
+    }
+    CHK(comm_allgather_var(c, mine, digs.data(), digs.size(), parts));
+    *nrecords = nrec;
+    if (nrec > cap) return PBSGPU_E_CAPACITY;
+    // ranks own contiguous, ascending runs of chunks: rank order == stream order
+    uint64_t k = 0;
+    for (auto &p : parts)
+        for (size_t o = 0; o + 32 <= p.size() && k < nrec; o += 32, ++k) {
+            out[k] = recs[(size_t)k];
+            std::memcpy(out[k].digest, p.data() + o, 32);
+            out[k].segment = 0;
+        }
+    return k == nrec ? PBSGPU_OK : PBSGPU_E_STATE;  // (every chunk starts in exactly one rank's range)
+}
+
 }  // extern "C"

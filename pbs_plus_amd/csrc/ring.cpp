@@ -287,7 +287,16 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     const uint32_t minsz = std::min(e->effmin, e->cfg.min);
     const uint64_t feed = e->sugg_feed.load(std::memory_order_relaxed);
     const uint64_t look = feed > 1 ? (uint64_t)e->cfg.max : 0;  // reader-buffer rule: boundaries just beyond the bytes matter too
-    for (uint32_t si = 0; si < r->slots.size() && np < r->round_pages; ++si) {
+    // While the services run the cut side has a quarter of the chip, and there a FULL round costs it 1.5x more per byte than a
+    // half one (the refill of round n + 1 then runs beside the scan of round n on the same CUs, and nothing of a 4.3 GB round
+    // is still in the last-level cache when the scan comes to it): measured with 184 + 8 service CUs, where every round was
+    // full, 680 GiB/s of feed phase at 256 pages per round, 763 at 128, 780 at 32 (profiles/r06_round_size_bistability.log).
+    // A ring that falls behind once grows its rounds, which makes it fall behind further: round 5's "unexplained" 184 + 8
+    // cliff and its few-large-rounds regime. So a round takes at most HALF the configured pages while a service runs; the
+    // whole-chip cut-ahead of an idle ring (no service yet: 64 GiB in ~20 ms) keeps full rounds.
+    const uint32_t round_cap = r->svc == SvcState::Stopped ? r->round_pages
+                                                           : std::max(std::min(r->round_pages, r->min_round_pages), r->round_pages / 2);
+    for (uint32_t si = 0; si < r->slots.size() && np < round_cap; ++si) {
         StreamSlot &s = r->slots[si];
         if (!s.open || (s.ready.empty() && !s.zero_final)) continue;
         pbsk::RingSeg g{};
@@ -298,7 +307,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
         const uint64_t end_old = s.bytes_enqueued;
         uint64_t end = end_old;
         uint32_t take = 0;
-        while (!s.ready.empty() && take < kPagesPerStreamRound && np < r->round_pages) {
+        while (!s.ready.empty() && take < kPagesPerStreamRound && np < round_cap) {
             const PageReq &q = s.ready.front();
             pbsk::RingPage p{};
             p.phys = q.phys;

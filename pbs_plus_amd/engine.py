@@ -425,6 +425,14 @@ class PayloadStream:
             pass
 
 
+def split_plan(total_len: int, world: int, rank: int, max_chunk: int):
+    """(own_start, own_end, lo, hi) of `rank` for a stream split over `world` ranks (pbsgpu_split_plan: arithmetic only)."""
+    v = [C.c_uint64() for _ in range(4)]
+    check(_lib.lib().pbsgpu_split_plan(int(total_len), int(world), int(rank), int(max_chunk), *[C.byref(x) for x in v]),
+          "split_plan")
+    return tuple(int(x.value) for x in v)
+
+
 class Comm:
     """The multi-GPU digest-set reduce through the C ABI (pbsgpu_comm_*): ONE RCCL all-gather of the ranks' (digest, size)
     records over xGMI + the device dedup — what a Go host binds directly (go/pbsgpu: Comm), no torch involved.
@@ -458,6 +466,16 @@ class Comm:
                                                     int(cap_records), dup.ctypes.data if want_flags else None,
                                                     C.byref(st)), "digest_allgather_dedup")
         return (dup[: recs.size] if want_flags else None), {k: getattr(st, k) for k, _ in _lib.DedupStats._fields_}
+
+    def split_stream(self, local_dptr: int, total_len: int) -> np.ndarray:
+        """Cut + hash ONE stream of total_len bytes that is split over the ranks (collective, pbsgpu_comm_split_stream):
+        local_dptr = device pointer to this rank's bytes [lo, hi) of split_plan(). The whole stream's records."""
+        cap = int(total_len) // max(64, min(self._eng.config.MinSize, 1 << 30)) + 16
+        out = np.zeros(cap, dtype=RECORD_DTYPE)
+        n = C.c_uint64()
+        check(self._L.pbsgpu_comm_split_stream(self._h, int(local_dptr) if local_dptr else None, int(total_len),
+                                               out.ctypes.data, cap, C.byref(n)), "comm_split_stream")
+        return out[: n.value].copy()
 
     def dedup_device(self, dptr: int, n: int, cap_records: int, want_flags: bool = True):
         """dedup() on n records that already are in DEVICE memory (they travel device -> device, no host round trip)."""

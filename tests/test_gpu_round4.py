@@ -233,6 +233,35 @@ def test_comm_digest_set_reduce_behind_the_c_abi_one_rank(gpu_lib, O):
     eng.close()
 
 
+def test_single_stream_split_behind_the_c_abi_one_rank(gpu_lib, O):
+    """pbsgpu_comm_split_stream (round 6; rounds 2-5: Python over torch.distributed): one stream cut and hashed through the
+    communicator's two exchange steps — candidates of the own range, digests of the chunks that start in it — with world size
+    1 on the one GPU here (scan -> all-gather -> resolve -> hash -> all-gather: the same code as with N ranks; the two-rank
+    arithmetic is checked on the CPU, tests/test_host_logic.py). Bit-exact vs the oracle, incl. a dense stretch and a tail
+    shorter than a block."""
+    import gc
+
+    from pbs_plus_amd import Comm
+    from pbs_plus_amd.engine import split_plan
+
+    gc.collect()
+    for avg, n in ((4096, 3_000_017), (4 << 20, (96 << 20) + 5)):
+        eng = _engine(avg)
+        cfg = O.new_config(avg)
+        data = O.fill(n, 77, 3)
+        assert split_plan(n, 1, 0, cfg.max) == (0, n, 0, n)
+        buf = eng.alloc(n + 64)
+        buf.upload(data)
+        comm = Comm(eng, Comm.unique_id(), 0, 1)
+        got = comm.split_stream(buf.ptr, n)
+        want = O.chunk_and_digest(cfg, data, [(0, n)])
+        assert got.size == want.size and np.array_equal(got["end"], want["end"]) and np.array_equal(got["digest"], want["digest"])
+        assert comm.split_stream(0, 0).size == 0
+        comm.close()
+        buf.free()
+        eng.close()
+
+
 def test_bench_ring_forced_dist_runs_the_c_abi_reduce_beside_torch(gpu_lib):
     """bench.py's multi-rank branch with ONE rank over RCCL (PBS_BENCH_FORCE_DIST): the digest-set reduce of the timed region
     goes through libpbsgpu's own communicator, and equals the torch.distributed path's."""

@@ -262,3 +262,21 @@ def test_ingest_corpus_more_ranks_than_segments(ws):
     st = got[0][2]
     assert st["total_bytes"] == (3 << 20) + (1 << 20) + 77 + 70000 and st["nrecords"] == allr.size
     assert st["total_bytes"] - st["unique_bytes"] > 0          # the shared prefix of segments 1 and 2 dedups
+
+
+def test_split_plan_behind_the_c_abi_equals_the_python_plan():
+    """pbsgpu_split_plan (round 6: the single-stream split lives behind the C ABI, a Go host needs no Python for BASELINE
+    configs[1] at N > 1) against dist.split_plan, the arithmetic the gloo tests of rounds 2-5 exercised: owned ranges tile the
+    stream, held ranges reach 63 bytes to the left and one maximum chunk to the right."""
+    from pbs_plus_amd import _lib
+    from pbs_plus_amd.dist import split_plan as py_plan
+    from pbs_plus_amd.engine import split_plan
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    for total in (0, 1, 63, 64, 1000, (64 << 30) + 12345, 1 << 40):
+        for world in (1, 2, 3, 8):
+            want = py_plan(total, world, 16 << 20)
+            got = [split_plan(total, world, r, 16 << 20) for r in range(world)]
+            assert got == [tuple(int(x) for x in w) for w in want], (total, world)
+            assert got[0][0] == 0 and got[-1][1] == total and all(got[r][1] == got[r + 1][0] for r in range(world - 1))
