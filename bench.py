@@ -1314,7 +1314,7 @@ def ring_files_run(a, rank, local_rank, world, ctx, mode):
 
 
 def load_traffic_ring():
-    for name in ("r05_traffic.json", "r04_traffic.json"):   # PMC passes on the ring's own kernels (newest round first)
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):   # PMC passes on the ring's own kernels (newest round first)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tj = json.load(f)

@@ -578,6 +578,17 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
                 break;
             }
             wb += 64;
+            // none of these 64 and none of the next 64 either: candidate-dense data lists thousands of candidates per MiB (a
+            // subset of an overflowed tile's: DenseTiles) — jump to the first one >= tlo by binary search instead of stepping
+            // (a stream whose every position is a candidate: 41 us per cut stepping through ~8 k entries, measured)
+            if (wb + 63 < n && cands[wb + 63] < tlo) {
+                uint64_t l2 = wb + 64, h2 = n;
+                while (l2 < h2) {
+                    const uint64_t mid = (l2 + h2) >> 1;
+                    if (cands[mid] < tlo) l2 = mid + 1; else h2 = mid;
+                }
+                wb = l2;
+            }
             cv = (wb + lane < n) ? cands[wb + lane] : ~0ull;
         }
         if (__builtin_expect(dz.tile_cnt != nullptr, 0)) c = dense_refine(dz, ds, tlo, min(thi, B), c);  // (some tile overflowed its slots)
