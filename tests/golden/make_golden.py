@@ -34,19 +34,48 @@ CASES = [
 
 
 def build_case(name, avg, segs):
+    """segs: (seed, kind, length) generator segments, or (pattern bytes, length): a crafted period repeated (round 6)"""
     cfg = O.new_config(avg)
-    parts, table, off = [], [], 0
-    for seed, kind, n in segs:
-        parts.append(O.fill(n, seed, kind))
+    parts, table, off, spec = [], [], 0, []
+    for sg in segs:
+        if len(sg) == 2:
+            pat, n = sg
+            parts.append(np.tile(pat, n // pat.size + 1)[:n].copy())
+            spec.append({"kind": 100, "pattern": bytes(pat).hex(), "length": n})
+        else:
+            seed, kind, n = sg
+            parts.append(O.fill(n, seed, kind))
+            spec.append({"seed": seed, "kind": kind, "length": n})
         table.append((off, n))
         off += n
     data = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
     recs = O.chunk_and_digest(cfg, data, table, impl=0)
     return {
-        "name": name, "avg": avg,
-        "segments": [{"seed": s, "kind": k, "length": n} for s, k, n in segs],
+        "name": name, "avg": avg, "segments": spec,
         "records": [[int(r["segment"]), int(r["end"]), int(r["size"]), bytes(r["digest"]).hex()] for r in recs],
     }
+
+
+def crafted_cases():
+    """Candidate-DENSE streams (tests/dense_inputs.py): a 64-byte period whose window hash is 0xFFFFFFFF makes every position
+    a candidate (the serial chunker cuts at the minimum every time), one that passes the break test at one phase gives a
+    candidate per period, a period of 16 cancels to none (max-size cuts). The engine resolves such data exactly since round 6
+    (rounds 3-5: PBSGPU_E_DENSITY on the streaming paths); a maintainer with the Go module pins the same behaviour with
+    tools/golden/main.go, which reads the patterns from THIS file's cases."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dense_inputs as D
+
+    allp = D.all_candidate_pattern(O.default_table())
+    one4k = D.one_phase_pattern(O, O.new_config(4096))
+    one64k = D.one_phase_pattern(O, O.new_config(65536))
+    assert one4k is not None and one64k is not None
+    return [
+        ("period64_every_position_avg4k", 4096, [(allp, 300_000)]),
+        ("period64_one_phase_avg4k", 4096, [(71, 0, 70_001), (one4k, 200_000), (72, 0, 5_003), (allp, 64), (allp, 65), (allp, 1_024)]),
+        ("period64_one_phase_avg64k", 65536, [(one64k, 3 << 20), (73, 3, 1 << 20)]),
+        ("period16_no_candidate_avg4k", 4096, [(allp[:16], 100_000)]),
+        ("period64_every_position_avg4m", 4 << 20, [(allp, (40 << 20) + 7)]),
+    ]
 
 
 def counter_case():
@@ -61,7 +90,7 @@ def counter_case():
 
 if __name__ == "__main__":
     out = {"schema": "pbsgpu-golden-v1", "generator": "oracle (C restatement), parity unpinned vs pbs-plus/pxar v0.34.0",
-           "cases": [build_case(*c) for c in CASES] + [counter_case()]}
+           "cases": [build_case(*c) for c in CASES] + [counter_case()] + [build_case(*c) for c in crafted_cases()]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chunks_v1.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=0, separators=(",", ":"))

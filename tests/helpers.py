@@ -85,6 +85,12 @@ def golden_case_data(O, case):
         return data, [(0, data.size)]
     parts, table, off = [], [], 0
     for s in case["segments"]:
+        if "pattern" in s:   # a crafted period (round 6: candidate-dense data): the pattern's bytes repeated
+            pat = np.frombuffer(bytes.fromhex(s["pattern"]), dtype=np.uint8)
+            parts.append(np.tile(pat, s["length"] // pat.size + 1)[: s["length"]].copy())
+            table.append((off, s["length"]))
+            off += s["length"]
+            continue
         parts.append(O.fill(s["length"], s["seed"], s["kind"]))
         table.append((off, s["length"]))
         off += s["length"]

@@ -63,6 +63,58 @@ type segSpec struct {
 	Seed   uint64 `json:"seed"`
 	Kind   uint32 `json:"kind"`
 	Length uint64 `json:"length"`
+	// Kind 100 (round 6): a crafted period — the pattern's bytes repeated. Candidate-DENSE data: with the casync table a
+	// 64-byte pattern whose window hash is 0xFFFFFFFF makes every position a candidate, one that passes the break test at one
+	// phase gives a candidate per period (tests/dense_inputs.py). The serial chunker cuts such data at the minimum size; the
+	// engine must too (it answered PBSGPU_E_DENSITY on its streaming paths until ABI v4). The patterns are read from the
+	// committed fixture so that both sides chunk the same bytes.
+	Pattern string `json:"pattern,omitempty"`
+}
+
+// craftedCases: the "period*" cases of tests/golden/chunks_v1.json (names, averages, segment specs incl. the patterns)
+func craftedCases(path string) []goldenCase {
+	raw, err := os.ReadFile(path)
+	if err != nil {
+		fmt.Fprintln(os.Stderr, "no crafted cases:", err)
+		return nil
+	}
+	var fx struct {
+		Cases []struct {
+			Name     string          `json:"name"`
+			Avg      int             `json:"avg"`
+			Segments json.RawMessage `json:"segments"`
+		} `json:"cases"`
+	}
+	if err := json.Unmarshal(raw, &fx); err != nil {
+		panic(err)
+	}
+	var out []goldenCase
+	for _, c := range fx.Cases {
+		if len(c.Name) < 6 || c.Name[:6] != "period" {
+			continue
+		}
+		var segs []segSpec
+		if err := json.Unmarshal(c.Segments, &segs); err != nil {
+			panic(err)
+		}
+		out = append(out, goldenCase{Name: c.Name, Avg: c.Avg, Segments: segs})
+	}
+	return out
+}
+
+func segmentBytes(s segSpec) []byte {
+	if s.Pattern == "" {
+		return fill(s.Length, s.Seed, s.Kind)
+	}
+	pat, err := hex.DecodeString(s.Pattern)
+	if err != nil || len(pat) == 0 {
+		panic("bad pattern")
+	}
+	out := make([]byte, s.Length)
+	for i := range out {
+		out[i] = pat[i%len(pat)]
+	}
+	return out
 }
 
 type goldenCase struct {
@@ -106,11 +158,12 @@ func fill(n, seed uint64, kind uint32) []byte {
 
 func main() {
 	cases := []goldenCase{
-		{Name: "rand_avg4k", Avg: 4096, Segments: []segSpec{{11, 0, 1 << 20}}},
-		{Name: "rand_avg64k", Avg: 65536, Segments: []segSpec{{31, 0, 8 << 20}}},
-		{Name: "zero_extents_avg64k", Avg: 65536, Segments: []segSpec{{41, 3, 6 << 20}, {42, 1, 1 << 20}}},
-		{Name: "rand_avg4m", Avg: 4 << 20, Segments: []segSpec{{51, 0, 48 << 20}}},
+		{Name: "rand_avg4k", Avg: 4096, Segments: []segSpec{{Seed: 11, Kind: 0, Length: 1 << 20}}},
+		{Name: "rand_avg64k", Avg: 65536, Segments: []segSpec{{Seed: 31, Kind: 0, Length: 8 << 20}}},
+		{Name: "zero_extents_avg64k", Avg: 65536, Segments: []segSpec{{Seed: 41, Kind: 3, Length: 6 << 20}, {Seed: 42, Kind: 1, Length: 1 << 20}}},
+		{Name: "rand_avg4m", Avg: 4 << 20, Segments: []segSpec{{Seed: 51, Kind: 0, Length: 48 << 20}}},
 	}
+	cases = append(cases, craftedCases("../../tests/golden/chunks_v1.json")...) // (run from tools/golden: `make golden-go`)
 	for ci := range cases {
 		c := &cases[ci]
 		cfg, err := buzhash.NewConfig(c.Avg)
@@ -118,7 +171,7 @@ func main() {
 			panic(err)
 		}
 		for si, s := range c.Segments {
-			data := fill(s.Length, s.Seed, s.Kind)
+			data := segmentBytes(s)
 			ch := buzhash.NewChunker(cfg) // adjust to the module's constructor
 			start, pos := 0, 0
 			emit := func(end int) {
