@@ -294,8 +294,13 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     // A ring that falls behind once grows its rounds, which makes it fall behind further: round 5's "unexplained" 184 + 8
     // cliff and its few-large-rounds regime. So a round takes at most HALF the configured pages while a service runs; the
     // whole-chip cut-ahead of an idle ring (no service yet: 64 GiB in ~20 ms) keeps full rounds.
-    const uint32_t round_cap = r->svc == SvcState::Stopped ? r->round_pages
-                                                           : std::max(std::min(r->round_pages, r->min_round_pages), r->round_pages / 2);
+    // (one stream alone is cut-bound on the cut side's quarter of the chip once its service has started, with most lanes
+    // idle: there the full round is the faster one — one file alone 407 vs 395 ms — and nothing can pile up behind it)
+    uint32_t streams_waiting = 0;
+    for (auto &s : r->slots) streams_waiting += (s.open && !s.ready.empty()) ? 1u : 0u;
+    const uint32_t round_cap = (r->svc == SvcState::Stopped || streams_waiting < 2)
+                                   ? r->round_pages
+                                   : std::max(std::min(r->round_pages, r->min_round_pages), r->round_pages / 2);
     for (uint32_t si = 0; si < r->slots.size() && np < round_cap; ++si) {
         StreamSlot &s = r->slots[si];
         if (!s.open || (s.ready.empty() && !s.zero_final)) continue;
