@@ -4,6 +4,7 @@
 // the writers the reference drives (internal/pxarmount/commit_orchestrate.go:137-177,
 // internal/tapeio/converter.go:386-439). No CPU fallback exists in this file: every data
 // path launches the HIP kernels; without a device the engine cannot be created.
+#include <chrono>
 #include "engine_internal.h"
 
 #include <cstdio>
@@ -26,6 +27,7 @@ struct Graveyard {
     std::atomic<int> services{0};    // page-ring services launched on the device and not yet known to have ended
     std::atomic<int> park_request{0};
     std::atomic<uint32_t> park_gen{0};  // requests raised so far (a ring honours each request once)
+    double park_t = 0, park_backoff_ms = 0;  // (under mu) when the pending request was raised last, and how long until it is raised again
     std::mutex mu;                   // the lists below
     std::vector<void *> dev, host;
     uint64_t dev_bytes = 0;
@@ -57,6 +59,10 @@ void graveyard_flush(int device) {
         g.dev_bytes = 0;
     }
     g.park_request.store(0, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.park_backoff_ms = 0;
+    }
     if (d.empty() && h.empty()) return;
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
@@ -122,9 +128,22 @@ void dev_free(void *p) {
             const uint64_t cap = env_cap ? env_cap : (g.cap_bytes.load() ? g.cap_bytes.load() : (8ull << 30));
             g.dev.push_back(p);
             g.dev_bytes += size;
-            if (g.dev_bytes > cap && g.park_request.load(std::memory_order_relaxed) == 0) {
-                g.park_gen.fetch_add(1, std::memory_order_acq_rel);
-                g.park_request.store(1, std::memory_order_release);
+            if (g.dev_bytes > cap) {
+                // A request every ring honours ONCE can fail: ring A lets go, waits its grace period for ring B, B's service is
+                // still finishing its chunks when the grace ends, A starts again — and when B ends the count is back at one. The
+                // request would then stay pending, unanswerable, until a service ends for another reason, while frees keep
+                // being parked (one run in five of tests/test_gpu_round5.py's two-ring case ran out of memory that way). It is
+                // raised AGAIN, as a new generation, while frees arrive over the cap: after 0.5 s, then 1, 2, 4, 8 s — bounded,
+                // because a ring that nobody calls any more (a leaked engine) can never answer, and each new generation costs
+                // every other ring one more grace period.
+                const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                const bool pending = g.park_request.load(std::memory_order_relaxed) != 0;
+                if (!pending || t - g.park_t > g.park_backoff_ms) {
+                    g.park_backoff_ms = pending ? std::min(g.park_backoff_ms * 2.0, 8000.0) : 500.0;
+                    g.park_t = t;
+                    g.park_gen.fetch_add(1, std::memory_order_acq_rel);
+                    g.park_request.store(1, std::memory_order_release);
+                }
             }
             return;
         }

@@ -1085,6 +1085,36 @@ __device__ __forceinline__ void sha256_iv(uint32_t (&H)[8]) {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// Chunk data is read through GLOBAL-address-space pointers, never generic ones. A generic pointer compiles to flat_load,
+// which counts in lgkmcnt as well as vmcnt; the producer's `s_waitcnt lgkmcnt(0)` in front of every s_barrier (its LDS
+// writes must have landed) then also waits for the block it requested a moment ago, i.e. the FIFO's prefetch distance
+// collapses to less than one step and the step time follows the slowest of the wave's 320 outstanding requests
+// (rounds 3-5 shipped that; the address space is not inferred through the lambdas and the page select). global_load
+// counts in vmcnt only.
+#define PBSK_GLOBAL __attribute__((address_space(1)))
+typedef const PBSK_GLOBAL u32x4_a4 *gvec4_ptr;
+typedef const PBSK_GLOBAL uint32_t *gword_ptr;
+
+// What a producer lane WITHOUT a data block requests in a step (and ignores). The request itself is unconditional, FIVE
+// loads in every step of every lane: only then does the number of requests issued after a slot's own five not depend on
+// the path taken, and the compiler can await a slot with `s_waitcnt vmcnt(5)` — the other slot's requests stay in flight
+// — instead of vmcnt(0). (A branch around the loads, even a wave-uniform one, brings the vmcnt(0) back.)
+__device__ uint32_t kIdleBlock[32];
+
+// Request the 64 bytes at p (+ the 4 behind them if p is not 4-byte aligned) as raw little-endian dwords; `sel` = the
+// v_perm selector that byte-swaps and funnels them into big-endian message words.
+__device__ __forceinline__ void sha256_request_block(const uint8_t *p, uint32_t (&R)[17], uint32_t &sel) {
+    const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
+    const gvec4_ptr q = (gvec4_ptr)(p - o);
+    const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+    R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w;
+    R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w;
+    R[8] = v2.x; R[9] = v2.y; R[10] = v2.z; R[11] = v2.w;
+    R[12] = v3.x; R[13] = v3.y; R[14] = v3.z; R[15] = v3.w;
+    R[16] = ((gword_ptr)(p - o))[o ? 16 : 15];  // aligned: nothing behind the block is touched (the word is not selected)
+    sel = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
+}
+
 // Raw little-endian words of a block that is NOT 64 full data bytes (the last data bytes + 0x80 marker, zero fill, and
 // the big-endian bit length in the final block): the funnel-shifted data words come from aligned dword loads whose
 // addresses are clamped to the range's last valid dword (nothing beyond the chunk is touched), then everything behind the
@@ -1101,7 +1131,7 @@ __device__ __forceinline__ void sha256_tail_words(const uint8_t *base, uint64_t 
     if (valid) {
         const uint8_t *p = base + off;
         o = (uint32_t)((uintptr_t)p & 3u);
-        const uint32_t *a = reinterpret_cast<const uint32_t *>(p - o);
+        const gword_ptr a = (gword_ptr)(p - o);
         const uint32_t jmax = (o + valid - 1u) >> 2;               // last dword that holds a valid byte
 #pragma unroll
         for (int j = 0; j < 17; ++j) q[j] = a[min((uint32_t)j, jmax)];
@@ -1226,13 +1256,13 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
         if (off + 64 <= len) {  // pure data block: aligned dword loads + per-lane funnel selector
             const uint8_t *p = base + off;
             const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
-            const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
+            const gvec4_ptr q = (gvec4_ptr)(p - o);
             const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
             R[0] = v0.x; R[1] = v0.y; R[2] = v0.z; R[3] = v0.w;
             R[4] = v1.x; R[5] = v1.y; R[6] = v1.z; R[7] = v1.w;
             R[8] = v2.x; R[9] = v2.y; R[10] = v2.z; R[11] = v2.w;
             R[12] = v3.x; R[13] = v3.y; R[14] = v3.z; R[15] = v3.w;
-            R[16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
+            R[16] = o ? ((gword_ptr)(p - o))[16] : 0u;
             sel = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
         } else {  // tail / padding block (at most two per range)
             sha256_tail_words(base, len, off, blk + 1 == nblk, R);
@@ -1554,48 +1584,58 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
         auto prep = [&](const int s) {
             acquire(!have && !exhausted);
             uint32_t c = 0;
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(kIdleBlock);
+            const uint8_t *bb = base;
+            uint64_t off = 0;
+            bool tail = false, last = false;
             if (have) {
-                const uint64_t off = blk * 64;
-                const uint8_t *bb = base;
+                off = blk * 64;
                 if constexpr (Source::kRing) bb = (off < len1) ? base : base2;  // which physical page holds this block
-                if (off + 64 <= len) {  // pure data block: 4-byte aligned vector loads + funnel selector
-                    const uint8_t *p = bb + off;
-                    const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
-                    const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
-                    const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-                    R[s][0] = v0.x; R[s][1] = v0.y; R[s][2] = v0.z; R[s][3] = v0.w;
-                    R[s][4] = v1.x; R[s][5] = v1.y; R[s][6] = v1.z; R[s][7] = v1.w;
-                    R[s][8] = v2.x; R[s][9] = v2.y; R[s][10] = v2.z; R[s][11] = v2.w;
-                    R[s][12] = v3.x; R[s][13] = v3.y; R[s][14] = v3.z; R[s][15] = v3.w;
-                    R[s][16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
-                    selv[s] = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
-                } else {  // tail / padding block (<= 2 per range)
-                    sha256_tail_words(bb, len, off, blk + 1 == nblk, R[s]);
-                    selv[s] = 0x00010203u;
-                }
-                c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
+                last = blk + 1 == nblk;
+                if (off + 64 <= len) p = bb + off;  // pure data block: 4-byte aligned vector loads + funnel selector
+                else tail = true;                   // tail / padding block (<= 2 per range)
+                c = 1u | (last ? 2u : 0u);
                 dstv[s] = dst;
                 if constexpr (Source::kRing) pagesv[s] = pages;
                 if (++blk == nblk) have = false;
+            }
+            sha256_request_block(p, R[s], selv[s]);
+            if (tail) {
+                sha256_tail_words(bb, len, off, last, R[s]);
+                selv[s] = 0x00010203u;
             }
             cflag[s] = c;
         };
 
 #pragma unroll
         for (int s = 0; s < D; ++s) prep(s);
-        bool running = true;
+        // ONE exit, behind the last slot's step. Every path from a slot's requests back to the perm that consumes them then
+        // passes the other slot's five requests, and the slot is awaited with vmcnt(5). (An exit in the middle — a test of
+        // `running` per slot, or a return — is routed through the loop's latch by the structuriser: an edge from slot 0's
+        // barrier to the loop's head on which nothing follows slot 0's requests, and the wait at the head is vmcnt(0).)
+        // If the pairs drain at slot 0's barrier, slot 1's step is one empty step whose barrier only the producer waves
+        // still reach: the consumers have ended, and s_barrier waits for the surviving waves of a workgroup only.
+        bool drained = false;
         [[maybe_unused]] bool wg_busy = false;  // some pair of this workgroup had a block in the previous step
         [[maybe_unused]] RingProbe probe;
         [[maybe_unused]] const bool probe_on = blockIdx.x == 0 && wave == 2;
-        while (running) {
+        while (!drained) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
-                if (running) {
+                {
                     constexpr int kBufMask = 1;
                     const int pb = s & kBufMask;  // D is even: buffer parity is static
                     uint32_t W[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
+                    for (int j = 0; j < 16; ++j) {
+                        W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
+                        // pinned HERE (an empty volatile statement is neither sunk into the `any_cur` branch below nor
+                        // moved behind prep(s)): the slot's registers must be dead before its refill is requested, or
+                        // the refill lands in a second register set that is copied back at the loop's end behind an
+                        // s_waitcnt vmcnt(0) — every block would again be awaited in the step that requested it
+                        asm volatile("" : "+v"(W[j]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     const uint32_t c = cflag[s];
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
@@ -1694,7 +1734,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
-                    if (!any_alive(pb)) running = false;  // every pair drained
+                    drained = drained || __builtin_amdgcn_readfirstlane(any_alive(pb)) == 0u;  // every pair drained
                     if constexpr (Source::kRing) {
                         uint32_t w = curw[0][pb] | curw[1][pb];
                         if constexpr (DENSE) w |= curw[2][pb] | curw[3][pb];
@@ -1738,7 +1778,10 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                 }
                 H[0] += a; H[1] += b; H[2] += cc; H[3] += dd; H[4] += e; H[5] += f; H[6] += g; H[7] += h;
                 if (x.c & 2u) {
-                    uint32_t *o = reinterpret_cast<uint32_t *>(x.d);
+                    // (a GLOBAL pointer as well: one flat_store anywhere in the kernel — the two roles share one function — leaves
+                    // a "flat access may be pending" state on the paths into the producer's loop, and with it every wait
+                    // for a block slot becomes vmcnt(0) lgkmcnt(0))
+                    PBSK_GLOBAL uint32_t *o = (PBSK_GLOBAL uint32_t *)x.d;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(H[j]);
                     if constexpr (Source::kRing) {  // record cell in mapped pinned memory: digest first, then its flag
@@ -1998,30 +2041,26 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
             const bool pair_busy = ((hm >> (lane & ~1)) & 3ull) != 0ull;
             acquire(!roleB && !pair_busy && !exhausted);
             uint32_t c = 0;
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(kIdleBlock);  // (unconditional request: k_sha256_pair)
+            const uint8_t *bb = base;
+            uint64_t off = 0;
+            bool tail = false, last = false;
             if (have) {
-                const uint64_t off = blk * 64;
-                const uint8_t *bb = base;
+                off = blk * 64;
                 if constexpr (Source::kRing) bb = (off < len1) ? base : base2;
-                if (off + 64 <= len) {
-                    const uint8_t *p = bb + off;
-                    const uint32_t o = (uint32_t)((uintptr_t)p & 3u);
-                    const u32x4_a4 *q = reinterpret_cast<const u32x4_a4 *>(p - o);
-                    const u32x4_a4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-                    R[s][0] = v0.x; R[s][1] = v0.y; R[s][2] = v0.z; R[s][3] = v0.w;
-                    R[s][4] = v1.x; R[s][5] = v1.y; R[s][6] = v1.z; R[s][7] = v1.w;
-                    R[s][8] = v2.x; R[s][9] = v2.y; R[s][10] = v2.z; R[s][11] = v2.w;
-                    R[s][12] = v3.x; R[s][13] = v3.y; R[s][14] = v3.z; R[s][15] = v3.w;
-                    R[s][16] = o ? reinterpret_cast<const uint32_t *>(p - o)[16] : 0u;
-                    selv[s] = ((o) << 24) | ((o + 1) << 16) | ((o + 2) << 8) | (o + 3);
-                } else {
-                    sha256_tail_words(bb, len, off, blk + 1 == nblk, R[s]);
-                    selv[s] = 0x00010203u;
-                }
-                c = 1u | ((blk + 1 == nblk) ? 2u : 0u);
+                last = blk + 1 == nblk;
+                if (off + 64 <= len) p = bb + off;
+                else tail = true;
+                c = 1u | (last ? 2u : 0u);
                 dstv[s] = dst;
                 if constexpr (Source::kRing) pagesv[s] = pages;
                 blk += 2;
                 if (blk >= nblk) have = false;
+            }
+            sha256_request_block(p, R[s], selv[s]);
+            if (tail) {
+                sha256_tail_words(bb, len, off, last, R[s]);
+                selv[s] = 0x00010203u;
             }
             cflag[s] = c;
         };
@@ -2030,18 +2069,26 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
 
 #pragma unroll
         for (int s = 0; s < D; ++s) prep(s);
-        bool running = true;
+        bool drained = false;  // (one exit behind the last slot: k_sha256_pair)
         [[maybe_unused]] bool wg_busy = false;
         [[maybe_unused]] RingProbe probe;
         [[maybe_unused]] const bool probe_on = blockIdx.x == 0 && wave == 2;
-        while (running) {
+        while (!drained) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
-                if (running) {
+                {
                     const int pb = s & 1;
                     uint32_t W[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
+                    for (int j = 0; j < 16; ++j) {
+                        W[j] = __builtin_amdgcn_perm(R[s][j + 1], R[s][j], selv[s]);
+                        // pinned HERE (an empty volatile statement is neither sunk into the `any_cur` branch below nor
+                        // moved behind prep(s)): the slot's registers must be dead before its refill is requested, or
+                        // the refill lands in a second register set that is copied back at the loop's end behind an
+                        // s_waitcnt vmcnt(0) — every block would again be awaited in the step that requested it
+                        asm volatile("" : "+v"(W[j]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     const uint32_t c = cflag[s];
                     uint8_t *cur_dst = dstv[s];
                     if constexpr (Source::kRing) {
@@ -2098,7 +2145,7 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();
-                    if (!any_alive(pb)) running = false;
+                    drained = drained || __builtin_amdgcn_readfirstlane(any_alive(pb)) == 0u;
                     if constexpr (Source::kRing) wg_busy = (curw[0][pb] | curw[1][pb]) != 0u;
                 }
             }
@@ -2143,12 +2190,12 @@ __global__ __launch_bounds__(256) void k_sha256_xpair(Source src, const uint32_t
                 HR[3] += xp_sel(role, o60, o62);
                 if (x.c & 2u) {
                     // B holds digest words 0..3, A words 4..7: one 16-byte store each
-                    uint32_t *o = reinterpret_cast<uint32_t *>(x.d) + (roleB ? 0 : 4);
+                    PBSK_GLOBAL uint32_t *o = (PBSK_GLOBAL uint32_t *)x.d + (roleB ? 0 : 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = __builtin_bswap32(HR[j]);
                     if constexpr (Source::kRing) {  // record cell in mapped pinned memory: both halves first, then the flag
                         __threadfence_system();
-                        __hip_atomic_store(reinterpret_cast<uint32_t *>(x.d) + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store((PBSK_GLOBAL uint32_t *)x.d + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) HR[j] = ivr[j];
