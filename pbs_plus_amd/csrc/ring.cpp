@@ -156,7 +156,7 @@ void ring_reap_rounds(pbsgpu_ring *r) {
 int ring_launch_services(pbsgpu_ring *r) {
     HIPCHK(hipStreamWaitEvent(r->ss, r->ev_reset, 0));  // (never recorded before the first launch: no wait)
     HIPCHK(hipEventRecord(r->ev_svc0, r->ss));
-    HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss));
+    HIPCHK(pbsk::launch_ring_service(r->source(), r->sha_cus, r->ss, r->dense_service));
     if (r->xp_cus) {
         HIPCHK(hipStreamWaitEvent(r->xs, r->ev_reset, 0));
         HIPCHK(pbsk::launch_ring_service_xp(r->source(), r->xp_cus, r->xs));
@@ -464,7 +464,7 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     bool defer = r->defer_service;
     if (!defer && r->svc == SvcState::Stopped && r->lone_defer_ms > 0 && !any_final &&
         np >= std::max<uint32_t>(1, r->round_pages / 2)) {
-        const uint64_t lanes_worth = (uint64_t)r->sha_cus * 128u * (uint64_t)e->cfg.avg;
+        const uint64_t lanes_worth = (uint64_t)r->sha_cus * (r->dense_service ? 256u : 128u) * (uint64_t)e->cfg.avg;
         const double t = now_ms();
         if (r->defer_t0 == 0) r->defer_t0 = t;
         defer = t - r->defer_t0 < r->lone_defer_ms && r->deferred_bytes + new_bytes < lanes_worth;
@@ -576,6 +576,7 @@ void ring_env_overrides(pbsgpu_ring_options &o) {
         {"PBSGPU_RING_SPLIT_AUTO", FLAG_IF_ZERO, &o.flags, PBSGPU_RING_F_NO_SPLIT_AUTO},
         {"PBSGPU_RING_DEFER_SERVICE", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DEFER_SERVICE},
         {"PBSGPU_RING_FILL_SERIAL", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_FILL_SERIAL},
+        {"PBSGPU_RING_DENSE_SERVICE", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DENSE_SERVICE},
     };
     for (const Entry &e : table) {
         const char *v = getenv(e.name);
@@ -809,6 +810,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->autopark_ms = std::max(0.0, o.autopark_ms);
         r->defer_service = (o.flags & PBSGPU_RING_F_DEFER_SERVICE) != 0;
         r->fill_serial = (o.flags & PBSGPU_RING_F_FILL_SERIAL) != 0;
+        r->dense_service = (o.flags & PBSGPU_RING_F_DENSE_SERVICE) != 0;
         r->lone_defer_ms = o.lone_defer_ms < 0 ? 0.0 : o.lone_defer_ms > 0 ? o.lone_defer_ms : 25.0;
         r->idle_timeout_s = o.idle_timeout_s;
         r->opt_long_lo = o.long_lo_bytes;
@@ -1242,7 +1244,7 @@ int pbsgpu_ring_pump(pbsgpu_ring *r) {
         // the deferral has lasted long enough
         bool waiting = false;
         for (auto &s : r->slots) waiting |= s.open && !s.ready.empty();
-        const uint64_t lanes_worth = (uint64_t)r->sha_cus * 128u * (uint64_t)r->eng->cfg.avg;
+        const uint64_t lanes_worth = (uint64_t)r->sha_cus * (r->dense_service ? 256u : 128u) * (uint64_t)r->eng->cfg.avg;
         // (Round 5 tried a 1 ms grace before "nothing waiting" ends the deferral — a feeder that commits a round's worth, pumps
         // and polls in a loop has nothing waiting after every pump, so its cut-ahead ends with the first poll: the file's last
         // bytes are cut ~7 ms sooner, its first chunks start ~25 ms later; one file alone 487-500 vs 496-502 ms on the same box,

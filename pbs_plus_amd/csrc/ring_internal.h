@@ -126,6 +126,7 @@ struct pbsgpu_ring {
     uint32_t rounds_enq = 0;              // mirrored into the heartbeat block for the service's self-stop handshake
     double autopark_ms = 0;               // > 0: stop the service when the ring has been idle this long (engine ring of the stream writer)
     double idle_since_ms = 0;
+    bool dense_service = false;           // PBSGPU_RING_F_DENSE_SERVICE
     uint32_t park_gen_seen = 0;           // last graveyard park request this ring honoured (engine_internal.h: dev_free)
     uint32_t park_grace_gen = 0;          // the park request this ring has already waited its grace period for (ring_start_service)
     double park_wait_t0 = 0;              // since when a start has been waiting for the other rings of the device to let go (ring_start_service)

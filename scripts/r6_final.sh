@@ -30,7 +30,7 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python3 $ROOT/s
 $EXP counters $(db $OUT/pmc_fetch) $OUT/pmc_fetch_size_ring.csv
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python3 $ROOT/scripts/r4_ring_pmc.py 48 4 > $OUT/ring_pmc_write.json 2> $OUT/ring_pmc_write.err
 $EXP counters $(db $OUT/pmc_write) $OUT/pmc_write_size_ring.csv
-python3 $ROOT/scripts/r5_traffic.py $OUT/pmc_fetch_size_ring.csv $OUT/pmc_write_size_ring.csv $OUT/ring_pmc_fetch.json $OUT/traffic.json
+python3 $ROOT/scripts/r6_traffic.py $OUT/pmc_fetch_size_ring.csv $OUT/pmc_write_size_ring.csv $OUT/ring_pmc_fetch.json $OUT/traffic.json
 find $OUT -name "*.db" -delete; find $OUT -type d -empty -delete
 grep -i "sha256" $OUT/pmc_sq_ring.csv $OUT/pmc_fetch_size_ring.csv | sed 's/void pbsk:://' | cut -c1-230
 cat $OUT/ring_pmc_sq.json | cut -c1-400

@@ -68,6 +68,9 @@ SMALL = dict(page_bytes=65536, max_streams=8, sha_cus=4, round_pages=6)
      [(31, 0, (1 << 20) + 5), (32, 1, 300 * 1024), (33, 3, 700 * 1024 + 3), (34, 0, 64), (35, 0, 65), (36, 4, 131072)], 2),
     ("avg 64 KiB", 65536, dict(arena_bytes=96 * (262144 + 256), page_bytes=262144, max_streams=8, sha_cus=16, round_pages=16),
      [(41 + i, i % 5, (8 << 20) + 4099 * i) for i in range(6)], None),
+    # PBSGPU_RING_F_DENSE_SERVICE = 64: the pair service with eight waves per CU (measured and not the default: DESIGN.md 5.2)
+    ("dense service form", 4096, dict(arena_bytes=24 * (65536 + 256), flags=64, **SMALL),
+     [(51, 0, (1 << 20) + 5), (52, 1, 300 * 1024), (53, 3, 700 * 1024 + 3), (54, 0, 0), (55, 0, 63), (56, 2, 65536)], None),
 ])
 def test_ring_streams_match_the_oracle(gpu_lib, O, name, avg, opt, jobs, conc):
     from pbs_plus_amd import PageRing
