@@ -642,6 +642,23 @@ def _copy_args(a, **kw):
     return b
 
 
+def cu_time_budget(regime):
+    """Where the CU-seconds of one GiB go: the pair service's figure is THIS run's (regime probe), scan and refill are static
+    (profiles/r06_kernel_trace_bench_default.csv.gz: kernel time x the cut side's 64 CUs / bytes, one box)."""
+    svc = (regime or {}).get("pair_cu_ms_per_GiB")
+    scan, refill = 45, 16
+    out = {"service_cu_ms_per_GiB": svc, "service_source": "measured in this run (regime.pair_cu_ms_per_GiB)",
+           "scan_cu_ms_per_GiB": scan, "refill_cu_ms_per_GiB": refill,
+           "scan_refill_source": "static: profiles/r06_kernel_trace_bench_default.csv.gz (round 6, one box), NOT measured in this run"}
+    if svc:
+        tot = svc + scan + refill
+        out["chip_ceiling_GiBps"] = round(256 * 1e3 / tot)
+        out["note"] = ("%.0f CU-ms per GiB over the three kernels -> 256 CUs / that = the feed phase's ceiling however the CUs are "
+                       "split (refill: bench only); SHA-256 is 14 VALU instructions per round and lane in the consumer and as many "
+                       "issue slots in the producer, both SIMDs of a pair busy (profiles/r06_dense_service_and_cu_split.log)" % tot)
+    return out
+
+
 def regime_block(ring, p0, p_fed, p1, p2, pair_cus, xp_cus):
     """roofline.regime: ns per block step of the chains under load and the shader clock they ran at, per phase of the line."""
     try:
@@ -998,6 +1015,8 @@ def ring_run(a, rank, local_rank, world, ctx):
         svc_gbs = svc_bytes / max(svc_ms, 1e-9) / 1e6
         tr = load_traffic_ring()
         recs0 = kept[min(kept)]
+        # which regime did THIS run land in? (pbsgpu_ring_get_probe)
+        regime = regime_block(ring, probe0, probe_fed, probe1, probe2, int(st1["sha_cus"]), ring.express()[0])
         out = {
             "metric": "GiB/s ingested through CDC+SHA-256",
             "value": round(value, 2), "unit": "GiB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -1048,12 +1067,8 @@ def ring_run(a, rank, local_rank, world, ctx):
                          "note": "whole timed region incl. ramp-up from an idle ring and the drain of the last chunks"},
                 # which regime did THIS run land in? (pbsgpu_ring_get_probe: every service wave samples the shader clock and the
                 # wall clock once per 4096 block steps; only intervals in which the wave carried a block in every step count)
-                "regime": regime_block(ring, probe0, probe_fed, probe1, probe2, int(st1["sha_cus"]), ring.express()[0]),
-                "cu_time_budget": {"service_cu_ms_per_GiB": 233, "scan_cu_ms_per_GiB": 50, "refill_cu_ms_per_GiB": 28,
-                                   "chip_ceiling_GiBps": 823, "source": "static: profiles/r05_kernel_trace_bench_default*.csv.gz "
-                                   "(round 5, one box), NOT measured in this run — this run's service figure is regime.pair_cu_ms_per_GiB",
-                                   "note": "311 CU-ms per GiB over the three kernels -> 256 CUs / 311 = 823 GiB/s however the CUs "
-                                           "are split; the feed phase runs at ~0.93 of it (refill: bench only)"},
+                "regime": regime,
+                "cu_time_budget": cu_time_budget(regime),
                 "traffic": None if tr is None else int(tr["ratio"] * svc_bytes),
                 "traffic_note": None if tr is None else tr["note"],
                 "algorithmic_bytes_per_launch": int(svc_bytes),

@@ -91,3 +91,49 @@ def test_single_wave_sha_and_scan_register_budgets(usage):
         r = usage[k]
         assert r["vgprs"] <= 256 and r["occupancy"] >= 2, r   # two waves per SIMD: the scan's latency hiding
         assert r["lds"] <= LDS_PER_CU, r
+
+
+@pytest.fixture(scope="module")
+def sha_isa(tmp_path_factory):
+    """The device ISA of kernels.hip, one text per SHA-256 kernel (hipcc -S --offload-device-only; ~1 min)."""
+    d = tmp_path_factory.mktemp("isa")
+    src = os.path.join(ROOT, "pbs_plus_amd", "csrc", "kernels.hip")
+    out = os.path.join(str(d), "kernels.s")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                        "--offload-device-only", "-S", src, "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    kernels = {}
+    for m in re.finditer(r"^(_ZN4pbsk\w*k_sha256\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):
+        kernels[m.group(1)] = m.group(2)
+    assert len(kernels) >= 10, list(kernels)
+    return kernels
+
+
+def test_sha256_kernels_read_and_write_through_global_instructions_only(sha_isa):
+    """a flat_load counts in lgkmcnt, so the producer's wait in front of every s_barrier awaited the block requested in
+    the same step (rounds 3-5: no prefetch under load); and ONE flat_store anywhere in the kernel leaves a pending-flat state that
+    turns every VMEM wait of the producer's loop into vmcnt(0). No flat memory instruction may come back."""
+    bad = {k: re.findall(r"^\s*(flat_(?:load|store|atomic)\w*)", v, re.M)[:3] for k, v in sha_isa.items()}
+    bad = {k: v for k, v in bad.items() if v}
+    assert not bad, bad
+
+
+def test_sha256_producers_keep_the_other_slot_in_flight(sha_isa):
+    """Each block slot's sixteen v_perm are awaited with vmcnt(9)..vmcnt(5): the other slot's five requests stay outstanding. A
+    vmcnt(0) in front of them means the prefetch is gone again (a branch around the requests, an exit in the middle of the loop,
+    message words sunk behind the refill: kernels.hip, k_sha256_pair)."""
+    checked = 0
+    for k, v in sha_isa.items():
+        if "k_sha256_pair" not in k and "k_sha256_xpair" not in k:
+            continue
+        lines = v.splitlines()
+        first = [i for i, l in enumerate(lines) if re.match(r"\s*v_perm_b32 v\d+, v\d+, v\d+, v\d+\s*$", l)
+                 and not re.match(r"\s*v_perm_b32 v\d+, v\d+, v\d+, v\d+\s*$", lines[i - 1])]
+        waits = [lines[i - 1].strip() for i in first]
+        loop = [w for w in waits if w.startswith("s_waitcnt vmcnt(")]
+        depth = [int(re.search(r"vmcnt\((\d+)\)", w).group(1)) for w in loop]
+        assert len(depth) >= 2 and min(depth) >= 5, (k, waits)   # never fewer than the other slot's five requests outstanding
+        assert depth.count(5) >= 2, (k, waits)                   # both slots
+        checked += 1
+    assert checked >= 8, checked
