@@ -757,6 +757,7 @@ def extras(a, rank, local_rank, world, ctx, with_batch=False):
                           "write_phase_frac_of_measured_h2d": None if not o["roofline"]["measured_h2d_GBps"] else round(
                               o["write_phase"]["GiBps"] * GiB / 1e9 / o["roofline"]["measured_h2d_GBps"], 3),
                           "records_match_oracle": o["stream_records_match_oracle"],
+                          "in_subprocess": not os.environ.get("PBS_BENCH_HF_INPROC"),  # (since round 5: a fresh process per leg)
                           "leg_seconds": round(time.perf_counter() - t0, 1)}
         except BaseException as exc:  # noqa: BLE001
             res[label] = {"error": repr(exc)}
@@ -773,7 +774,11 @@ def _hostfeed_subprocess(b, local_rank):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PBS_BENCH_FORCE_DIST"):
         env.pop(k, None)
-    if "HIP_VISIBLE_DEVICES" not in env and local_rank:
+    # the child sees ONE device: the parent rank's (the local_rank-th entry of the parent's own mask, if it has one)
+    mask = [x for x in env.get("HIP_VISIBLE_DEVICES", "").split(",") if x.strip()]
+    if mask:
+        env["HIP_VISIBLE_DEVICES"] = mask[local_rank] if local_rank < len(mask) else mask[-1]
+    elif local_rank:
         env["HIP_VISIBLE_DEVICES"] = str(local_rank)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     if os.environ.get("PBS_BENCH_HF_TRACE"):

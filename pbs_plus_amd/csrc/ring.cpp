@@ -190,6 +190,7 @@ void ring_adapt_split(pbsgpu_ring *r) {
     r->xp_cus = (uint32_t)xp;
     r->sha_cus = r->svc_cus - r->xp_cus;
     r->st.sha_cus = r->sha_cus;
+    if (r->backlog_auto) r->backlog_limit = (uint64_t)r->sha_cus << 27;  // (the gate is sized by the pair service's CUs)
 }
 
 // (`force`: quiesce / destroy — the caller is about to wait for the queue to drain, a service must run now)
@@ -472,6 +473,9 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     if (!defer) {
         const int st = ring_start_service(r);
         if (st != PBSGPU_OK) return fail(st);
+        // the start may have moved the pair / express split (ring_adapt_split): this round publishes against the split it
+        // will be served by, not the one before it (xp_pairs, long_spill, long_lo: heuristics only, records do not depend on them)
+        rr.q = r->source();
     }
     if (r->svc == SvcState::Stopped) r->deferred_bytes += new_bytes;  // cut ahead of the service (or the start waits for a graveyard flush)
     if (r->svc == SvcState::Stopped) rr.scan_blocks = (uint32_t)std::max(1, e->num_cus);  // nobody else on the chip: full width
@@ -806,6 +810,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
                                                : std::max(1u, r->round_pages / 4);
         // ~30 ms of the service's throughput (4.3 GiB/s per CU measured) is plenty to ride out the gaps between rounds
         r->backlog_limit = o.backlog_mib < 0 ? 0 : o.backlog_mib > 0 ? (uint64_t)(o.backlog_mib * 1048576.0) : (uint64_t)r->sha_cus << 27;
+        r->backlog_auto = o.backlog_mib == 0;
         if (o.max_inflight) r->max_inflight = std::min<uint32_t>(std::max(1u, o.max_inflight), kRingInputs);
         r->autopark_ms = std::max(0.0, o.autopark_ms);
         r->defer_service = (o.flags & PBSGPU_RING_F_DEFER_SERVICE) != 0;
