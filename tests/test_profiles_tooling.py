@@ -46,5 +46,5 @@ def test_bench_quotes_the_newest_measured_traffic():
 
     bench = importlib.import_module("bench")
     t = bench.load_traffic_ring()
-    want = json.load(open(os.path.join(PROF, "r05_traffic.json")))["ring"]["hbm_bytes_per_algorithmic_byte"]
-    assert t and abs(t["ratio"] - want) < 1e-9 and "round 5" in t["note"]
+    want = json.load(open(os.path.join(PROF, "r06_traffic.json")))["ring"]["hbm_bytes_per_algorithmic_byte"]
+    assert t and abs(t["ratio"] - want) < 1e-9 and "round 6" in t["note"]
