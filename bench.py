@@ -906,6 +906,8 @@ def ring_run(a, rank, local_rank, world, ctx):
         """nfiles whole files through the ring, S at a time; returns {file index: records} of the kept ones"""
         out, active, opened, done = {}, {}, 0, 0
         marks.clear()
+        loopstat = [0, 0, 0]   # feeder loop: iterations, fill calls, fill calls that got no page (arena empty or backlog gate)
+        marks["loopstat"] = loopstat
         base = state["next_file"]
         enq0 = ring.stats()["bytes_enqueued"]
         t_last = time.perf_counter()
@@ -921,14 +923,19 @@ def ring_run(a, rank, local_rank, world, ctx):
             # (a file that is ALONE gets a whole round's worth per turn: with 16 pages per turn one 64 GiB file went through
             # 253 small rounds and ~100 ms of per-round latency — and never qualified for the ring's lone-stream cut-ahead)
             q_turn = quota if (state["S"] > 1 or len(active) > 1) else 256 * int(ring.page_bytes)
+            loopstat[0] += 1
             for sid, st in active.items():
                 if st[1]:
                     want = min(st[1], q_turn)
-                    st[1] -= ring.fill(sid, seed_of(st[0]), kind, want, final=(want == st[1]))
+                    got = ring.fill(sid, seed_of(st[0]), kind, want, final=(want == st[1]))
+                    st[1] -= got
+                    loopstat[1] += 1
+                    loopstat[2] += 1 if got == 0 else 0
             ring.pump()
             if (opened == nfiles and "t_fed" not in marks and not any(st[1] for st in active.values())
                     and ring.stats()["bytes_enqueued"] >= enq0 + nfiles * file_bytes):
                 marks["t_fed"] = time.perf_counter()     # every byte of the last file is in a cut round
+                marks["loopstat_fed"] = list(loopstat)
                 marks["probe_fed"] = ring.probe()
                 if os.environ.get("PBS_BENCH_RING_TRACE"):   # queue state at the end of the feed phase (diagnostic)
                     marks["fed_state"] = (ring.debug().splitlines()[0], ring.stats())
@@ -979,6 +986,10 @@ def ring_run(a, rank, local_rank, world, ctx):
     kept = run_files(a.steps, True)
     t_fed = marks.get("t_fed", None)
     probe_fed = marks.get("probe_fed", None)
+    if os.environ.get("PBS_BENCH_RING_DEBUG") and rank == 0 and t_fed and "loopstat_fed" in marks:
+        it, nf, nz = marks["loopstat_fed"]
+        print("[feeder] feed phase %.3f s: %d loop iterations (%.0f us each), %d fill calls, %d of them got no page (%.1f %%)"
+              % (t_fed - t0, it, (t_fed - t0) * 1e6 / max(it, 1), nf, nz, 100.0 * nz / max(nf, 1)), file=sys.stderr, flush=True)
     if "fed_state" in marks and rank == 0:
         print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
               "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)
@@ -1010,6 +1021,8 @@ def ring_run(a, rank, local_rank, world, ctx):
     ring.quiesce()
     single_s = time.perf_counter() - ts0
     probe2 = ring.probe()
+    if os.environ.get("PBS_BENCH_RING_DEBUG"):
+        sys.stderr.write("[ring debug] " + ring.debug().splitlines()[1] + "\n")
     state["S"] = s_saved
     out = None
     if rank == 0:

@@ -53,6 +53,8 @@ type (
 		ExpressCUs                                                                       uint32
 		MinRoundPages, MaxInflight, LongBytes, LongLoBytes, LongSpill, PollEvery, Flags uint32
 		BacklogMiB, LoneDeferMs, IdleTimeoutS, AutoparkMs                                float64
+		LanesCUs                                                                         uint32
+		ShortBytes                                                                       uint64
 	}
 	EngineOptions struct {
 		Inflight, ShaForm, ShaSlackPct, ShaDensePct                      uint32

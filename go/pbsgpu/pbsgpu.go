@@ -678,6 +678,10 @@ type RingOptions struct {
 	// ABI v5: what used to be PBSGPU_RING_* environment variables (pbsgpu.h); zero = default, RingOff = "none"
 	MinRoundPages, MaxInflight, LongBytes, LongLoBytes, LongSpill, PollEvery, Flags uint32
 	BacklogMiB, LoneDeferMs, IdleTimeoutS, AutoparkMs                                float64
+	// LanesCUs of the pair service's share run the LANES service (one lane per chunk) for chunks of at most ShortBytes
+	// (0 = 3/2 of the average chunk size). Off by default: measured neutral on bulk rings (DESIGN.md 5.5).
+	LanesCUs   uint32
+	ShortBytes uint64
 }
 
 // RingOff expresses "none" for RingOptions fields whose zero value means "default" (PBSGPU_RING_OFF).
@@ -691,7 +695,7 @@ func (e *Engine) NewRing(o RingOptions) (*Ring, error) {
 		max_inflight: C.uint32_t(o.MaxInflight), long_bytes: C.uint32_t(o.LongBytes), long_lo_bytes: C.uint32_t(o.LongLoBytes),
 		long_spill: C.uint32_t(o.LongSpill), poll_every: C.uint32_t(o.PollEvery), flags: C.uint32_t(o.Flags),
 		backlog_mib: C.double(o.BacklogMiB), lone_defer_ms: C.double(o.LoneDeferMs), idle_timeout_s: C.double(o.IdleTimeoutS),
-		autopark_ms: C.double(o.AutoparkMs)}
+		autopark_ms: C.double(o.AutoparkMs), lanes_cus: C.uint32_t(o.LanesCUs), short_bytes: C.uint64_t(o.ShortBytes)}
 	r := &Ring{eng: e}
 	if err := check(C.pbsgpu_ring_create(e.h, &co, &r.h), "ring_create"); err != nil {
 		return nil, err

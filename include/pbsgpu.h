@@ -353,13 +353,16 @@ typedef struct pbsgpu_ring_options {
     uint32_t long_spill;       /* long chunks waiting beyond which the pair lanes help (0 = default rule) */
     uint32_t poll_every;       /* block steps between two looks at the queue of a service wave that carries work (0 = 8..64 by chunker) */
     uint32_t flags;            /* PBSGPU_RING_F_* */
-    uint32_t reserved0;
+    uint32_t lanes_cus;        /* CUs of the LANES service (one lane per chunk, four independent waves per CU: ~1.1x the bytes per
+                                * CU-second of the pair service, every chain ~1.8x slower) for chunks of at most short_bytes, taken
+                                * out of sha_cus' share; 0 = none (`reserved0` before). PBSGPU_RING_LANES_CUS overrides. */
     double backlog_mib;        /* bytes waiting in front of the service beyond which no page is handed out (0 = 128 MiB per
                                 * service CU; < 0 = no limit) */
     double lone_defer_ms;      /* how long the first rounds of bulk streams on an idle ring are cut ahead of the service (0 = 25; < 0 = never) */
     double idle_timeout_s;     /* the service stops on its own after this long without work or a call (0 = 20 s) */
     double autopark_ms;        /* > 0: the ring parks its service when nothing has been anywhere in it for this long */
-    uint64_t reserved[4];
+    uint64_t short_bytes;      /* largest chunk the lanes service takes (0 = 3/2 of the average chunk size; first word of `reserved` before) */
+    uint64_t reserved[3];
 } pbsgpu_ring_options;
 #define PBSGPU_RING_OFF 0xffffffffu
 #define PBSGPU_RING_F_NO_OVERLAP 1u      /* scan of round n + 1 NOT beside the control kernel of round n (one scan set) */

@@ -94,8 +94,8 @@ class RingOptions(C.Structure):
                 ("sha_cus", C.c_uint32), ("round_pages", C.c_uint32), ("express_cus", C.c_uint32),
                 ("min_round_pages", C.c_uint32), ("max_inflight", C.c_uint32), ("long_bytes", C.c_uint32),
                 ("long_lo_bytes", C.c_uint32), ("long_spill", C.c_uint32), ("poll_every", C.c_uint32), ("flags", C.c_uint32),
-                ("reserved0", C.c_uint32), ("backlog_mib", C.c_double), ("lone_defer_ms", C.c_double),
-                ("idle_timeout_s", C.c_double), ("autopark_ms", C.c_double), ("reserved", C.c_uint64 * 4)]
+                ("lanes_cus", C.c_uint32), ("backlog_mib", C.c_double), ("lone_defer_ms", C.c_double),
+                ("idle_timeout_s", C.c_double), ("autopark_ms", C.c_double), ("short_bytes", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 class EngineOptions(C.Structure):

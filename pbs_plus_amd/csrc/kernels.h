@@ -210,8 +210,17 @@ struct alignas(64) RingCtl {   // device memory, one 64-byte line
                            // enqueued rounds before it stops on its own
     uint32_t xp_busy;      // express service: lane pairs that hold a chunk right now (the pair service's lanes take a long
                            // chunk only while every express pair is busy: waiting for one would cost more than it saves)
-    uint32_t pad[7];
+    uint32_t pad0;
+    union {
+        struct {
+            uint32_t stail;    // SHORT-chunk queue (the lanes service, RingSource::sdesc): positions < stail are published
+            uint32_t shead;    // ... positions < shead have been taken (CAS, like lhead)
+        };
+        unsigned long long sq;
+    };
+    uint32_t pad[4];
 };
+static_assert(sizeof(RingCtl) == 64, "RingCtl is one 64-byte line");
 struct RingSource {
     static constexpr bool kRing = true;
     const uint4 *desc;         // ring of positions, 2 x uint4 each: {p1.lo, p1.hi, len, len1} {p2v.lo, p2v.hi, cell, pages}
@@ -230,6 +239,15 @@ struct RingSource {
     const uint4 *ldesc;
     uint32_t lmask;
     uint32_t long_bytes;       // 0 = no second queue
+    // Chunks of at most `short_bytes` may go through a THIRD queue, served by the LANES service (k_sha256_lanes: one lane per
+    // chunk, schedule and rounds in one wave, four independent waves per CU: 81 chain-blocks per us and CU against the pair
+    // form's 74, every chain at 3.2 instead of 1.73 us per block — profiles/r06_sha_forms_full_lanes.log). The control kernel
+    // sends a short chunk there only while fewer than `short_room` entries wait (the lanes are kept busy, nothing queues up
+    // behind them); everything else stays with the pair service. CAS queue like the long one: lanes never wait at a position.
+    const uint4 *sdesc;
+    uint32_t smask;
+    uint32_t short_bytes;      // 0 = no lanes service
+    uint32_t short_room;
     RingCtl *ctl;
     uint8_t *cells;            // mapped pinned: 64-byte record cells {end, digest[32], segment, size, flag, pad}
     uint32_t *pending;         // per physical page: chunks not yet loaded + holds of open chunks
@@ -262,7 +280,7 @@ constexpr uint32_t kRingProbeSteps = 4096;  // block steps between two samples o
 
 
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)
-enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsTileq = 6 /* u64 */, kRsCount = 10 };
+enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsNshort = 4, kRsShortRoom = 5, kRsTileq = 6 /* u64 */, kRsCount = 10 };
 
 // One physical page of a round (host-written into mapped pinned memory; the round's kernels read the device copy k_ring_stage makes).
 struct RingPage {
@@ -339,6 +357,7 @@ struct RingRound {
     RingSource q;
     uint4 *desc_w;             // writable view of q.desc
     uint4 *ldesc_w;            // ... and of q.ldesc
+    uint4 *sdesc_w;            // ... and of q.sdesc (nullptr: no lanes service)
     // work buffers. The SCAN side (tile_cnt, tile_slots, tile_queue) exists twice: round n + 1 is scanned on its own HIP
     // stream while round n's control kernel still reads round n's candidates; everything behind the scan runs in order on
     // the control stream and has one set.
@@ -384,6 +403,7 @@ hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st, hi
 // the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
 hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st, bool dense = false);
 hipError_t launch_ring_service_xp(const RingSource &q, unsigned workgroups, hipStream_t st);
+hipError_t launch_ring_service_lanes(const RingSource &q, unsigned workgroups, hipStream_t st);
 // raise `stop` behind everything enqueued so far on `st`
 hipError_t launch_ring_stop(RingCtl *ctl, hipStream_t st);
 hipError_t launch_ring_reset(RingCtl *ctl, hipStream_t st);

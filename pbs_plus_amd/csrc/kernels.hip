@@ -1323,6 +1323,145 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
 }
 
 // -------------------------------------------------------------------------------------
+// SHA-256, LANES service of the page ring (RingSource::sdesc): the single-wave form above on the ring's protocol. One lane per
+// chunk, schedule and rounds in the same wave, no LDS hand-over and no barrier: four independent waves per CU (the launch takes
+// the CU's whole LDS like the other services). 81 chain-blocks per us and CU against the pair form's 74 — and 3.2 us per block for
+// every chain, which is why only SHORT chunks come here and only while this service has room (k_ring_control). The queue is a
+// compare-and-swap queue like the long one: a lane never claims a position it then has to wait at.
+__global__ __launch_bounds__(256) void k_sha256_lanes(RingSource src) {
+    const int lane = threadIdx.x & 63;
+    const uint8_t *base = nullptr, *base2 = nullptr;
+    uint64_t len = 0, blk = 0, nblk = 0;
+    uint32_t len1 = 0, pages = 0xffffffffu, poll_ctr = 0;
+    uint8_t *dst = nullptr;
+    bool have = false, exhausted = false;
+    uint32_t R[17];
+    uint32_t sel = 0x00010203u;
+#pragma unroll
+    for (int j = 0; j < 17; ++j) R[j] = 0;
+    uint32_t H[8];
+    sha256_iv(H);
+
+    auto load_block = [&]() {  // request block `blk` of the lane's chunk (k_sha256_pair's prep)
+        const uint64_t off = blk * 64;
+        const uint8_t *bb = (off < len1) ? base : base2;  // which physical page holds this block
+        if (off + 64 <= len) {
+            sha256_request_block(bb + off, R, sel);
+        } else {
+            sha256_tail_words(bb, len, off, blk + 1 == nblk, R);
+            sel = 0x00010203u;
+        }
+    };
+    auto acquire = [&](bool need) {
+        if (__ballot(need) == 0) return;
+        if (__ballot(have) != 0 && ((++poll_ctr) & src.poll_mask) != 0u) return;
+        const unsigned long long sq = __hip_atomic_load(&src.ctl->sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = (uint32_t)sq, sh = (uint32_t)(sq >> 32);
+        const int32_t avail = (int32_t)(st - sh);
+        const unsigned long long mn = __ballot(need);
+        if (avail > 0) {
+            const uint32_t cnt = min((uint32_t)__popcll(mn), (uint32_t)avail);
+            const int leader = __ffsll((long long)mn) - 1;
+            uint32_t got0 = 0xffffffffu;
+            if (lane == leader && atomicCAS(&src.ctl->shead, sh, sh + cnt) == sh) got0 = sh;
+            got0 = __shfl(got0, leader, 64);
+            if (got0 != 0xffffffffu) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                const uint32_t rank = (uint32_t)__popcll(mn & ((1ull << lane) - 1ull));
+                const bool got = need && rank < cnt;
+                uint4 e0 = make_uint4(0, 0, 0, 0), e1 = make_uint4(0, 0, 0, 0);
+                if (got) {
+                    e0 = src.sdesc[2u * ((got0 + rank) & src.smask)];
+                    e1 = src.sdesc[2u * ((got0 + rank) & src.smask) + 1u];
+                }
+                base = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e0.y << 32) | e0.x) : base;
+                base2 = got ? reinterpret_cast<const uint8_t *>(((uint64_t)e1.y << 32) | e1.x) : base2;
+                len = got ? (uint64_t)e0.z : len;
+                len1 = got ? e0.w : len1;
+                dst = got ? src.cells + (uint64_t)e1.z * 64u + 8u : dst;
+                pages = got ? e1.w : pages;
+                blk = got ? 0ull : blk;
+                nblk = got ? ((uint64_t)e0.z + 8u) / 64u + 1u : nblk;
+                have = have | got;
+            }
+        } else {
+            // nothing published: has the service been told to stop? (stop is raised behind the last publish; the queue is looked
+            // at again behind the fence, so no lane leaves while short chunks are unclaimed)
+            const unsigned long long ts = __hip_atomic_load(&src.ctl->tail_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(ts >> 32) != 0u) {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                const unsigned long long sq2 = __hip_atomic_load(&src.ctl->sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int32_t)((uint32_t)sq2 - (uint32_t)(sq2 >> 32)) <= 0) exhausted = exhausted | need;
+            }
+        }
+    };
+
+    // regime probe of this service (pbsgpu_ring_debug): workgroup 0's first wave, steps and 100 MHz ticks of the intervals in which
+    // it carried a block in every step -> probe[6], probe[7]
+    const bool probe_on = src.probe != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
+    uint32_t pn = 0, pidle = 0;
+    unsigned long long pw0 = 0;
+    acquire(true);
+    if (have) load_block();
+    for (;;) {
+        if (probe_on) {
+            pidle |= __any(have) ? 0u : 1u;
+            if (++pn >= kRingProbeSteps) {
+                const unsigned long long w = wall_clock64();
+                if (!pidle && pw0 != 0ull && lane == 0) {
+                    atomicAdd(src.probe + 6, (unsigned long long)kRingProbeSteps);
+                    atomicAdd(src.probe + 7, w - pw0);
+                }
+                pn = 0; pidle = 0; pw0 = w;
+            }
+        }
+        if (!__any(have)) {  // the wave holds nothing: leave once every lane has seen `stop` with the queue empty, else nap and look again
+            if (__ballot(!exhausted) == 0ull) break;
+            __builtin_amdgcn_s_sleep(48);
+            poll_ctr = 0;
+            acquire(!exhausted);
+            if (have) load_block();
+            continue;
+        }
+        uint32_t W[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) W[j] = __builtin_amdgcn_perm(R[j + 1], R[j], sel);
+        const bool cur = have;
+        const bool cur_last = have && (blk + 1 == nblk);
+        uint8_t *cur_dst = dst;
+        if (have) {
+            if (!cur_last) ++blk; else have = false;
+        }
+        if (cur_last) {  // the chunk's last block is in registers: drop its page references (k_sha256_pair)
+            const uint32_t pg = pages;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t pi = h ? (pg >> 16) : (pg & 0xffffu);
+                if (pi != 0xffffu) {
+                    const uint32_t old = __hip_atomic_fetch_sub(&src.pending[pi], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old == 1u) {
+                        const uint32_t fs = atomicAdd(&src.ctl->free_count, 1u);
+                        __hip_atomic_store(&src.free_fifo[fs & src.free_mask], ((unsigned long long)(fs + 1u) << 32) | pi,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
+        acquire(!have && !exhausted);
+        if (have) load_block();
+        if (cur) sha256_compress(H, W);
+        if (cur_last) {  // record cell in mapped pinned memory: digest first, then its flag
+            PBSK_GLOBAL uint32_t *o = (PBSK_GLOBAL uint32_t *)cur_dst;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_bswap32(H[j]);
+            __threadfence_system();
+            __hip_atomic_store(o + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sha256_iv(H);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // SHA-256, wave-pair form. The ingest workload is parallelism-starved on this chip: at a
 // 4 MiB average chunk even a full 288 GB of HBM holds ~70 k chunks, while 256 CUs x 4 SIMDs
 // x 2 waves offer 131 k lanes, and a lone wave only issues one instruction every ~4 cycles.

@@ -163,6 +163,12 @@ int ring_launch_services(pbsgpu_ring *r) {
         HIPCHK(hipEventRecord(r->ev_xsvc1, r->xs));
         HIPCHK(hipStreamWaitEvent(r->ss, r->ev_xsvc1, 0));
     }
+    if (r->lanes_cus) {
+        HIPCHK(hipStreamWaitEvent(r->ls, r->ev_reset, 0));
+        HIPCHK(pbsk::launch_ring_service_lanes(r->source(), r->lanes_cus, r->ls));
+        HIPCHK(hipEventRecord(r->ev_lsvc1, r->ls));
+        HIPCHK(hipStreamWaitEvent(r->ss, r->ev_lsvc1, 0));
+    }
     HIPCHK(hipEventRecord(r->ev_svc1, r->ss));
     return PBSGPU_OK;
 }
@@ -188,9 +194,9 @@ void ring_adapt_split(pbsgpu_ring *r) {
     r->obs_long_bytes *= 0.5;
     if (std::abs(xp - (int)r->xp_cus) < 16) return;  // hysteresis
     r->xp_cus = (uint32_t)xp;
-    r->sha_cus = r->svc_cus - r->xp_cus;
+    r->sha_cus = r->svc_cus - r->xp_cus - r->lanes_cus;
     r->st.sha_cus = r->sha_cus;
-    if (r->backlog_auto) r->backlog_limit = (uint64_t)r->sha_cus << 27;  // (the gate is sized by the pair service's CUs)
+    if (r->backlog_auto) r->backlog_limit = (uint64_t)(r->sha_cus + r->lanes_cus) << 27;  // (the gate is sized by the CUs that serve the main and the short queue)
 }
 
 // (`force`: quiesce / destroy — the caller is about to wait for the queue to drain, a service must run now)
@@ -422,12 +428,13 @@ int ring_enqueue_round(pbsgpu_ring *r, bool *did) {
     rr.cell_base = (uint32_t)(ri.cell_base & (r->ncells - 1));
     rr.cell_cap = ri.cell_cap;
     rr.cell_mask = r->ncells - 1;
-    rr.scan_blocks = (uint32_t)std::max(1, e->num_cus - (int)r->sha_cus - (int)r->xp_cus);
+    rr.scan_blocks = (uint32_t)std::max(1, e->num_cus - (int)r->svc_cus);
     rr.status = hs;
     rr.streams = r->streams.as<pbsk::RingStreamState>();
     rr.q = r->source();
     rr.desc_w = r->desc.as<uint4>();
     rr.ldesc_w = r->ldesc.as<uint4>();
+    rr.sdesc_w = r->lanes_cus ? r->sdesc.as<uint4>() : nullptr;
     const uint32_t set = r->ps ? r->scan_set : 0u;
     rr.scalars = r->scalars.as<uint32_t>();
     rr.tile_queue = r->tileq.as<unsigned long long>() + set * 8u;
@@ -553,7 +560,7 @@ int ring_take_page(pbsgpu_ring *r, uint32_t *phys) {
 // host passes in the options is what counts (two engines of one process may want different rings); these exist so that an
 // unmodified binary can be A/B-tested (scripts/, the parity tests that force a code path).
 void ring_env_overrides(pbsgpu_ring_options &o) {
-    enum Kind { U32, U32_ZERO_OFF, F64, F64_ZERO_NEG, FLAG_IF_ZERO, FLAG_IF_SET };
+    enum Kind { U32, U32_ZERO_OFF, U64, F64, F64_ZERO_NEG, FLAG_IF_ZERO, FLAG_IF_SET };
     struct Entry {
         const char *name;
         Kind kind;
@@ -563,6 +570,8 @@ void ring_env_overrides(pbsgpu_ring_options &o) {
     const Entry table[] = {
         {"PBSGPU_RING_SHA_CUS", U32, &o.sha_cus, 0},
         {"PBSGPU_RING_XP_CUS", U32_ZERO_OFF, &o.express_cus, 0},
+        {"PBSGPU_RING_LANES_CUS", U32, &o.lanes_cus, 0},
+        {"PBSGPU_RING_SHORT_BYTES", U64, &o.short_bytes, 0},
         {"PBSGPU_RING_ROUND_PAGES", U32, &o.round_pages, 0},
         {"PBSGPU_RING_MIN_ROUND_PAGES", U32, &o.min_round_pages, 0},
         {"PBSGPU_RING_MAX_INFLIGHT", U32, &o.max_inflight, 0},
@@ -588,6 +597,7 @@ void ring_env_overrides(pbsgpu_ring_options &o) {
         switch (e.kind) {
         case U32: *static_cast<uint32_t *>(e.field) = (uint32_t)std::max(0L, atol(v)); break;
         case U32_ZERO_OFF: *static_cast<uint32_t *>(e.field) = atol(v) <= 0 ? PBSGPU_RING_OFF : (uint32_t)atol(v); break;
+        case U64: *static_cast<uint64_t *>(e.field) = strtoull(v, nullptr, 10); break;
         case F64: *static_cast<double *>(e.field) = std::max(0.0, atof(v)); break;
         case F64_ZERO_NEG: *static_cast<double *>(e.field) = atof(v) <= 0.0 ? -1.0 : atof(v); break;
         case FLAG_IF_ZERO: if (atoi(v) == 0) *static_cast<uint32_t *>(e.field) |= e.flag; break;
@@ -606,6 +616,12 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.ldesc = ldesc.as<uint4>();
     q.lmask = lslots - 1;
     q.long_bytes = long_bytes;
+    q.sdesc = sdesc.as<uint4>();
+    q.smask = sslots ? sslots - 1 : 0;
+    q.short_bytes = lanes_cus ? short_bytes : 0u;
+    // entries that may wait for the lanes service: its lanes take ~2 chunks per CU and round (256 lanes x 1.2 ms / ~0.15 s per
+    // chunk); 32 per CU rides out a dozen rounds and fills an idle service within ten
+    q.short_room = lanes_cus * 32u;
     q.xp = xp_cus ? 1u : 0u;
     // the pair lanes take a long chunk only while EVERY express pair is busy (RingCtl::xp_busy): random data keeps the express
     // service just busy (2.6 long chunks per ms against the 2.8 it can take), a corpus whose files are mostly zero runs or
@@ -802,14 +818,18 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (sha + xp > svc_max) sha = std::max(1, svc_max - xp);
         r->xp_cus = (uint32_t)xp;
         r->sha_cus = (uint32_t)std::min(std::max(sha, 1), std::max(1, e->num_cus - 1 - xp));
-        r->svc_cus = r->sha_cus + r->xp_cus;
+        // LANES service: out of the pair service's share (at most 3/4 of it)
+        r->lanes_cus = std::min<uint32_t>(o.lanes_cus, r->sha_cus * 3u / 4u);
+        r->sha_cus -= r->lanes_cus;
+        r->short_bytes = o.short_bytes ? (uint32_t)std::min<uint64_t>(o.short_bytes, e->cfg.max) : (uint32_t)((uint64_t)e->cfg.avg * 3 / 2);
+        r->svc_cus = r->sha_cus + r->xp_cus + r->lanes_cus;
         r->split_auto = xp > 0 && !o.sha_cus && !o.express_cus && r->svc_cus >= 96 && !(o.flags & PBSGPU_RING_F_NO_SPLIT_AUTO);
         r->round_pages = o.round_pages ? o.round_pages : 256;
         r->round_pages = std::min(r->round_pages, r->npages);
         r->min_round_pages = o.min_round_pages ? std::max(1u, std::min(o.min_round_pages, std::max(1u, r->round_pages / 4)))
                                                : std::max(1u, r->round_pages / 4);
         // ~30 ms of the service's throughput (4.3 GiB/s per CU measured) is plenty to ride out the gaps between rounds
-        r->backlog_limit = o.backlog_mib < 0 ? 0 : o.backlog_mib > 0 ? (uint64_t)(o.backlog_mib * 1048576.0) : (uint64_t)r->sha_cus << 27;
+        r->backlog_limit = o.backlog_mib < 0 ? 0 : o.backlog_mib > 0 ? (uint64_t)(o.backlog_mib * 1048576.0)   : (uint64_t)(r->sha_cus + r->lanes_cus) << 27;
         r->backlog_auto = o.backlog_mib == 0;
         if (o.max_inflight) r->max_inflight = std::min<uint32_t>(std::max(1u, o.max_inflight), kRingInputs);
         r->autopark_ms = std::max(0.0, o.autopark_ms);
@@ -858,6 +878,8 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (r->xp_cus && r->long_bytes == 0) r->xp_cus = 0;  // (no long queue: nothing the express service could take)
         r->lslots = pow2_at_least(2 * ((uint64_t)r->npages * r->page_bytes / std::max<uint32_t>(r->long_bytes, minsz) + r->rec_cap) + 1024);
         CHK(r->ldesc.ensure((size_t)r->lslots * 32));
+        r->sslots = r->lanes_cus ? r->qslots : 2;
+        CHK(r->sdesc.ensure((size_t)r->sslots * 32));
         CHK(r->scalars.ensure(pbsk::kRsCount * 4 + 64));
         CHK(r->tile_cnt.ensure((size_t)ntiles * 4 + 16));
         CHK(r->tile_off.ensure((size_t)ntiles * 4 + 16));
@@ -934,6 +956,10 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         if (r->xp_cus) {
             HIPCHK(hipStreamCreateWithPriority(&r->xs, hipStreamNonBlocking, hi));
             HIPCHK(hipEventCreateWithFlags(&r->ev_xsvc1, hipEventDisableTiming));
+        }
+        if (r->lanes_cus) {
+            HIPCHK(hipStreamCreateWithPriority(&r->ls, hipStreamNonBlocking, hi));
+            HIPCHK(hipEventCreateWithFlags(&r->ev_lsvc1, hipEventDisableTiming));
         }
         HIPCHK(hipEventCreateWithFlags(&r->ev_reset, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&r->ev_svc0));
@@ -1034,6 +1060,8 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
         if (r->ss) (void)hipStreamDestroy(r->ss);
         if (r->xs) (void)hipStreamDestroy(r->xs);
         if (r->ev_xsvc1) (void)hipEventDestroy(r->ev_xsvc1);
+        if (r->ls) (void)hipStreamDestroy(r->ls);
+        if (r->ev_lsvc1) (void)hipEventDestroy(r->ev_lsvc1);
         if (r->cs) (void)hipStreamDestroy(r->cs);
         if (r->ps) (void)hipStreamDestroy(r->ps);
         if (r->fs) (void)hipStreamDestroy(r->fs);
@@ -1049,7 +1077,7 @@ void pbsgpu_ring_destroy(pbsgpu_ring *r) {
             for (auto &q : s.ready)
                 if (q.dep) r->ev_pool.push_back(q.dep);
         for (auto ev : r->ev_pool) (void)hipEventDestroy(ev);
-        for (DevBuf *b : {&r->arena, &r->ctl, &r->probe, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->scalars, &r->tile_cnt, &r->tile_off,
+        for (DevBuf *b : {&r->arena, &r->ctl, &r->probe, &r->streams, &r->pending, &r->desc, &r->ldesc, &r->sdesc, &r->scalars, &r->tile_cnt, &r->tile_off,
                           &r->tile_slots, &r->tile_cnt2, &r->tile_slots2, &r->tileq, &r->scan_tmp, &r->dense, &r->segs, &r->seg_cnt, &r->seg_off, &r->recs, &r->seg_newc,
                           &r->seg_open, &r->seg_ecand_in, &r->seg_ecand, &r->inputs_dev})
             b->release();
@@ -1327,6 +1355,12 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
         ctl.tail, ctl.stop, ctl.head, ctl.ltail, ctl.lhead, ctl.free_count, ctl.error, ctl.rounds_done, r->free_read,
         r->free_pages.size(), r->rounds.size(), r->next_seq, r->rounds_enq, (int)r->svc, r->tail_seen, hb[pbsk::kHbClaim],
         (unsigned long long)r->backlog_limit, hb[pbsk::kHbIntent], hb[pbsk::kHbCommitted]);
+    {
+        unsigned long long pr[8] = {};
+        HIPCHK(hipMemcpy(pr, r->probe.p, sizeof(pr), hipMemcpyDeviceToHost));
+        put("lanes service: cus=%u short_bytes=%u stail=%u shead=%u steps_sampled=%llu ns_per_block_step=%.1f | pair cus=%u express cus=%u\n",
+            r->lanes_cus, r->short_bytes, ctl.stail, ctl.shead, pr[6], pr[6] ? (double)pr[7] * 10.0 / (double)pr[6] : 0.0, r->sha_cus, r->xp_cus);
+    }
     uint32_t nz = 0;
     for (uint32_t p = 0; p < r->npages && nz < 64; ++p)
         if (pend[p]) {

@@ -88,8 +88,9 @@ struct pbsgpu_ring {
     uint64_t rec_cap = 0, dense_cap = 0;
     uint32_t qslots = 0, ncells = 0, nfree = 0;
     // device
-    pbse::DevBuf arena, ctl, streams, pending, desc, ldesc, probe;
+    pbse::DevBuf arena, ctl, streams, pending, desc, ldesc, sdesc, probe;
     uint32_t lslots = 0, long_bytes = 0;
+    uint32_t sslots = 0, short_bytes = 0, lanes_cus = 0;  // the LANES service and its short-chunk queue (kernels.h: RingSource::sdesc)
     pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
     pbse::DevBuf tile_cnt2, tile_slots2, tileq;  // second set of the scan side (rounds alternate) + the two tile-queue counters
     pbse::DevBuf seg_ecand_in, seg_ecand;
@@ -103,6 +104,7 @@ struct pbsgpu_ring {
     pbse::PinnedBuf sugg_in[pbse::kRingInputs];  // suggested offsets of the round built in input i (grown on demand)
     size_t input_stride = 0, in_pages_off = 0, in_segs_off = 0, in_recbase_off = 0, in_suggidx_off = 0, in_status_off = 0;
     hipStream_t cs = nullptr, ss = nullptr, fs = nullptr;  // cut rounds, SHA service, synthetic producer
+    hipStream_t ls = nullptr;             // the LANES service when lanes_cus > 0
     hipStream_t xs = nullptr;             // the EXPRESS service (two lanes per chunk, long chunks only) when xp_cus > 0
     hipStream_t ps = nullptr;             // scan side of the cut rounds (head pads + scan): round n + 1 is scanned while round n's
                                           // control kernel runs on cs (PBSGPU_RING_OVERLAP=0: everything on cs)
@@ -119,7 +121,7 @@ struct pbsgpu_ring {
     bool split_auto = false;
     uint32_t svc_cus = 0;                 // CUs of both services together (constant)
     double obs_bytes = 0, obs_long_bytes = 0;
-    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr, ev_xsvc1 = nullptr;
+    hipEvent_t ev_reset = nullptr, ev_svc0 = nullptr, ev_svc1 = nullptr, ev_xsvc1 = nullptr, ev_lsvc1 = nullptr;
     hipEvent_t ev_fill[pbse::kRingInputs] = {};
     std::vector<hipEvent_t> ev_pool;      // page dependency events (ring_event_get / ring_event_put)
     pbse::SvcState svc = pbse::SvcState::Stopped;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 6, call 28: what does the lanes service carry?
+out=gpurun_out/r6c28; mkdir -p $out
+export PYTHONFAULTHANDLER=1 PBS_BENCH_RING_DEBUG=1
+run() { t=$1; shift
+  env "$@" timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $out/b_$t.json 2> $out/b_$t.err
+  python3 - $out/b_$t.json "$*" <<'PY'
+import json,sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']; print(sys.argv[2], d['value'], r['feed_phase']['GiBps'], r['feed_phase']['drain_seconds'])
+PY
+  grep "ring debug" $out/b_$t.err | tail -1
+}
+run a PBSGPU_RING_LANES_CUS=64 PBSGPU_RING_SHORT_BYTES=6291456
+run b PBSGPU_RING_LANES_CUS=32 PBSGPU_RING_SHORT_BYTES=6291456

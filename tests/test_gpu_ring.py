@@ -69,6 +69,12 @@ SMALL = dict(page_bytes=65536, max_streams=8, sha_cus=4, round_pages=6)
     ("avg 64 KiB", 65536, dict(arena_bytes=96 * (262144 + 256), page_bytes=262144, max_streams=8, sha_cus=16, round_pages=16),
      [(41 + i, i % 5, (8 << 20) + 4099 * i) for i in range(6)], None),
     # PBSGPU_RING_F_DENSE_SERVICE = 64: the pair service with eight waves per CU (measured and not the default: DESIGN.md 5.2)
+    # the LANES service (lanes_cus of the pair service's CUs, chunks of at most short_bytes: DESIGN.md 5.5): 2 of 4 CUs, and every
+    # chunk short enough for it
+    ("lanes service", 4096, dict(arena_bytes=24 * (65536 + 256), lanes_cus=2, short_bytes=8192, **SMALL),
+     [(61, 0, (1 << 20) + 5), (62, 1, 300 * 1024), (63, 3, 700 * 1024 + 3), (64, 0, 0), (65, 0, 63), (66, 2, 65536)], None),
+    ("lanes service, all chunks", 4096, dict(arena_bytes=24 * (65536 + 256), lanes_cus=3, short_bytes=16384, **SMALL),
+     [(71, 0, (1 << 20) + 5), (72, 4, 300 * 1024), (73, 3, 700 * 1024 + 3), (74, 0, 1)], None),
     ("dense service form", 4096, dict(arena_bytes=24 * (65536 + 256), flags=64, **SMALL),
      [(51, 0, (1 << 20) + 5), (52, 1, 300 * 1024), (53, 3, 700 * 1024 + 3), (54, 0, 0), (55, 0, 63), (56, 2, 65536)], None),
 ])
