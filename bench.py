@@ -936,6 +936,8 @@ def ring_run(a, rank, local_rank, world, ctx):
                     and ring.stats()["bytes_enqueued"] >= enq0 + nfiles * file_bytes):
                 marks["t_fed"] = time.perf_counter()     # every byte of the last file is in a cut round
                 marks["loopstat_fed"] = list(loopstat)
+                if os.environ.get("PBS_BENCH_RING_DEBUG"):
+                    marks["raw_fed"] = ring.debug()
                 marks["probe_fed"] = ring.probe()
                 if os.environ.get("PBS_BENCH_RING_TRACE"):   # queue state at the end of the feed phase (diagnostic)
                     marks["fed_state"] = (ring.debug().splitlines()[0], ring.stats())
@@ -982,6 +984,7 @@ def ring_run(a, rank, local_rank, world, ctx):
     state["timed"], state["first_timed"] = True, state["next_file"]
     st0 = ring.stats()
     probe0 = ring.probe()
+    raw0 = ring.debug() if os.environ.get("PBS_BENCH_RING_DEBUG") else None
     t0 = time.perf_counter()
     kept = run_files(a.steps, True)
     t_fed = marks.get("t_fed", None)
@@ -990,6 +993,18 @@ def ring_run(a, rank, local_rank, world, ctx):
         it, nf, nz = marks["loopstat_fed"]
         print("[feeder] feed phase %.3f s: %d loop iterations (%.0f us each), %d fill calls, %d of them got no page (%.1f %%)"
               % (t_fed - t0, it, (t_fed - t0) * 1e6 / max(it, 1), nf, nz, 100.0 * nz / max(nf, 1)), file=sys.stderr, flush=True)
+    if raw0 and "raw_fed" in marks and rank == 0:   # lane occupancy of the probe waves in the feed phase (pbsgpu_ring_debug's raw counters)
+        import re as _re
+
+        def _raw(t):
+            m = _re.search(r"probe raw: pair_steps=(\d+) pair_active=(\d+) lanes_steps=(\d+) lanes_active=(\d+)", t)
+            return [int(x) for x in m.groups()] if m else None
+        a0, a1 = _raw(raw0), _raw(marks["raw_fed"])
+        if a0 and a1:
+            d = [y - x for x, y in zip(a0, a1)]
+            print("[occupancy] feed phase: pair probe wave %.3f of its lanes busy (%d steps)%s" % (
+                d[1] / (64.0 * d[0]) if d[0] else 0.0, d[0],
+                ", lanes-service probe wave %.3f (%d steps)" % (d[3] / (64.0 * d[2]), d[2]) if d[2] else ""), file=sys.stderr, flush=True)
     if "fed_state" in marks and rank == 0:
         print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
               "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)

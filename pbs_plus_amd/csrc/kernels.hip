@@ -1199,19 +1199,25 @@ struct SegmentSource {
 
 // the services' regime probe (RingSource::probe): called once per block step by the service's probe wave, wave-uniform
 struct RingProbe {
-    uint32_t n = 0, idle = 0;
+    uint32_t n = 0, idle = 0, act = 0;
     unsigned long long c0 = 0, w0 = 0;
 };
-__device__ __forceinline__ void ring_probe_step(const RingSource &src, RingProbe &pb, const bool busy, const int slot, const int lane) {
+// (`active`: lanes of the probe wave that carried a block in this step -> probe[8] for the pair service: how full its lanes are,
+// pbsgpu_ring_debug)
+__device__ __forceinline__ void ring_probe_step(const RingSource &src, RingProbe &pb, const bool busy, const int slot, const int lane,
+                                                const uint32_t active = 0) {
     pb.idle |= busy ? 0u : 1u;
+    pb.act += active;
     if (++pb.n < kRingProbeSteps) return;
     const unsigned long long c = clock64(), w = wall_clock64();
     if (!pb.idle && pb.w0 != 0ull && lane == 0 && src.probe) {
         atomicAdd(src.probe + slot, (unsigned long long)kRingProbeSteps);
         atomicAdd(src.probe + slot + 1, c - pb.c0);
         atomicAdd(src.probe + slot + 2, w - pb.w0);
+        if (slot == 0) atomicAdd(src.probe + 8, (unsigned long long)pb.act);
     }
     pb.n = 0;
+    pb.act = 0;
     pb.idle = 0;
     pb.c0 = c;
     pb.w0 = w;
@@ -1399,20 +1405,23 @@ __global__ __launch_bounds__(256) void k_sha256_lanes(RingSource src) {
     // regime probe of this service (pbsgpu_ring_debug): workgroup 0's first wave, steps and 100 MHz ticks of the intervals in which
     // it carried a block in every step -> probe[6], probe[7]
     const bool probe_on = src.probe != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
-    uint32_t pn = 0, pidle = 0;
+    uint32_t pn = 0, pidle = 0, pact = 0;
     unsigned long long pw0 = 0;
     acquire(true);
     if (have) load_block();
     for (;;) {
         if (probe_on) {
-            pidle |= __any(have) ? 0u : 1u;
+            const unsigned long long hm = __ballot(have);
+            pidle |= hm ? 0u : 1u;
+            pact += (uint32_t)__popcll(hm);
             if (++pn >= kRingProbeSteps) {
                 const unsigned long long w = wall_clock64();
                 if (!pidle && pw0 != 0ull && lane == 0) {
                     atomicAdd(src.probe + 6, (unsigned long long)kRingProbeSteps);
                     atomicAdd(src.probe + 7, w - pw0);
+                    atomicAdd(src.probe + 9, (unsigned long long)pact);
                 }
-                pn = 0; pidle = 0; pw0 = w;
+                pn = 0; pidle = 0; pact = 0; pw0 = w;
             }
         }
         if (!__any(have)) {  // the wave holds nothing: leave once every lane has seen `stop` with the queue empty, else nap and look again
@@ -1869,7 +1878,7 @@ __global__ __launch_bounds__(DENSE ? 512 : 256) void k_sha256_pair(Source src, c
                             idle_since = 0;
                         }
                         if (lane == 0) curw[pr][pb] = any_cur ? 1u : 0u;
-                        if (probe_on) ring_probe_step(src, probe, any_cur, 0, lane);
+                        if (probe_on) ring_probe_step(src, probe, any_cur, 0, lane, (uint32_t)__popcll(__ballot(c & 1u)));
                     }
                     if (lane == 0) alive[pr][pb] = live ? 1u : 0u;
                     __syncthreads();

@@ -864,7 +864,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
 
         CHK(r->arena.ensure((size_t)r->npages * r->stride + 512));
         CHK(r->ctl.ensure(256));
-        CHK(r->probe.ensure(64));
+        CHK(r->probe.ensure(128));
         CHK(r->streams.ensure((size_t)r->max_streams * sizeof(pbsk::RingStreamState)));
         CHK(r->pending.ensure((size_t)r->npages * 4 + 64));
         CHK(r->desc.ensure((size_t)r->qslots * 32));
@@ -935,7 +935,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         // tail, stream states and page reference counts — pages never came back, lanes waited at positions the tail had
         // been reset below (the one-in-a-few-hundred hang of the small-ring tests).
         HIPCHK(hipMemsetAsync(r->ctl.p, 0, 256, r->cs));
-        HIPCHK(hipMemsetAsync(r->probe.p, 0, 64, r->cs));
+        HIPCHK(hipMemsetAsync(r->probe.p, 0, 128, r->cs));
         HIPCHK(hipMemsetAsync(r->streams.p, 0, (size_t)r->max_streams * sizeof(pbsk::RingStreamState), r->cs));
         HIPCHK(hipMemsetAsync(r->pending.p, 0, (size_t)r->npages * 4 + 64, r->cs));
         HIPCHK(hipMemsetAsync(r->scalars.p, 0, pbsk::kRsCount * 4 + 64, r->cs));
@@ -1356,10 +1356,13 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
         r->free_pages.size(), r->rounds.size(), r->next_seq, r->rounds_enq, (int)r->svc, r->tail_seen, hb[pbsk::kHbClaim],
         (unsigned long long)r->backlog_limit, hb[pbsk::kHbIntent], hb[pbsk::kHbCommitted]);
     {
-        unsigned long long pr[8] = {};
+        unsigned long long pr[16] = {};
         HIPCHK(hipMemcpy(pr, r->probe.p, sizeof(pr), hipMemcpyDeviceToHost));
-        put("lanes service: cus=%u short_bytes=%u stail=%u shead=%u steps_sampled=%llu ns_per_block_step=%.1f | pair cus=%u express cus=%u\n",
-            r->lanes_cus, r->short_bytes, ctl.stail, ctl.shead, pr[6], pr[6] ? (double)pr[7] * 10.0 / (double)pr[6] : 0.0, r->sha_cus, r->xp_cus);
+        put("lanes service: cus=%u short_bytes=%u stail=%u shead=%u steps_sampled=%llu ns_per_block_step=%.1f lanes_busy=%.3f | pair cus=%u "
+            "lanes_busy=%.3f (probe wave, intervals with a block in every step) express cus=%u\n",
+            r->lanes_cus, r->short_bytes, ctl.stail, ctl.shead, pr[6], pr[6] ? (double)pr[7] * 10.0 / (double)pr[6] : 0.0,
+            pr[6] ? (double)pr[9] / (64.0 * (double)pr[6]) : 0.0, r->sha_cus, pr[0] ? (double)pr[8] / (64.0 * (double)pr[0]) : 0.0, r->xp_cus);
+        put("probe raw: pair_steps=%llu pair_active=%llu lanes_steps=%llu lanes_active=%llu\n", pr[0], pr[8], pr[6], pr[9]);
     }
     uint32_t nz = 0;
     for (uint32_t p = 0; p < r->npages && nz < 64; ++p)

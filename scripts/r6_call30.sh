@@ -10,7 +10,7 @@ for l in open(sys.argv[1]):
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; print(sys.argv[2], d['value'], r['feed_phase']['GiBps'], r['feed_phase']['drain_seconds'], 'one file', r['single_file']['ms'], 'rounds', d['config']['rounds_in_timed_region'])
 PY
-  grep "feeder\]" $out/b_$t.err | tail -1 | cut -c1-220
+  grep "feeder\]\|occupancy\]" $out/b_$t.err | tail -2 | cut -c1-400
 }
 run base X=1
 run l64 PBSGPU_RING_LANES_CUS=64 PBSGPU_RING_SHORT_BYTES=6291456
