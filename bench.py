@@ -902,12 +902,16 @@ def ring_run(a, rank, local_rank, world, ctx):
             extra["dedup_last_step"] = {k: int(v) for k, v in stats.items()}
             state["next_reduce"] += 1
 
+    trace_free_all = []
+
     def run_files(nfiles, keep):
         """nfiles whole files through the ring, S at a time; returns {file index: records} of the kept ones"""
         out, active, opened, done = {}, {}, 0, 0
         marks.clear()
         loopstat = [0, 0, 0]   # feeder loop: iterations, fill calls, fill calls that got no page (arena empty or backlog gate)
         marks["loopstat"] = loopstat
+        del trace_free_all[:]
+        trace_free = trace_free_all if (os.environ.get("PBS_BENCH_RING_TRACE") and state["timed"] and nfiles > 1) else None
         base = state["next_file"]
         enq0 = ring.stats()["bytes_enqueued"]
         t_last = time.perf_counter()
@@ -932,6 +936,8 @@ def ring_run(a, rank, local_rank, world, ctx):
                     loopstat[1] += 1
                     loopstat[2] += 1 if got == 0 else 0
             ring.pump()
+            if trace_free is not None and loopstat[0] % 128 == 0 and "t_fed" not in marks:    # diagnostic: what refuses the feeder, the gate or the arena?
+                trace_free.append(ring.stats()["pages_free"])
             if (opened == nfiles and "t_fed" not in marks and not any(st[1] for st in active.values())
                     and ring.stats()["bytes_enqueued"] >= enq0 + nfiles * file_bytes):
                 marks["t_fed"] = time.perf_counter()     # every byte of the last file is in a cut round
@@ -1005,6 +1011,12 @@ def ring_run(a, rank, local_rank, world, ctx):
             print("[occupancy] feed phase: pair probe wave %.3f of its lanes busy (%d steps)%s" % (
                 d[1] / (64.0 * d[0]) if d[0] else 0.0, d[0],
                 ", lanes-service probe wave %.3f (%d steps)" % (d[3] / (64.0 * d[2]), d[2]) if d[2] else ""), file=sys.stderr, flush=True)
+    if trace_free_all and rank == 0:
+        trace_free = list(trace_free_all)
+        tf = np.array(trace_free[len(trace_free) // 4:], dtype=np.float64)   # the steady state: without the first quarter
+        print("[ring trace] free pages seen by the feeder (every 128th loop iteration, last 3/4 of the run): min %d median %d mean %.0f "
+              "max %d of %d; share of samples with fewer than 64 free: %.3f" % (tf.min(), np.median(tf), tf.mean(), tf.max(),
+              ring.stats()["pages_total"], float((tf < 64).mean())), file=sys.stderr, flush=True)
     if "fed_state" in marks and rank == 0:
         print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
               "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)

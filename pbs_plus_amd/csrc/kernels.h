@@ -280,7 +280,7 @@ constexpr uint32_t kRingProbeSteps = 4096;  // block steps between two samples o
 
 
 // scalar slots of a round (same numbering as engine_internal.h's SC_*)
-enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsNshort = 4, kRsShortRoom = 5, kRsTileq = 6 /* u64 */, kRsCount = 10 };
+enum : int { kRsNcand = 0, kRsNrec = 1, kRsMaxcnt = 2, kRsNlong = 3, kRsNshort = 4, kRsShortRoom = 5, kRsTileq = 6 /* u64 */, kRsNmain = 8, kRsCount = 10 };
 
 // One physical page of a round (host-written into mapped pinned memory; the round's kernels read the device copy k_ring_stage makes).
 struct RingPage {
@@ -335,7 +335,11 @@ struct RingRoundStatus {   // mapped pinned: written last by a round
     uint32_t error;        // 2 = record / cell capacity (ring-wide: the host's own bound was wrong, never the data's fault)
     uint32_t tail;         // queue tail after this round
     uint32_t pad[3];
+    // the services' probe counters (RingSource::probe, words 0..5) as this round found them: pbsgpu_ring_get_probe answers from
+    // the newest reaped round while a service runs — no HIP call of the host beside a persistent kernel
+    unsigned long long probe[6];
 };
+static_assert(sizeof(RingRoundStatus) == 80, "host slot: 128 bytes (ring.cpp: input_stride)");
 struct RingRound {
     // geometry / constants
     uint8_t *arena;            // device: [pad | page 0 | pad][pad | page 1 | pad] ...

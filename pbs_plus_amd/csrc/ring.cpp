@@ -142,6 +142,8 @@ void ring_reap_rounds(pbsgpu_ring *r) {
             r->pub_positions += (uint32_t)(hs->tail - r->tail_seen);
             r->pub_bytes += ri.new_bytes;
             r->tail_seen = hs->tail;
+            for (int i = 0; i < 6; ++i) r->probe_seen[i] = hs->probe[i];
+            r->probe_seen_valid = true;
         }
         for (uint32_t s : ri.finals) r->slots[s].final_done = true;
         r->inflight_bytes -= ri.new_bytes;
@@ -911,7 +913,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->in_recbase_off = al64(r->in_segs_off + (size_t)r->max_streams * sizeof(pbsk::RingSeg));
         r->in_suggidx_off = al64(r->in_recbase_off + ((size_t)r->max_streams + 1) * 4);
         r->in_status_off = al64(r->in_suggidx_off + ((size_t)r->max_streams + 1) * 4);
-        r->input_stride = r->in_status_off + 64;
+        r->input_stride = r->in_status_off + 128;
         CHK(r->inputs.ensure(r->input_stride * kRingInputs));
         // PBSGPU_RING_F_NO_STAGE: the round's kernels read their tables from mapped host memory (rounds 3-4), for A/B runs
         r->stage_inputs = !(o.flags & PBSGPU_RING_F_NO_STAGE);
@@ -1399,8 +1401,20 @@ int pbsgpu_ring_express(pbsgpu_ring *r, uint32_t *express_cus, uint64_t *long_by
 int pbsgpu_ring_get_probe(pbsgpu_ring *r, pbsgpu_ring_probe *out) {
     if (!r || !out) return PBSGPU_E_INVALID;
     static_assert(sizeof(pbsgpu_ring_probe) == 48, "six counters");
+    // While a service runs the answer comes from the newest reaped round's status block (k_ring_control copies the counters
+    // there, mapped pinned: at most one round — about a millisecond — old; the probe waves sample every ~7 ms): no HIP call
+    // of the host beside a persistent kernel. (Until the end of round 6 this was a hipMemcpy on the null stream inside
+    // bench.py's timed region; pbsgpu_ring_debug, which still copies that way, was seen to stall for the service's idle
+    // timeout in 2 of 6 diagnostic runs.) With the service stopped the device counters are read directly: exact.
+    if (r->svc == SvcState::Running) {
+        ring_reap_rounds(r);
+        if (r->probe_seen_valid) {
+            std::memcpy(out, r->probe_seen, sizeof(*out));
+            return PBSGPU_OK;
+        }
+    }
     CHK(set_device(r->eng));
-    HIPCHK(hipMemcpy(out, r->probe.p, sizeof(*out), hipMemcpyDeviceToHost));  // (null stream: not ordered against the service)
+    HIPCHK(hipMemcpy(out, r->probe.p, sizeof(*out), hipMemcpyDeviceToHost));
     return PBSGPU_OK;
 }
 
