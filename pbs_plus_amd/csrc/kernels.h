@@ -407,7 +407,7 @@ hipError_t launch_ring_round(const RingRound &r, int num_cus, hipStream_t st, hi
 // the persistent SHA-256 service: `workgroups` x (2 producer + 2 consumer waves), one per CU
 hipError_t launch_ring_service(const RingSource &q, unsigned workgroups, hipStream_t st, bool dense = false);
 hipError_t launch_ring_service_xp(const RingSource &q, unsigned workgroups, hipStream_t st);
-hipError_t launch_ring_service_lanes(const RingSource &q, unsigned workgroups, hipStream_t st);
+hipError_t launch_ring_service_lanes(const RingSource &q, unsigned workgroups, hipStream_t st, bool dense);
 // raise `stop` behind everything enqueued so far on `st`
 hipError_t launch_ring_stop(RingCtl *ctl, hipStream_t st);
 hipError_t launch_ring_reset(RingCtl *ctl, hipStream_t st);

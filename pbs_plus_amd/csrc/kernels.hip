@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(64) void k_sha256(Source src, const uint32_t *nitem
 // the CU's whole LDS like the other services). 81 chain-blocks per us and CU against the pair form's 74 — and 3.2 us per block for
 // every chain, which is why only SHORT chunks come here and only while this service has room (k_ring_control). The queue is a
 // compare-and-swap queue like the long one: a lane never claims a position it then has to wait at.
-__global__ __launch_bounds__(256) void k_sha256_lanes(RingSource src) {
+__global__ __launch_bounds__(512) void k_sha256_lanes(RingSource src) {
     const int lane = threadIdx.x & 63;
     const uint8_t *base = nullptr, *base2 = nullptr;
     uint64_t len = 0, blk = 0, nblk = 0;
@@ -2529,10 +2529,14 @@ hipError_t launch_sha256_segments(const uint8_t *data, const pbsgpu_segment *seg
     }
     hipError_t e = allow_lds(&k_sha256<SegmentSource>, kLaneLdsPad);
     if (e != hipSuccess) return e;
-    unsigned grid = (unsigned)num_cus * 4u;
+    // `dense` with this form (sha_form 1 + sha_dense_pct): EIGHT single-wave workgroups per CU, two waves per SIMD — a measurement
+    // (profiles/r06_sha_forms_full_lanes.log section 3): with two waves on a SIMD v_add_u32 / v_xor_b32 issue at twice the rate
+    // of the three-operand forms (profiles/r01_ubench_opcode_issue_cost.log)
+    const size_t pad = dense ? kLaneLdsPad / 2 : kLaneLdsPad;
+    unsigned grid = (unsigned)num_cus * (dense ? 8u : 4u);
     const unsigned need = (nseg + 63) / 64;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), kLaneLdsPad, st, src, (const uint32_t *)nullptr,
+    hipLaunchKernelGGL((k_sha256<SegmentSource>), dim3(grid), dim3(64), pad, st, src, (const uint32_t *)nullptr,
                        nseg, queue, (const uint32_t *)nullptr, 0u);
     return hipGetLastError();
 }

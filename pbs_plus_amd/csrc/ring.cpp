@@ -167,7 +167,7 @@ int ring_launch_services(pbsgpu_ring *r) {
     }
     if (r->lanes_cus) {
         HIPCHK(hipStreamWaitEvent(r->ls, r->ev_reset, 0));
-        HIPCHK(pbsk::launch_ring_service_lanes(r->source(), r->lanes_cus, r->ls));
+        HIPCHK(pbsk::launch_ring_service_lanes(r->source(), r->lanes_cus, r->ls, r->dense_lanes));
         HIPCHK(hipEventRecord(r->ev_lsvc1, r->ls));
         HIPCHK(hipStreamWaitEvent(r->ss, r->ev_lsvc1, 0));
     }
@@ -592,6 +592,7 @@ void ring_env_overrides(pbsgpu_ring_options &o) {
         {"PBSGPU_RING_DEFER_SERVICE", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DEFER_SERVICE},
         {"PBSGPU_RING_FILL_SERIAL", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_FILL_SERIAL},
         {"PBSGPU_RING_DENSE_SERVICE", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DENSE_SERVICE},
+        {"PBSGPU_RING_DENSE_LANES", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DENSE_LANES},
     };
     for (const Entry &e : table) {
         const char *v = getenv(e.name);
@@ -623,7 +624,7 @@ pbsk::RingSource pbsgpu_ring::source() const {
     q.short_bytes = lanes_cus ? short_bytes : 0u;
     // entries that may wait for the lanes service: its lanes take ~2 chunks per CU and round (256 lanes x 1.2 ms / ~0.15 s per
     // chunk); 32 per CU rides out a dozen rounds and fills an idle service within ten
-    q.short_room = lanes_cus * 32u;
+    q.short_room = lanes_cus * (dense_lanes ? 64u : 32u);
     q.xp = xp_cus ? 1u : 0u;
     // the pair lanes take a long chunk only while EVERY express pair is busy (RingCtl::xp_busy): random data keeps the express
     // service just busy (2.6 long chunks per ms against the 2.8 it can take), a corpus whose files are mostly zero runs or
@@ -838,6 +839,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->defer_service = (o.flags & PBSGPU_RING_F_DEFER_SERVICE) != 0;
         r->fill_serial = (o.flags & PBSGPU_RING_F_FILL_SERIAL) != 0;
         r->dense_service = (o.flags & PBSGPU_RING_F_DENSE_SERVICE) != 0;
+        r->dense_lanes = (o.flags & PBSGPU_RING_F_DENSE_LANES) != 0;
         r->lone_defer_ms = o.lone_defer_ms < 0 ? 0.0 : o.lone_defer_ms > 0 ? o.lone_defer_ms : 25.0;
         r->idle_timeout_s = o.idle_timeout_s;
         r->opt_long_lo = o.long_lo_bytes;

@@ -16,7 +16,7 @@ segs = [(i * seg, seg) for i in range(nseg)]
 host = data[: seg].cpu().numpy().tobytes()
 want0 = hashlib.sha256(host).digest()
 for name, opts in (("pairs sparse", dict(sha_form=0, sha_dense_pct=1000000)), ("pairs dense", dict(sha_form=0, sha_dense_pct=1)),
-                   ("lanes", dict(sha_form=1)), ("express", dict(sha_form=2))):
+                   ("lanes", dict(sha_form=1, sha_dense_pct=1000000)), ("lanes dense", dict(sha_form=1, sha_dense_pct=1)), ("express", dict(sha_form=2))):
     e = Engine(buzhash.NewConfig(4 << 20), **opts)
     out = e.sha256_many(data, segs)
     assert bytes(out[0]) == want0, name

@@ -75,6 +75,9 @@ SMALL = dict(page_bytes=65536, max_streams=8, sha_cus=4, round_pages=6)
      [(61, 0, (1 << 20) + 5), (62, 1, 300 * 1024), (63, 3, 700 * 1024 + 3), (64, 0, 0), (65, 0, 63), (66, 2, 65536)], None),
     ("lanes service, all chunks", 4096, dict(arena_bytes=24 * (65536 + 256), lanes_cus=3, short_bytes=16384, **SMALL),
      [(71, 0, (1 << 20) + 5), (72, 4, 300 * 1024), (73, 3, 700 * 1024 + 3), (74, 0, 1)], None),
+    # PBSGPU_RING_F_DENSE_LANES = 128: the lanes service with eight waves per CU (profiles/r06_lanes_service.log, calls 37-40)
+    ("lanes service, eight waves per CU", 4096, dict(arena_bytes=24 * (65536 + 256), lanes_cus=2, short_bytes=16384, flags=128, **SMALL),
+     [(81, 0, (1 << 20) + 5), (82, 1, 300 * 1024), (83, 3, 700 * 1024 + 3), (84, 0, 0), (85, 0, 65), (86, 2, 65536)], None),
     ("dense service form", 4096, dict(arena_bytes=24 * (65536 + 256), flags=64, **SMALL),
      [(51, 0, (1 << 20) + 5), (52, 1, 300 * 1024), (53, 3, 700 * 1024 + 3), (54, 0, 0), (55, 0, 63), (56, 2, 65536)], None),
 ])
