@@ -903,6 +903,7 @@ def ring_run(a, rank, local_rank, world, ctx):
             state["next_reduce"] += 1
 
     trace_free_all = []
+    trace_done, delivered = [], [0]
 
     def run_files(nfiles, keep):
         """nfiles whole files through the ring, S at a time; returns {file index: records} of the kept ones"""
@@ -911,6 +912,9 @@ def ring_run(a, rank, local_rank, world, ctx):
         loopstat = [0, 0, 0]   # feeder loop: iterations, fill calls, fill calls that got no page (arena empty or backlog gate)
         marks["loopstat"] = loopstat
         del trace_free_all[:]
+        if state["timed"] and nfiles > 1:
+            del trace_done[:]
+            delivered[0] = 0
         trace_free = trace_free_all if (os.environ.get("PBS_BENCH_RING_TRACE") and state["timed"] and nfiles > 1) else None
         base = state["next_file"]
         enq0 = ring.stats()["bytes_enqueued"]
@@ -945,13 +949,17 @@ def ring_run(a, rank, local_rank, world, ctx):
                 if os.environ.get("PBS_BENCH_RING_DEBUG"):
                     marks["raw_fed"] = ring.debug()
                 marks["probe_fed"] = ring.probe()
-                if os.environ.get("PBS_BENCH_RING_TRACE"):   # queue state at the end of the feed phase (diagnostic)
+                if os.environ.get("PBS_BENCH_RING_TRACE") == "2":   # queue state at the end of the feed phase (diagnostic; pbsgpu_ring_debug
+                    # copies on the null stream and was seen to stall beside the services: profiles/r06_lanes_service.log)
                     marks["fed_state"] = (ring.debug().splitlines()[0], ring.stats())
             for sid in list(active):
                 recs, fin = ring.poll(sid, 8192)
                 if recs.size:
                     active[sid][2].append(recs.copy())
                     t_last = time.perf_counter()
+                    if trace_free is not None:   # diagnostic: bytes of delivered records against time (the services' real rate)
+                        delivered[0] += int(recs["size"].sum())
+                        trace_done.append((t_last, delivered[0]))
                 if fin:
                     fidx, _, parts = active.pop(sid)
                     ring.close_stream(sid)
@@ -1017,6 +1025,16 @@ def ring_run(a, rank, local_rank, world, ctx):
         print("[ring trace] free pages seen by the feeder (every 128th loop iteration, last 3/4 of the run): min %d median %d mean %.0f "
               "max %d of %d; share of samples with fewer than 64 free: %.3f" % (tf.min(), np.median(tf), tf.mean(), tf.max(),
               ring.stats()["pages_total"], float((tf < 64).mean())), file=sys.stderr, flush=True)
+    if trace_done and t_fed and rank == 0:
+        # slope of delivered bytes over the steady state: from 35 % of the feed phase to its end (records are delivered in stream
+        # order, so the curve lags the hashing by up to one long chain — a constant lag in the steady state)
+        td = np.array(trace_done, dtype=np.float64)
+        a_, b_ = t0 + 0.35 * (t_fed - t0), t_fed
+        m_ = (td[:, 0] >= a_) & (td[:, 0] <= b_)
+        if m_.sum() > 8:
+            sl = np.polyfit(td[m_, 0], td[m_, 1], 1)[0]
+            print("[ring trace] delivered records, slope over the last 65 %% of the feed phase: %.1f GiB/s (%d samples)"
+                  % (sl / GiB, int(m_.sum())), file=sys.stderr, flush=True)
     if "fed_state" in marks and rank == 0:
         print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
               "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)
