@@ -440,13 +440,16 @@ int pbsgpu_ring_express(pbsgpu_ring *ring, uint32_t *express_cus, uint64_t *long
  * block in every step of the interval, adds the interval to these sums. ticks / steps x 10 = ns per block step of a chain
  * UNDER LOAD (an express step is two blocks of a chunk); cycles / ticks x 100 = the shader clock in MHz that chain ran at.
  * Read it twice and subtract to look at a phase (bench.py: feed phase and drain of the timed region -> `roofline`).
- * Safe while the service runs. */
+ * Safe while the service runs: the answer then comes from the newest finished cut round's status block (the control kernel
+ * copies the counters there, at most one round old) and no HIP call is made beside the persistent kernels; with the service
+ * stopped (after pbsgpu_ring_quiesce) the device counters are read directly. Same thread rule as every pbsgpu_ring_* call. */
 typedef struct pbsgpu_ring_probe {
     uint64_t pair_steps, pair_cycles, pair_ticks;
     uint64_t express_steps, express_cycles, express_ticks;
 } pbsgpu_ring_probe;
 int pbsgpu_ring_get_probe(pbsgpu_ring *ring, pbsgpu_ring_probe *out);
-/* Diagnostic text snapshot of the ring's device-side state (queue words, page reference counts, stream states). */
+/* Diagnostic text snapshot of the ring's device-side state (queue words, page reference counts, stream states). Debugging
+ * only: it copies from the device on the null stream, which may wait for a running service's idle time-out. */
 int pbsgpu_ring_debug(pbsgpu_ring *ring, char *buf, uint64_t cap);
 
 /* ---- whole-stream SHA-256 batch ---------------------------------------------
