@@ -903,7 +903,7 @@ def ring_run(a, rank, local_rank, world, ctx):
             state["next_reduce"] += 1
 
     trace_free_all = []
-    trace_done, delivered = [], [0]
+    trace_done, delivered = [], [0, 0, 0]
 
     def run_files(nfiles, keep):
         """nfiles whole files through the ring, S at a time; returns {file index: records} of the kept ones"""
@@ -914,7 +914,7 @@ def ring_run(a, rank, local_rank, world, ctx):
         del trace_free_all[:]
         if state["timed"] and nfiles > 1:
             del trace_done[:]
-            delivered[0] = 0
+            delivered[:] = [0, 0, 0]
         trace_free = trace_free_all if (os.environ.get("PBS_BENCH_RING_TRACE") and state["timed"] and nfiles > 1) else None
         base = state["next_file"]
         enq0 = ring.stats()["bytes_enqueued"]
@@ -959,7 +959,10 @@ def ring_run(a, rank, local_rank, world, ctx):
                     t_last = time.perf_counter()
                     if trace_free is not None:   # diagnostic: bytes of delivered records against time (the services' real rate)
                         delivered[0] += int(recs["size"].sum())
-                        trace_done.append((t_last, delivered[0]))
+                        tier = recs["segment"] >> 28   # (PBSGPU_RING_TIER_TAG=1: 0 main queue, 1 long, 2 short; else all 0)
+                        for k_ in (1, 2):
+                            delivered[k_] += int(recs["size"][tier == k_].sum())
+                        trace_done.append((t_last, delivered[0], delivered[1], delivered[2]))
                 if fin:
                     fidx, _, parts = active.pop(sid)
                     ring.close_stream(sid)
@@ -1032,9 +1035,10 @@ def ring_run(a, rank, local_rank, world, ctx):
         a_, b_ = t0 + 0.35 * (t_fed - t0), t_fed
         m_ = (td[:, 0] >= a_) & (td[:, 0] <= b_)
         if m_.sum() > 8:
-            sl = np.polyfit(td[m_, 0], td[m_, 1], 1)[0]
-            print("[ring trace] delivered records, slope over the last 65 %% of the feed phase: %.1f GiB/s (%d samples)"
-                  % (sl / GiB, int(m_.sum())), file=sys.stderr, flush=True)
+            sl = [np.polyfit(td[m_, 0], td[m_, c_], 1)[0] / GiB for c_ in (1, 2, 3)]
+            print("[ring trace] delivered records, slope over the last 65 %% of the feed phase: %.1f GiB/s (%d samples); by queue "
+                  "(PBSGPU_RING_TIER_TAG): main %.1f, long %.1f, short %.1f" % (sl[0], int(m_.sum()), sl[0] - sl[1] - sl[2], sl[1], sl[2]),
+                  file=sys.stderr, flush=True)
     if "fed_state" in marks and rank == 0:
         print("[ring trace] at end of feed:", marks["fed_state"][0], "| pages_free", marks["fed_state"][1]["pages_free"],
               "of", marks["fed_state"][1]["pages_total"], file=sys.stderr, flush=True)

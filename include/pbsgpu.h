@@ -373,6 +373,7 @@ typedef struct pbsgpu_ring_options {
 #define PBSGPU_RING_F_FILL_SERIAL 32u    /* experiments: the synthetic refill in stream order behind the previous scan */
 #define PBSGPU_RING_F_DENSE_SERVICE 64u  /* the pair service with FOUR pairs (eight waves) per CU: more bytes per CU-second, every chain slower */
 #define PBSGPU_RING_F_DENSE_LANES 128u   /* the lanes service (lanes_cus) with EIGHT waves per CU: 84 instead of 77-81 chain-blocks per us and CU, 6 us per block */
+#define PBSGPU_RING_F_TIER_TAG 256u      /* diagnostics: pbsgpu_ring_poll* report the queue a chunk went through in bits 28-29 of `segment` (0 main, 1 long, 2 short) */
 typedef struct pbsgpu_ring_stats {
     uint64_t page_bytes, bytes_enqueued, chunks, candidates, pages_enqueued, pages_recycled, service_bytes_last;
     uint32_t pages_total, pages_free, sha_cus, rounds, rounds_done, rounds_in_flight, streams_opened, service_launches;

@@ -87,6 +87,7 @@ RING_OFF = 0xFFFFFFFF
 RING_F_NO_OVERLAP, RING_F_NO_STAGE, RING_F_NO_CUT_PRIO, RING_F_NO_SPLIT_AUTO, RING_F_DEFER_SERVICE, RING_F_FILL_SERIAL = 1, 2, 4, 8, 16, 32
 RING_F_DENSE_SERVICE = 64
 RING_F_DENSE_LANES = 128
+RING_F_TIER_TAG = 256
 
 
 class RingOptions(C.Structure):

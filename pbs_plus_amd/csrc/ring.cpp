@@ -593,6 +593,7 @@ void ring_env_overrides(pbsgpu_ring_options &o) {
         {"PBSGPU_RING_FILL_SERIAL", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_FILL_SERIAL},
         {"PBSGPU_RING_DENSE_SERVICE", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DENSE_SERVICE},
         {"PBSGPU_RING_DENSE_LANES", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_DENSE_LANES},
+        {"PBSGPU_RING_TIER_TAG", FLAG_IF_SET, &o.flags, PBSGPU_RING_F_TIER_TAG},
     };
     for (const Entry &e : table) {
         const char *v = getenv(e.name);
@@ -682,6 +683,7 @@ void ring_pop_records(pbsgpu_ring *r, uint32_t slot, pbsgpu_record *out, uint64_
         pbsgpu_record rec;
         std::memcpy(&rec, c, sizeof(rec));
         rec.segment = slot;
+        if (r->tier_tag) rec.segment |= (reinterpret_cast<const uint32_t *>(c)[13] & 3u) << 28;  // PBSGPU_RING_F_TIER_TAG
         out[(*n)++] = rec;
         s.cells.pop_front();
         s.records_out++;
@@ -840,6 +842,7 @@ int ring_create_internal(pbsgpu_engine *e, const pbsgpu_ring_options *opt, bool 
         r->fill_serial = (o.flags & PBSGPU_RING_F_FILL_SERIAL) != 0;
         r->dense_service = (o.flags & PBSGPU_RING_F_DENSE_SERVICE) != 0;
         r->dense_lanes = (o.flags & PBSGPU_RING_F_DENSE_LANES) != 0;
+        r->tier_tag = (o.flags & PBSGPU_RING_F_TIER_TAG) != 0;
         r->lone_defer_ms = o.lone_defer_ms < 0 ? 0.0 : o.lone_defer_ms > 0 ? o.lone_defer_ms : 25.0;
         r->idle_timeout_s = o.idle_timeout_s;
         r->opt_long_lo = o.long_lo_bytes;

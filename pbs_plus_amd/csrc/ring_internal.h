@@ -132,6 +132,7 @@ struct pbsgpu_ring {
     double idle_since_ms = 0;
     bool dense_service = false;           // PBSGPU_RING_F_DENSE_SERVICE
     bool dense_lanes = false;             // PBSGPU_RING_F_DENSE_LANES
+    bool tier_tag = false;                // PBSGPU_RING_F_TIER_TAG
     bool backlog_auto = true;             // backlog_limit derived from sha_cus (follows ring_adapt_split)
     uint32_t park_gen_seen = 0;           // last graveyard park request this ring honoured (engine_internal.h: dev_free)
     uint32_t park_grace_gen = 0;          // the park request this ring has already waited its grace period for (ring_start_service)
