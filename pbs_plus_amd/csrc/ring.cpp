@@ -1420,6 +1420,8 @@ int pbsgpu_ring_get_probe(pbsgpu_ring *r, pbsgpu_ring_probe *out) {
     }
     CHK(set_device(r->eng));
     HIPCHK(hipMemcpy(out, r->probe.p, sizeof(*out), hipMemcpyDeviceToHost));
+    std::memcpy(r->probe_seen, out, sizeof(*out));  // (the counters only grow: a later answer from a status block is never older)
+    r->probe_seen_valid = true;
     return PBSGPU_OK;
 }
 
