@@ -1071,7 +1071,11 @@ def ring_run(a, rank, local_rank, world, ctx):
     single_s = time.perf_counter() - ts0
     probe2 = ring.probe()
     if os.environ.get("PBS_BENCH_RING_DEBUG"):
-        sys.stderr.write("[ring debug] " + ring.debug().splitlines()[1] + "\n")
+        dbg = ring.debug().splitlines()
+        sys.stderr.write("[ring debug] " + dbg[1] + "\n")
+        for ln in dbg:
+            if ln.startswith("control kernel"):
+                sys.stderr.write("[ring debug] " + ln + "\n")
     state["S"] = s_saved
     out = None
     if rank == 0:

@@ -338,8 +338,12 @@ struct RingRoundStatus {   // mapped pinned: written last by a round
     // the services' probe counters (RingSource::probe, words 0..5) as this round found them: pbsgpu_ring_get_probe answers from
     // the newest reaped round while a service runs — no HIP call of the host beside a persistent kernel
     unsigned long long probe[6];
+    // wall-clock ticks (100 MHz) the control kernel spent in its phases: [0] tile prefix + compaction, [1] resolve walks,
+    // [2] numbering, [3] records -> cells / descriptors / page references, [4] publish (holds, releases, tail); [5] its start
+    // (low 32 bits of the wall clock). pbsgpu_ring_debug sums them per ring.
+    uint32_t phase_ticks[6];
 };
-static_assert(sizeof(RingRoundStatus) == 80, "host slot: 128 bytes (ring.cpp: input_stride)");
+static_assert(sizeof(RingRoundStatus) == 104, "host slot: 128 bytes (ring.cpp: input_stride)");
 struct RingRound {
     // geometry / constants
     uint8_t *arena;            // device: [pad | page 0 | pad][pad | page 1 | pad] ...

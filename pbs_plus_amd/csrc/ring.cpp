@@ -144,6 +144,11 @@ void ring_reap_rounds(pbsgpu_ring *r) {
             r->tail_seen = hs->tail;
             for (int i = 0; i < 6; ++i) r->probe_seen[i] = hs->probe[i];
             r->probe_seen_valid = true;
+            {   // the control kernel's phase times, summed per round size class (pbsgpu_ring_debug): small (< 100 pages) / large rounds
+                const int cls = ri.new_bytes < 100ull * r->page_bytes ? 0 : 1;
+                for (int i = 0; i < 5; ++i) r->ctl_phase_ticks[cls][i] += hs->phase_ticks[i];
+                r->ctl_phase_rounds[cls]++;
+            }
         }
         for (uint32_t s : ri.finals) r->slots[s].final_done = true;
         r->inflight_bytes -= ri.new_bytes;
@@ -1369,6 +1374,13 @@ int pbsgpu_ring_debug(pbsgpu_ring *r, char *buf, uint64_t cap) {
             "lanes_busy=%.3f (probe wave, intervals with a block in every step) express cus=%u\n",
             r->lanes_cus, r->short_bytes, ctl.stail, ctl.shead, pr[6], pr[6] ? (double)pr[7] * 10.0 / (double)pr[6] : 0.0,
             pr[6] ? (double)pr[9] / (64.0 * (double)pr[6]) : 0.0, r->sha_cus, pr[0] ? (double)pr[8] / (64.0 * (double)pr[0]) : 0.0, r->xp_cus);
+        for (int cls = 0; cls < 2; ++cls)
+            if (r->ctl_phase_rounds[cls])
+                put("control kernel, %s rounds: %llu rounds, us per round: tiles+compaction %.1f, resolve %.1f, numbering %.1f, records %.1f, publish %.1f\n",
+                    cls ? "large (>= 100 pages)" : "small (< 100 pages)", (unsigned long long)r->ctl_phase_rounds[cls],
+                    r->ctl_phase_ticks[cls][0] * 0.01 / r->ctl_phase_rounds[cls], r->ctl_phase_ticks[cls][1] * 0.01 / r->ctl_phase_rounds[cls],
+                    r->ctl_phase_ticks[cls][2] * 0.01 / r->ctl_phase_rounds[cls], r->ctl_phase_ticks[cls][3] * 0.01 / r->ctl_phase_rounds[cls],
+                    r->ctl_phase_ticks[cls][4] * 0.01 / r->ctl_phase_rounds[cls]);
         put("probe raw: pair_steps=%llu pair_active=%llu lanes_steps=%llu lanes_active=%llu\n", pr[0], pr[8], pr[6], pr[9]);
     }
     uint32_t nz = 0;

@@ -91,6 +91,8 @@ struct pbsgpu_ring {
     pbse::DevBuf arena, ctl, streams, pending, desc, ldesc, sdesc, probe;
     unsigned long long probe_seen[6] = {};  // the probe counters as the newest reaped round reported them (pbsgpu_ring_get_probe)
     bool probe_seen_valid = false;
+    unsigned long long ctl_phase_ticks[2][5] = {};  // k_ring_control's phase times summed over the reaped rounds (small / large rounds)
+    unsigned long long ctl_phase_rounds[2] = {};
     uint32_t lslots = 0, long_bytes = 0;
     uint32_t sslots = 0, short_bytes = 0, lanes_cus = 0;  // the LANES service and its short-chunk queue (kernels.h: RingSource::sdesc)
     pbse::DevBuf scalars, tile_cnt, tile_off, tile_slots, scan_tmp, dense, segs, seg_cnt, seg_off, recs, seg_newc, seg_open;
