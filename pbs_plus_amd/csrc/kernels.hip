@@ -549,6 +549,12 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
     const int lane = threadIdx.x & 63;
     uint64_t s = A;
     uint32_t k = 0;
+    // WRITE: record k waits in the registers of lane k mod 64 and 64 records leave with ONE store instruction. (Until round 6 lane 0
+    // stored every record as it was cut — and the loop's header waits for vmcnt(0), a loaded window may be pending there, which
+    // on this ISA also counts the stores: every record paid a store round trip, ~1.2 us beside the ring's streaming traffic;
+    // 87 of the control kernel's 147 us per round: profiles/r06_control_kernel_phases.log.)
+    [[maybe_unused]] uint64_t my_end = 0;
+    [[maybe_unused]] uint32_t my_size = 0;
     // coordinates of the suggested offsets / of the absolute reader grid: the segment start, or (ring) the stream's byte 0
     const uint64_t P = ring ? (A & ~kRingOffMask) : A;
     bool last_real = true;
@@ -634,11 +640,18 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
             }
         }
         if (WRITE) {
-            if (lane == 0 && rbase + k < rec_cap) {
-                pbsgpu_record *r = recs + rbase + k;
-                r->end = e - A;
-                r->segment = seg;
-                r->size = (uint32_t)(e - s);
+            if (lane == (int)(k & 63u)) {
+                my_end = e - A;
+                my_size = (uint32_t)(e - s);
+            }
+            if ((k & 63u) == 63u) {  // records k - 63 .. k
+                const uint64_t idx = rbase + (uint64_t)(k - 63u) + (uint64_t)lane;
+                if (idx < rec_cap) {
+                    pbsgpu_record *r = recs + idx;
+                    r->end = my_end;
+                    r->segment = seg;
+                    r->size = my_size;
+                }
             }
         }
         last_real = real;
@@ -646,6 +659,16 @@ __device__ __forceinline__ uint32_t resolve_walk(const uint64_t *cands, const ui
         last_ecand = ec;
         ++k;
         s = e;
+    }
+    if (WRITE) {  // the last, partial group
+        const uint32_t rest = k & 63u;
+        const uint64_t idx = rbase + (uint64_t)(k - rest) + (uint64_t)lane;
+        if ((uint32_t)lane < rest && idx < rec_cap) {
+            pbsgpu_record *r = recs + idx;
+            r->end = my_end;
+            r->segment = seg;
+            r->size = my_size;
+        }
     }
     *last_real_out = last_real;
     *last_start_out = last_start;
